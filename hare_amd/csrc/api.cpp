@@ -1,0 +1,731 @@
+// api.cpp -- the C-ABI of include/hare_hip.h: scene lifetime, device upload, kernel launches.
+// Product code; nothing from oracle/.  There is deliberately no CPU shoot path here.
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hare_hip.h"
+#include "scene.h"
+
+// the embedded gfx950 code object (embed.S)
+extern "C" const unsigned char hare_kernels_co[];
+extern "C" const unsigned char hare_kernels_co_end[];
+
+struct hare_scene : hare::Scene {};
+
+static_assert(sizeof(hare_ray) == sizeof(hare::RayRec), "hare_ray layout");
+static_assert(sizeof(hare_xevent) == sizeof(hare::XEventRec), "hare_xevent layout");
+static_assert(sizeof(hare_xevent) == 56 && sizeof(hare_ray) == 48, "wire sizes");
+static_assert(sizeof(hare_counters) == hare::CTR_WORDS * 8, "hare_counters layout");
+
+namespace hare {
+
+static thread_local std::string t_err;
+void set_error(const std::string& msg) { t_err = msg; }
+const char* last_error() { return t_err.c_str(); }
+
+namespace {
+
+const HipApi* api_or_err()
+{
+    std::string e;
+    const HipApi* h = hip_api(&e);
+    if (!h) set_error(e);
+    return h;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + " failed: " + (H->GetErrorString ? H->GetErrorString(_e) : "?")); \
+            return (_e == hipErrorOutOfMemory) ? HARE_E_NOMEM : HARE_E_HIP;                    \
+        }                                                                                      \
+    } while (0)
+
+std::mutex g_mod_mu;
+std::map<int, std::unique_ptr<DeviceModule>> g_modules;
+
+int get_module(const HipApi* H, int device, const DeviceModule** out)
+{
+    std::lock_guard<std::mutex> lk(g_mod_mu);
+    auto it = g_modules.find(device);
+    if (it != g_modules.end()) {
+        *out = it->second.get();
+        return HARE_OK;
+    }
+    HIP_TRY(H->SetDevice(device));
+    std::unique_ptr<DeviceModule> m(new DeviceModule());
+    HIP_TRY(H->ModuleLoadData(&m->mod, hare_kernels_co));
+    struct { const char* name; hipFunction_t* fn; } table[] = {
+        {"hare_voxel_shoot_tri", &m->voxel_tri},
+        {"hare_voxel_shoot_quad", &m->voxel_quad},
+        {"hare_voxel_shoot_count", &m->voxel_count},
+        {"hare_voxel_persist_tri", &m->voxel_persist_tri},
+        {"hare_voxel_persist_quad", &m->voxel_persist_quad},
+        {"hare_octree_shoot", &m->octree},
+        {"hare_octree_shoot_count", &m->octree_count},
+        {"hare_kdtree_shoot", &m->kdtree},
+        {"hare_kdtree_shoot_count", &m->kdtree_count},
+        {"hare_reflect", &m->reflect},
+    };
+    for (auto& t : table) {
+        hipError_t e = H->ModuleGetFunction(t.fn, m->mod, t.name);
+        if (e != hipSuccess) *t.fn = nullptr;   // optional kernels may be absent in a given build
+    }
+    if (!m->voxel_tri || !m->voxel_quad) {
+        set_error("embedded code object lacks hare_voxel_shoot_* (not a gfx950 device?)");
+        return HARE_E_HIP;
+    }
+    int cus = 0;
+    if (H->DeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+    m->cu_count = cus;
+    *out = m.get();
+    g_modules[device] = std::move(m);
+    return HARE_OK;
+}
+
+int dev_free(const HipApi* H, void*& p)
+{
+    if (p) (void)H->Free(p);
+    p = nullptr;
+    return 0;
+}
+
+int upload(const HipApi* H, void** dst, const void* src, size_t bytes)
+{
+    if (*dst) {
+        (void)H->Free(*dst);
+        *dst = nullptr;
+    }
+    HIP_TRY(H->Malloc(dst, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(H->Memcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return HARE_OK;
+}
+
+int ensure_device(Scene& s, const HipApi*& H)
+{
+    H = api_or_err();
+    if (!H) return HARE_E_NODEVICE;
+    int n = 0;
+    if (H->GetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible");
+        return HARE_E_NODEVICE;
+    }
+    if (s.device < 0 || s.device >= n) {
+        set_error("scene device ordinal out of range");
+        return HARE_E_INVALID;
+    }
+    HIP_TRY(H->SetDevice(s.device));
+    if (!s.module) {
+        int rc = get_module(H, s.device, &s.module);
+        if (rc) return rc;
+    }
+    if (!s.stream) HIP_TRY(H->StreamCreate(&s.stream));
+    if (!s.d_work) {
+        HIP_TRY(H->Malloc(&s.d_work, 256));
+        HIP_TRY(H->MemsetAsync(s.d_work, 0, 256, nullptr));
+    }
+    return HARE_OK;
+}
+
+int upload_polys(Scene& s, const HipApi* H)
+{
+    if (s.d_polys.size() == s.topos.size()) return HARE_OK;
+    s.d_polys.assign(s.topos.size(), nullptr);
+    for (size_t m = 0; m < s.topos.size(); ++m) {
+        const Topo& T = s.topos[m];
+        std::vector<PolyRec> rec((size_t)std::max(T.P, 1));
+        memset(rec.data(), 0, rec.size() * sizeof(PolyRec));
+        for (int32_t p = 0; p < T.P; ++p) {
+            const double* V = &T.verts[(size_t)p * 12];
+            PolyRec& r = rec[p];
+            for (int a = 0; a < 3; ++a) {
+                r.v0[a] = V[a];
+                r.v1[a] = V[3 + a];
+                r.v2[a] = V[6 + a];
+                r.v3[a] = T.nverts[p] == 4 ? V[9 + a] : 0.0;
+                r.n[a] = T.normals[(size_t)p * 3 + a];
+            }
+            r.nverts = T.nverts[p];
+        }
+        int rc = upload(H, &s.d_polys[m], rec.data(), rec.size() * sizeof(PolyRec));
+        if (rc) return rc;
+    }
+    return HARE_OK;
+}
+
+int upload_voxel(Scene& s, const HipApi* H)
+{
+    const VoxelHost& g = s.vox;
+    const size_t M = s.topos.size();
+    for (auto* v : {&s.d_cells, &s.d_items, &s.d_occ}) {
+        for (void*& p : *v) dev_free(H, p);
+        v->assign(M, nullptr);
+    }
+    const size_t ncell = (size_t)g.ct * g.ct * g.ct;
+    s.occ_words = (int32_t)((ncell + 31) / 32);
+    for (size_t m = 0; m < M; ++m) {
+        std::vector<CellRec> cells(ncell);
+        std::vector<uint32_t> occ((size_t)s.occ_words, 0u);
+        for (size_t c = 0; c < ncell; ++c) {
+            cells[c].start = g.start[m][c];
+            cells[c].count = g.start[m][c + 1] - g.start[m][c];
+            if (cells[c].count) occ[c >> 5] |= 1u << (c & 31);
+        }
+        int rc = upload(H, &s.d_cells[m], cells.data(), cells.size() * sizeof(CellRec));
+        if (rc) return rc;
+        rc = upload(H, &s.d_items[m], g.items[m].data(), g.items[m].size() * sizeof(int32_t));
+        if (rc) return rc;
+        rc = upload(H, &s.d_occ[m], occ.data(), occ.size() * sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    return HARE_OK;
+}
+
+int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, void** args)
+{
+    HIP_TRY(H->ModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, lds, st, args, nullptr));
+    return HARE_OK;
+}
+
+int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
+                      const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st)
+{
+    if (n < 0 || top < 0 || top >= (int32_t)s.topos.size()) {
+        set_error("hare_shoot: bad n or top_index");
+        return HARE_E_INVALID;
+    }
+    if (n == 0) return HARE_OK;
+    if (n > 0x7FFFFFFFll * 64) {
+        set_error("hare_shoot: batch too large");
+        return HARE_E_INVALID;
+    }
+    if (!d_rays || !d_out) {
+        set_error("hare_shoot: null rays/out");
+        return HARE_E_INVALID;
+    }
+    ShootIO io;
+    memset(&io, 0, sizeof io);
+    io.rays = (RayRec*)d_rays;
+    io.excl1 = (const int32_t*)d_e1;
+    io.excl2 = (const int32_t*)d_e2;
+    io.out = (XEventRec*)d_out;
+    io.ctr = (unsigned long long*)d_ctr;
+    io.work = (unsigned int*)s.d_work;
+    io.n = n;
+    io.flags = flags & 0xFFFFu;
+    const bool quads = s.topos[top].has_quads;
+    const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0;
+    const DeviceModule& M = *s.module;
+    const unsigned block = 256;
+    const unsigned grid = (unsigned)((n + block - 1) / block);
+
+    if (kind == HARE_KIND_VOXEL) {
+        if (!s.vox.built || s.d_cells.empty()) {
+            set_error("hare_shoot: voxel grid not built");
+            return HARE_E_STATE;
+        }
+        VoxelArgs g;
+        memset(&g, 0, sizeof g);
+        g.polys = (const PolyRec*)s.d_polys[top];
+        g.cells = (const CellRec*)s.d_cells[top];
+        g.items = (const int32_t*)s.d_items[top];
+        g.occ = (const uint32_t*)s.d_occ[top];
+        g.ct = s.vox.ct;
+        g.occ_words = s.occ_words;
+        for (int a = 0; a < 3; ++a) {
+            g.omin[a] = s.vox.omin[a];
+            g.omax[a] = s.vox.omax[a];
+            g.vd[a] = s.vox.vd[a];
+        }
+        hipFunction_t f = count ? M.voxel_count : (quads ? M.voxel_quad : M.voxel_tri);
+        if (!f) {
+            set_error("hare_shoot: kernel missing from code object");
+            return HARE_E_STATE;
+        }
+        void* args[] = {&g, &io};
+        return launch(H, f, grid, block, 0, st, args);
+    }
+    if (kind == HARE_KIND_OCTREE) {
+        if (!s.oct.built || !s.d_oct_nodes) {
+            set_error("hare_shoot: octree not built");
+            return HARE_E_STATE;
+        }
+        OctreeArgs g;
+        memset(&g, 0, sizeof g);
+        g.polys = (const PolyRec*)s.d_polys[top];
+        g.nodes = (const OctNode*)s.d_oct_nodes;
+        g.items = (const int32_t*)s.d_oct_items;
+        g.n_nodes = (int32_t)s.oct.nodes.size();
+        g.max_depth = s.oct.max_depth;
+        hipFunction_t f = count ? M.octree_count : M.octree;
+        if (!f) {
+            set_error("hare_shoot: octree kernel missing from code object");
+            return HARE_E_STATE;
+        }
+        void* args[] = {&g, &io};
+        return launch(H, f, grid, block, 0, st, args);
+    }
+    if (kind == HARE_KIND_KDTREE) {
+        if (!s.kd.built || !s.d_kd_nodes) {
+            set_error("hare_shoot: kd-tree not built");
+            return HARE_E_STATE;
+        }
+        KdArgs g;
+        memset(&g, 0, sizeof g);
+        g.polys = (const PolyRec*)s.d_polys[top];
+        g.nodes = (const KdNodeRec*)s.d_kd_nodes;
+        g.items = (const int32_t*)s.d_kd_items;
+        g.n_nodes = (int32_t)s.kd.nodes.size();
+        g.max_depth = s.kd.depth_reached;
+        hipFunction_t f = count ? M.kdtree_count : M.kdtree;
+        if (!f) {
+            set_error("hare_shoot: kd-tree kernel missing from code object");
+            return HARE_E_STATE;
+        }
+        void* args[] = {&g, &io};
+        return launch(H, f, grid, block, 0, st, args);
+    }
+    set_error("hare_shoot: unknown partition kind");
+    return HARE_E_INVALID;
+}
+
+}  // namespace
+}  // namespace hare
+
+using namespace hare;
+
+extern "C" {
+
+const char* hare_version(void) { return "hare_hip 0.1 (gfx950)"; }
+const char* hare_last_error(void) { return last_error(); }
+
+const char* hare_hip_runtime_path(void)
+{
+    const HipApi* H = api_or_err();
+    return H ? H->path.c_str() : "";
+}
+
+int hare_device_count(int32_t* count)
+{
+    if (!count) {
+        set_error("hare_device_count: null argument");
+        return HARE_E_INVALID;
+    }
+    *count = 0;
+    const HipApi* H = api_or_err();
+    if (!H) return HARE_E_NODEVICE;
+    int n = 0;
+    if (H->GetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return HARE_OK;
+}
+
+int hare_polygon_normals(const double* verts, const int32_t* nverts, int32_t P, double* normals_out)
+{
+    if (P < 0 || (P > 0 && (!verts || !nverts || !normals_out))) {
+        set_error("hare_polygon_normals: bad arguments");
+        return HARE_E_INVALID;
+    }
+    polygon_normals(verts, nverts, P, normals_out);
+    return HARE_OK;
+}
+
+int hare_topology_bounds(const double* verts, const int32_t* nverts, int32_t P, double mn[3], double mx[3])
+{
+    if (P < 0 || (P > 0 && (!verts || !nverts)) || !mn || !mx) {
+        set_error("hare_topology_bounds: bad arguments");
+        return HARE_E_INVALID;
+    }
+    topology_bounds(verts, nverts, P, mn, mx);
+    return HARE_OK;
+}
+
+int hare_scene_create(const hare_topology_desc* topos, int32_t n_topos, int32_t device, hare_scene** out)
+{
+    if (!out) {
+        set_error("hare_scene_create: null out");
+        return HARE_E_INVALID;
+    }
+    *out = nullptr;
+    if (!topos || n_topos < 1 || n_topos > 64 || device < 0) {
+        set_error("hare_scene_create: need 1..64 topologies and device >= 0");
+        return HARE_E_INVALID;
+    }
+    try {
+        std::unique_ptr<hare_scene> s(new hare_scene());
+        s->device = device;
+        s->topos.resize(n_topos);
+        for (int32_t m = 0; m < n_topos; ++m) {
+            const hare_topology_desc& d = topos[m];
+            if (d.P < 0 || (d.P > 0 && (!d.verts || !d.nverts || !d.normals))) {
+                set_error("hare_scene_create: topology with null arrays");
+                return HARE_E_INVALID;
+            }
+            Topo& T = s->topos[m];
+            T.P = d.P;
+            T.verts.assign(d.verts, d.verts + (size_t)d.P * 12);
+            T.nverts.assign(d.nverts, d.nverts + d.P);
+            T.normals.assign(d.normals, d.normals + (size_t)d.P * 3);
+            for (int a = 0; a < 3; ++a) {
+                T.mn[a] = d.min[a];
+                T.mx[a] = d.max[a];
+            }
+            for (int32_t p = 0; p < d.P; ++p) {
+                if (T.nverts[p] == 4) T.has_quads = true;
+                else if (T.nverts[p] != 3) {
+                    // Topology.Build_Topology throws NotImplementedException (Hare_Geometry_Topology.cs:298)
+                    set_error("Hare Does not yet support polygons of more than 4 sides.");
+                    return HARE_E_UNSUPPORTED;
+                }
+            }
+        }
+        *out = s.release();
+        return HARE_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("hare_scene_create: out of host memory");
+        return HARE_E_NOMEM;
+    } catch (...) {
+        set_error("hare_scene_create: unexpected failure");
+        return HARE_E_INVALID;
+    }
+}
+
+void hare_scene_destroy(hare_scene* s)
+{
+    if (!s) return;
+    std::string e;
+    const HipApi* H = hip_api(&e);
+    if (H && (s->module || s->stream)) {
+        (void)H->SetDevice(s->device);
+        if (s->stream) (void)H->StreamSynchronize(s->stream);
+        for (auto* v : {&s->d_polys, &s->d_cells, &s->d_items, &s->d_occ})
+            for (void*& p : *v) dev_free(H, p);
+        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_rays,
+                         &s->d_e1, &s->d_e2, &s->d_out, &s->d_ctr})
+            dev_free(H, *p);
+        if (s->stream) (void)H->StreamDestroy(s->stream);
+    }
+    delete s;
+}
+
+#define GUARD_BEGIN try {
+#define GUARD_END                                               \
+    }                                                           \
+    catch (const std::bad_alloc&)                               \
+    {                                                           \
+        set_error("out of host memory");                        \
+        return HARE_E_NOMEM;                                    \
+    }                                                           \
+    catch (...)                                                 \
+    {                                                           \
+        set_error("unexpected C++ exception");                  \
+        return HARE_E_INVALID;                                  \
+    }
+
+// After a host build: push the partition to the device when one is available.  Builds succeed
+// without a GPU (introspection works); shooting then fails with HARE_E_NODEVICE.
+static int sync_partition_to_device(hare_scene* s, int kind)
+{
+    std::string e;
+    const HipApi* H = hip_api(&e);
+    int n = 0;
+    if (!H || H->GetDeviceCount(&n) != hipSuccess || n <= 0) return HARE_OK;
+    int rc = ensure_device(*s, H);
+    if (rc) return rc;
+    rc = upload_polys(*s, H);
+    if (rc) return rc;
+    if (kind == HARE_KIND_VOXEL) return upload_voxel(*s, H);
+    if (kind == HARE_KIND_OCTREE) {
+        rc = upload(H, &s->d_oct_nodes, s->oct.nodes.data(), s->oct.nodes.size() * sizeof(OctNode));
+        if (rc) return rc;
+        return upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
+    }
+    rc = upload(H, &s->d_kd_nodes, s->kd.nodes.data(), s->kd.nodes.size() * sizeof(KdNodeRec));
+    if (rc) return rc;
+    return upload(H, &s->d_kd_items, s->kd.items.data(), s->kd.items.size() * sizeof(int32_t));
+}
+
+int hare_voxel_build(hare_scene* s, int32_t domain)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    int rc = build_voxel_fixed(*s, domain);
+    if (rc) return rc;
+    return sync_partition_to_device(s, HARE_KIND_VOXEL);
+    GUARD_END
+}
+
+int hare_voxel_build_adaptive(hare_scene* s, int32_t max_domain, int32_t avg_polys)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    int rc = build_voxel_adaptive(*s, max_domain, avg_polys);
+    if (rc) return rc;
+    return sync_partition_to_device(s, HARE_KIND_VOXEL);
+    GUARD_END
+}
+
+int hare_octree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    int rc = build_octree(*s, max_depth, max_polys);
+    if (rc) return rc;
+    return sync_partition_to_device(s, HARE_KIND_OCTREE);
+    GUARD_END
+}
+
+int hare_kdtree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    int rc = build_kdtree(*s, max_depth, max_polys);
+    if (rc) return rc;
+    return sync_partition_to_device(s, HARE_KIND_KDTREE);
+    GUARD_END
+}
+
+int hare_voxel_get_info(const hare_scene* s, hare_voxel_info* out)
+{
+    if (!s || !out) {
+        set_error("null argument");
+        return HARE_E_INVALID;
+    }
+    if (!s->vox.built) {
+        set_error("voxel grid not built");
+        return HARE_E_STATE;
+    }
+    memset(out, 0, sizeof *out);
+    out->ct = s->vox.ct;
+    out->n_topos = (int32_t)s->topos.size();
+    for (int a = 0; a < 3; ++a) {
+        out->obox_min[a] = s->vox.omin[a];
+        out->obox_max[a] = s->vox.omax[a];
+        out->box_dims[a] = s->vox.box_dims[a];
+        out->voxel_dims[a] = s->vox.vd[a];
+    }
+    out->char_step = s->vox.char_step;
+    out->total_items = s->vox.items[0].size();
+    return HARE_OK;
+}
+
+int hare_voxel_get_lists(const hare_scene* s, int32_t top, uint32_t* cell_start, int32_t* items)
+{
+    if (!s || !cell_start || top < 0 || top >= (int32_t)s->topos.size()) {
+        set_error("bad argument");
+        return HARE_E_INVALID;
+    }
+    if (!s->vox.built) {
+        set_error("voxel grid not built");
+        return HARE_E_STATE;
+    }
+    memcpy(cell_start, s->vox.start[top].data(), s->vox.start[top].size() * sizeof(uint32_t));
+    if (items && !s->vox.items[top].empty())
+        memcpy(items, s->vox.items[top].data(), s->vox.items[top].size() * sizeof(int32_t));
+    return HARE_OK;
+}
+
+int hare_octree_get_info(const hare_scene* s, hare_tree_info* out)
+{
+    if (!s || !out) {
+        set_error("null argument");
+        return HARE_E_INVALID;
+    }
+    if (!s->oct.built) {
+        set_error("octree not built");
+        return HARE_E_STATE;
+    }
+    memset(out, 0, sizeof *out);
+    out->n_nodes = (int32_t)s->oct.nodes.size();
+    out->max_depth = s->oct.max_depth;
+    out->max_polys = s->oct.max_polys;
+    out->total_items = s->oct.items.size();
+    return HARE_OK;
+}
+
+int hare_octree_get_nodes(const hare_scene* s, double* boxes, int32_t* first_child, int32_t* item_start,
+                          int32_t* item_count, int32_t* items)
+{
+    if (!s || !boxes || !first_child || !item_start || !item_count || !items) {
+        set_error("null argument");
+        return HARE_E_INVALID;
+    }
+    if (!s->oct.built) {
+        set_error("octree not built");
+        return HARE_E_STATE;
+    }
+    for (size_t i = 0; i < s->oct.nodes.size(); ++i) {
+        const OctNode& n = s->oct.nodes[i];
+        for (int a = 0; a < 3; ++a) {
+            boxes[6 * i + a] = n.bmin[a];
+            boxes[6 * i + 3 + a] = n.bmax[a];
+        }
+        first_child[i] = n.first_child;
+        item_start[i] = n.item_start;
+        item_count[i] = n.item_count;
+    }
+    if (!s->oct.items.empty()) memcpy(items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
+    return HARE_OK;
+}
+
+int hare_kdtree_get_info(const hare_scene* s, hare_tree_info* out)
+{
+    if (!s || !out) {
+        set_error("null argument");
+        return HARE_E_INVALID;
+    }
+    if (!s->kd.built) {
+        set_error("kd-tree not built");
+        return HARE_E_STATE;
+    }
+    memset(out, 0, sizeof *out);
+    out->n_nodes = (int32_t)s->kd.nodes.size();
+    out->max_depth = s->kd.max_depth;
+    out->max_polys = s->kd.max_polys;
+    out->total_items = s->kd.items.size();
+    return HARE_OK;
+}
+
+int hare_kdtree_get_nodes(const hare_scene* s, double* boxes, double* split, int32_t* axis, int32_t* left,
+                          int32_t* right, int32_t* item_start, int32_t* item_count, int32_t* items)
+{
+    if (!s || !boxes || !split || !axis || !left || !right || !item_start || !item_count || !items) {
+        set_error("null argument");
+        return HARE_E_INVALID;
+    }
+    if (!s->kd.built) {
+        set_error("kd-tree not built");
+        return HARE_E_STATE;
+    }
+    for (size_t i = 0; i < s->kd.nodes.size(); ++i) {
+        const KdNodeRec& n = s->kd.nodes[i];
+        for (int a = 0; a < 3; ++a) {
+            boxes[6 * i + a] = n.bmin[a];
+            boxes[6 * i + 3 + a] = n.bmax[a];
+        }
+        split[i] = n.split;
+        axis[i] = n.left < 0 ? 0 : n.axis;   // the C# field defaults to 0 on leaves
+        left[i] = n.left;
+        right[i] = n.right;
+        item_start[i] = n.item_start;
+        item_count[i] = n.item_count;
+    }
+    if (!s->kd.items.empty()) memcpy(items, s->kd.items.data(), s->kd.items.size() * sizeof(int32_t));
+    return HARE_OK;
+}
+
+int hare_shoot_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, void* d_rays, const void* d_excl1,
+                      const void* d_excl2, uint32_t flags, void* d_out, void* d_counters, void* stream)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    const HipApi* H = nullptr;
+    if (!s->module) {
+        int rc = ensure_device(*s, H);
+        if (rc) return rc;
+    } else {
+        H = api_or_err();
+        if (!H) return HARE_E_NODEVICE;
+    }
+    return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_out, d_counters,
+                             (hipStream_t)stream);
+    GUARD_END
+}
+
+int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays, const int32_t* excl1,
+                     const int32_t* excl2, uint32_t flags, hare_xevent* out, hare_counters* ctr)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    if (n < 0 || (n > 0 && (!rays || !out))) {
+        set_error("hare_shoot_batch: bad arguments");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    std::lock_guard<std::mutex> lk(s->mu);
+    const HipApi* H = nullptr;
+    int rc = ensure_device(*s, H);
+    if (rc) return rc;
+    if (ctr) memset(ctr, 0, sizeof *ctr);
+    if (n == 0) return HARE_OK;
+    if (n > s->staged_cap) {
+        for (void** p : {&s->d_rays, &s->d_e1, &s->d_e2, &s->d_out}) dev_free(H, *p);
+        s->staged_cap = 0;
+        HIP_TRY(H->Malloc(&s->d_rays, (size_t)n * sizeof(hare_ray)));
+        HIP_TRY(H->Malloc(&s->d_e1, (size_t)n * sizeof(int32_t)));
+        HIP_TRY(H->Malloc(&s->d_e2, (size_t)n * sizeof(int32_t)));
+        HIP_TRY(H->Malloc(&s->d_out, (size_t)n * sizeof(hare_xevent)));
+        s->staged_cap = n;
+    }
+    if (!s->d_ctr) HIP_TRY(H->Malloc(&s->d_ctr, sizeof(hare_counters)));
+    hipStream_t st = s->stream;
+    HIP_TRY(H->MemcpyAsync(s->d_rays, rays, (size_t)n * sizeof(hare_ray), hipMemcpyHostToDevice, st));
+    if (excl1) HIP_TRY(H->MemcpyAsync(s->d_e1, excl1, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (excl2) HIP_TRY(H->MemcpyAsync(s->d_e2, excl2, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(H->MemsetAsync(s->d_ctr, 0, sizeof(hare_counters), st));
+    rc = shoot_device_impl(*s, H, kind, top_index, n, s->d_rays, excl1 ? s->d_e1 : nullptr, excl2 ? s->d_e2 : nullptr,
+                           flags, s->d_out, s->d_ctr, st);
+    if (rc) return rc;
+    HIP_TRY(H->MemcpyAsync(out, s->d_out, (size_t)n * sizeof(hare_xevent), hipMemcpyDeviceToHost, st));
+    if (flags & HARE_SHOOT_WRITEBACK_ORIGIN)
+        HIP_TRY(H->MemcpyAsync(rays, s->d_rays, (size_t)n * sizeof(hare_ray), hipMemcpyDeviceToHost, st));
+    if (ctr) HIP_TRY(H->MemcpyAsync(ctr, s->d_ctr, sizeof(hare_counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(H->StreamSynchronize(st));
+    return HARE_OK;
+    GUARD_END
+}
+
+int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_rays, const void* d_events,
+                        void* d_excl_out, void* stream)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    if (n < 0 || top_index < 0 || top_index >= (int32_t)s->topos.size() || (n > 0 && (!d_rays || !d_events || !d_excl_out))) {
+        set_error("hare_reflect_device: bad arguments");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    const HipApi* H = nullptr;
+    int rc = ensure_device(*s, H);
+    if (rc) return rc;
+    rc = upload_polys(*s, H);
+    if (rc) return rc;
+    if (n == 0) return HARE_OK;
+    if (!s->module->reflect) {
+        set_error("hare_reflect_device: kernel missing from code object");
+        return HARE_E_STATE;
+    }
+    const void* polys = s->d_polys[top_index];
+    void* args[] = {&polys, &d_rays, &d_events, &d_excl_out, &n};
+    const unsigned block = 256;
+    return launch(H, s->module->reflect, (unsigned)((n + block - 1) / block), block, 0, (hipStream_t)stream, args);
+    GUARD_END
+}
+
+}  // extern "C"

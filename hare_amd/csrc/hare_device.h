@@ -1,0 +1,92 @@
+// hare_device.h -- kernel argument blocks shared by the host library (g++) and the gfx950
+// kernels (hipcc).  Plain data only.  Product code; nothing from oracle/.
+#pragma once
+#include <stdint.h>
+#include "hare_math.h"
+
+namespace hare {
+
+// Wire records of the C-ABI (include/hare_hip.h); duplicated here as plain structs so kernels do
+// not include the public header.  Layout checked against the ABI in api.cpp.
+struct RayRec {            // Hare.Geometry.Ray: Hare_Geometry_Primitives.cs:393-429
+    double x, y, z, dx, dy, dz;
+};
+struct XEventRec {         // Hare.Geometry.X_Event: Hare_Geometry_Primitives.cs:435-481
+    double t, u, v, x, y, z;
+    int32_t poly_id;
+    int32_t hit;
+};
+static_assert(sizeof(RayRec) == 48, "ray wire size");
+static_assert(sizeof(XEventRec) == 56, "x_event wire size");
+
+struct CellRec {           // one grid cell: [start, start+count) into items
+    uint32_t start;
+    uint32_t count;
+};
+
+enum : uint32_t {
+    SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
+    SHOOT_ALL_TRIS = 1u << 16,    // internal: topology has no quads
+};
+
+// Device counters (one block per scene, accumulated with atomics; 8 x u64)
+enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_WORDS = 8 };
+
+struct VoxelArgs {
+    const PolyRec* polys;
+    const CellRec* cells;      // ct^3, cell = (x*ct + y)*ct + z
+    const int32_t* items;
+    const uint32_t* occ;       // ct^3 bits: cell non-empty
+    int32_t ct;
+    int32_t occ_words;
+    double omin[3], omax[3];   // OBox
+    double vd[3];              // VoxelDims
+};
+
+struct OctNode {               // 64 bytes
+    double bmin[3], bmax[3];
+    int32_t first_child;       // -1 leaf
+    int32_t item_start;
+    int32_t item_count;
+    int32_t pad;
+};
+static_assert(sizeof(OctNode) == 64, "octree node size");
+
+struct OctreeArgs {
+    const PolyRec* polys;
+    const OctNode* nodes;
+    const int32_t* items;
+    int32_t n_nodes;
+    int32_t max_depth;
+};
+
+struct KdNodeRec {             // 80 bytes
+    double bmin[3], bmax[3];
+    double split;
+    int32_t axis;
+    int32_t left, right;       // -1,-1 leaf
+    int32_t item_start, item_count;
+    int32_t pad;
+};
+
+struct KdArgs {
+    const PolyRec* polys;
+    const KdNodeRec* nodes;
+    const int32_t* items;
+    int32_t n_nodes;
+    int32_t max_depth;
+};
+
+struct ShootIO {
+    RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN
+    const int32_t* excl1;      // nullable: poly_origin1 per ray
+    const int32_t* excl2;      // nullable: poly_origin2 per ray
+    XEventRec* out;            // n
+    unsigned long long* ctr;   // nullable: CTR_WORDS counters, atomically accumulated
+    unsigned int* work;        // persistent kernels: next-ray ticket (zeroed before launch)
+    int64_t n;
+    uint32_t flags;
+    uint32_t pad;
+};
+
+}  // namespace hare

@@ -1,0 +1,97 @@
+// hiprt.cpp -- run-time binding of the HIP runtime (see hiprt.h).
+#include "hiprt.h"
+
+#include <dlfcn.h>
+#include <link.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+
+namespace hare {
+namespace {
+
+int find_loaded_cb(struct dl_phdr_info* info, size_t, void* data)
+{
+    if (info->dlpi_name && strstr(info->dlpi_name, "libamdhip64.so")) {
+        *static_cast<std::string*>(data) = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
+
+HipApi g_api;
+bool g_ok = false;
+std::string g_err;
+std::once_flag g_once;
+
+template <class F>
+bool bind(void* h, const char* name, F& fn, std::string& err)
+{
+    void* p = dlsym(h, name);
+    if (!p) {
+        err = std::string("HIP runtime lacks symbol ") + name;
+        return false;
+    }
+    fn = reinterpret_cast<F>(p);
+    return true;
+}
+
+void do_bind()
+{
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_cb, &loaded);
+    void* h = nullptr;
+    std::string tried;
+    auto attempt = [&](const std::string& p) {
+        if (h || p.empty()) return;
+        h = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        if (h) g_api.path = p;
+        else tried += p + " ";
+    };
+    attempt(loaded);
+    if (const char* e = getenv("HARE_HIP_RUNTIME")) attempt(e);
+    attempt("libamdhip64.so.7");
+    attempt("libamdhip64.so");
+    if (const char* r = getenv("ROCM_PATH")) attempt(std::string(r) + "/lib/libamdhip64.so");
+    attempt("/opt/rocm/lib/libamdhip64.so");
+    if (!h) {
+        g_err = "cannot load a HIP runtime (tried: " + tried + ")";
+        return;
+    }
+    std::string e;
+    bool ok = bind(h, "hipGetDeviceCount", g_api.GetDeviceCount, e) && bind(h, "hipSetDevice", g_api.SetDevice, e) &&
+              bind(h, "hipGetDevice", g_api.GetDevice, e) &&
+              bind(h, "hipDeviceGetAttribute", g_api.DeviceGetAttribute, e) && bind(h, "hipMalloc", g_api.Malloc, e) &&
+              bind(h, "hipFree", g_api.Free, e) && bind(h, "hipMemcpy", g_api.Memcpy, e) &&
+              bind(h, "hipMemcpyAsync", g_api.MemcpyAsync, e) && bind(h, "hipMemsetAsync", g_api.MemsetAsync, e) &&
+              bind(h, "hipStreamCreate", g_api.StreamCreate, e) && bind(h, "hipStreamDestroy", g_api.StreamDestroy, e) &&
+              bind(h, "hipStreamSynchronize", g_api.StreamSynchronize, e) &&
+              bind(h, "hipDeviceSynchronize", g_api.DeviceSynchronize, e) &&
+              bind(h, "hipModuleLoadData", g_api.ModuleLoadData, e) && bind(h, "hipModuleUnload", g_api.ModuleUnload, e) &&
+              bind(h, "hipModuleGetFunction", g_api.ModuleGetFunction, e) &&
+              bind(h, "hipModuleLaunchKernel", g_api.ModuleLaunchKernel, e) &&
+              bind(h, "hipGetErrorString", g_api.GetErrorString, e) && bind(h, "hipEventCreate", g_api.EventCreate, e) &&
+              bind(h, "hipEventDestroy", g_api.EventDestroy, e) && bind(h, "hipEventRecord", g_api.EventRecord, e) &&
+              bind(h, "hipEventSynchronize", g_api.EventSynchronize, e) &&
+              bind(h, "hipEventElapsedTime", g_api.EventElapsedTime, e) && bind(h, "hipHostMalloc", g_api.HostMalloc, e) &&
+              bind(h, "hipHostFree", g_api.HostFree, e);
+    if (!ok) {
+        g_err = e + " (" + g_api.path + ")";
+        return;
+    }
+    g_ok = true;
+}
+
+}  // namespace
+
+const HipApi* hip_api(std::string* err)
+{
+    std::call_once(g_once, do_bind);
+    if (!g_ok) {
+        if (err) *err = g_err;
+        return nullptr;
+    }
+    return &g_api;
+}
+
+}  // namespace hare

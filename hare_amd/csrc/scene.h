@@ -1,0 +1,101 @@
+// scene.h -- host-side scene object behind the opaque hare_scene* of include/hare_hip.h.
+// Product code; nothing from oracle/.
+#pragma once
+#include <stdint.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hare_device.h"
+#include "hiprt.h"
+
+namespace hare {
+
+struct Topo {
+    int32_t P = 0;
+    std::vector<double> verts;    // P x 12
+    std::vector<int32_t> nverts;  // P
+    std::vector<double> normals;  // P x 3
+    double mn[3], mx[3];          // Topology.Min / Max
+    bool has_quads = false;
+};
+
+struct VoxelHost {
+    bool built = false;
+    int32_t ct = 0;
+    double omin[3], omax[3], box_dims[3], vd[3];
+    double char_step = 0;
+    std::vector<std::vector<uint32_t>> start;  // [topo][ct^3 + 1]
+    std::vector<std::vector<int32_t>> items;   // [topo][...]
+};
+
+struct OctreeHost {
+    bool built = false;
+    int32_t max_depth = 0, max_polys = 0;
+    std::vector<OctNode> nodes;
+    std::vector<int32_t> items;
+};
+
+struct KdHost {
+    bool built = false;
+    int32_t max_depth = 0, max_polys = 0;
+    int32_t depth_reached = 0;
+    std::vector<KdNodeRec> nodes;
+    std::vector<int32_t> items;
+};
+
+struct DeviceModule {
+    hipModule_t mod = nullptr;
+    hipFunction_t voxel_tri = nullptr, voxel_quad = nullptr, voxel_count = nullptr;
+    hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
+    hipFunction_t octree = nullptr, octree_count = nullptr;
+    hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
+    hipFunction_t reflect = nullptr;
+    int cu_count = 0;
+};
+
+struct Scene {
+    int device = 0;
+    std::vector<Topo> topos;
+    VoxelHost vox;
+    OctreeHost oct;
+    KdHost kd;
+
+    // device residents (all on `device`)
+    std::vector<void*> d_polys;                  // per topo: PolyRec[P]
+    std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
+    int32_t occ_words = 0;
+    void* d_oct_nodes = nullptr;
+    void* d_oct_items = nullptr;
+    void* d_kd_nodes = nullptr;
+    void* d_kd_items = nullptr;
+    void* d_work = nullptr;                      // ticket counters for persistent kernels (256 B)
+
+    // staging for hare_shoot_batch (guarded by mu)
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    void* d_rays = nullptr;
+    void* d_e1 = nullptr;
+    void* d_e2 = nullptr;
+    void* d_out = nullptr;
+    void* d_ctr = nullptr;
+    int64_t staged_cap = 0;
+
+    const DeviceModule* module = nullptr;
+};
+
+// error plumbing (thread-local message)
+void set_error(const std::string& msg);
+const char* last_error();
+
+// builders (host); return HARE_* codes
+int build_voxel_fixed(Scene& s, int32_t domain);
+int build_voxel_adaptive(Scene& s, int32_t max_domain, int32_t avg_polys);
+int build_octree(Scene& s, int32_t max_depth, int32_t max_polys);
+int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys);
+
+// host helpers
+void polygon_normals(const double* verts, const int32_t* nverts, int32_t P, double* out);
+void topology_bounds(const double* verts, const int32_t* nverts, int32_t P, double mn[3], double mx[3]);
+
+}  // namespace hare

@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's interface for the ray-cast path, over the C-ABI.
+
+Same names, argument meaning and error behaviour as Hare.Geometry's
+  Ray / X_Event            Hare_Geometry_Primitives.cs:393-481
+  Topology (the members a partition reads)   Hare_Geometry_Topology.cs:418-424, :482, :539, :50/:58
+  Spatial_Partition        Spatial_Partition.cs:27-35
+  Voxel_Grid / Octree / KDTree constructors  Voxel_Grid.cs:48,128  "Octree - alt.cs":45  KDTree.cs:51
+so the parity tests read like calls into the reference.  Every Shoot runs the HIP kernels through
+libhare_hip.so; there is no Python or CPU implementation of the path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import KIND_KDTREE, KIND_OCTREE, KIND_VOXEL, RAY_DTYPE, XEVENT_DTYPE, check, lib, ptr
+
+
+class Ray:
+    """Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429)."""
+
+    __slots__ = ("x", "y", "z", "dx", "dy", "dz", "ThreadID", "Ray_ID", "poly_origin1", "poly_origin2")
+
+    def __init__(self, x, y, z, dx, dy, dz, ThreadID_IN: int = 0, ID: int = 0):
+        self.x, self.y, self.z = float(x), float(y), float(z)
+        self.dx, self.dy, self.dz = float(dx), float(dy), float(dz)
+        self.ThreadID, self.Ray_ID = int(ThreadID_IN), int(ID)
+        self.poly_origin1 = self.poly_origin2 = 0
+
+    def Reverse(self):
+        self.dx *= -1
+        self.dy *= -1
+        self.dz *= -1
+
+
+class X_Event:
+    """Hare.Geometry.X_Event (Hare_Geometry_Primitives.cs:435-481)."""
+
+    __slots__ = ("u", "v", "t", "Hit", "X_Point", "Poly_id")
+
+    def __init__(self, P=None, u_in=0.0, v_in=0.0, t_in=0.0, Poly_index=-1):
+        if P is None:           # X_Event(): :454-462
+            self.u = self.v = self.t = 0.0
+            self.Hit = False
+            self.X_Point = None
+            self.Poly_id = -1
+        else:                   # X_Event(Point, u, v, t, Poly_index): :472-480
+            self.u, self.v, self.t = float(u_in), float(v_in), float(t_in)
+            self.Hit = True
+            self.X_Point = tuple(float(c) for c in P)
+            self.Poly_id = int(Poly_index)
+
+    @staticmethod
+    def from_record(r) -> "X_Event":
+        if r["hit"]:
+            return X_Event((r["x"], r["y"], r["z"]), r["u"], r["v"], r["t"], r["poly_id"])
+        return X_Event()
+
+
+class Topology:
+    """The part of Hare.Geometry.Topology a Spatial_Partition reads: polygons with their corner
+    coordinates, unit normals and the Min/Max box (after Finish_Topology).  Normals and bounds are
+    computed by the library's restatements of the Polygon ctor / Finish_Topology."""
+
+    def __init__(self, verts, nverts=None, normals=None, Min=None, Max=None):
+        v = np.ascontiguousarray(verts, np.float64)
+        if v.ndim == 3 and v.shape[1] == 3:      # [P,3,3] triangles
+            w = np.zeros((v.shape[0], 4, 3), np.float64)
+            w[:, :3] = v
+            v = w
+        self.verts = np.ascontiguousarray(v.reshape(-1, 4, 3))
+        P = self.verts.shape[0]
+        self.nverts = np.full(P, 3, np.int32) if nverts is None else np.ascontiguousarray(nverts, np.int32)
+        if self.nverts.shape != (P,):
+            raise ValueError("nverts must have one entry per polygon")
+        if normals is None:
+            normals = np.zeros((P, 3), np.float64)
+            check(lib.hare_polygon_normals(ptr(self.verts), ptr(self.nverts), P, ptr(normals)))
+        self.normals = np.ascontiguousarray(normals, np.float64)
+        if Min is None or Max is None:
+            Min = np.zeros(3)
+            Max = np.zeros(3)
+            check(lib.hare_topology_bounds(ptr(self.verts), ptr(self.nverts), P, ptr(Min), ptr(Max)))
+        self.Min = np.ascontiguousarray(Min, np.float64)
+        self.Max = np.ascontiguousarray(Max, np.float64)
+
+    @property
+    def Polygon_Count(self) -> int:
+        return int(self.verts.shape[0])
+
+    def Normal(self, Poly_ID: int):
+        return tuple(self.normals[Poly_ID])
+
+    def __getitem__(self, key):
+        poly, corner = key
+        return tuple(self.verts[poly, corner])
+
+    def Polygon_Vertices(self, Poly_ID: int):
+        return [tuple(self.verts[Poly_ID, c]) for c in range(int(self.nverts[Poly_ID]))]
+
+    def _desc(self) -> capi.TopologyDesc:
+        d = capi.TopologyDesc()
+        d.P = self.Polygon_Count
+        d.verts = ptr(self.verts)
+        d.nverts = ptr(self.nverts)
+        d.normals = ptr(self.normals)
+        for a in range(3):
+            d.min[a] = self.Min[a]
+            d.max[a] = self.Max[a]
+        return d
+
+
+class Spatial_Partition:
+    """Hare.Geometry.Spatial_Partition (Spatial_Partition.cs:27-35) over a native scene."""
+
+    _kind = -1
+
+    def __init__(self, Model_in: Sequence[Topology], device: int = 0):
+        self.Model = list(Model_in)
+        self.Char_Step = 0.0
+        descs = (capi.TopologyDesc * len(self.Model))(*[t._desc() for t in self.Model])
+        h = C.c_void_p()
+        check(lib.hare_scene_create(descs, len(self.Model), int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.hare_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # bool Shoot(Ray R, int top_index, out X_Event Ret_event[, int poly_origin1, int poly_origin2 = -1])
+    def Shoot(self, R: Ray, top_index: int, poly_origin1: int = -1, poly_origin2: int = -1):
+        rays = np.array([[R.x, R.y, R.z, R.dx, R.dy, R.dz]], np.float64)
+        ev, _ = self.Shoot_batch(rays, top_index, np.array([poly_origin1], np.int32), np.array([poly_origin2], np.int32),
+                                 writeback_origin=True)
+        R.x, R.y, R.z = (float(c) for c in rays[0, :3])   # the reference moves R when it starts outside (F11)
+        e = X_Event.from_record(ev[0])
+        return e.Hit, e
+
+    def Shoot_batch(self, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
+                    writeback_origin: bool = False, count_work: bool = False):
+        """n rays [n,6] through the HIP kernel (host buffers).  Returns (events, counters dict).
+        With writeback_origin the rays array is updated in place like the reference mutates R."""
+        if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
+            rays = np.array(rays, np.float64, order="C")
+        rays = rays.reshape(-1, 6)
+        n = rays.shape[0]
+        out = np.zeros(n, XEVENT_DTYPE)
+        e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
+        e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
+        for e in (e1, e2):
+            if e is not None and e.shape != (n,):
+                raise ValueError("poly_origin arrays must have one entry per ray")
+        flags = (capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0) | (capi.SHOOT_COUNT_WORK if count_work else 0)
+        ctr = capi.Counters()
+        check(lib.hare_shoot_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), flags,
+                                   ptr(out), C.addressof(ctr)))
+        return out, ctr.as_dict()
+
+    def shoot_device(self, n: int, d_rays: int, d_out: int, top_index: int = 0, d_excl1: int = 0, d_excl2: int = 0,
+                     d_counters: int = 0, stream: int = 0, flags: int = 0):
+        """Device-resident shoot: raw device addresses (e.g. torch.Tensor.data_ptr()) + a hipStream_t."""
+        check(lib.hare_shoot_device(self._h, self._kind, int(top_index), int(n), d_rays or None, d_excl1 or None,
+                                    d_excl2 or None, int(flags), d_out or None, d_counters or None, stream or None))
+
+    def reflect_device(self, n: int, d_rays: int, d_events: int, d_excl_out: int, top_index: int = 0, stream: int = 0):
+        check(lib.hare_reflect_device(self._h, int(top_index), int(n), d_rays, d_events, d_excl_out, stream or None))
+
+
+class Voxel_Grid(Spatial_Partition):
+    """Voxel_Grid(Topology[] Model_in, int Domain) / (Topology[] Model_in, int MaxDomain, int Avg_polys)
+    (Voxel_Grid.cs:48, :128)."""
+
+    _kind = KIND_VOXEL
+
+    def __init__(self, Model_in, Domain: int, Avg_polys: Optional[int] = None, device: int = 0):
+        super().__init__(Model_in, device)
+        if Avg_polys is None:
+            check(lib.hare_voxel_build(self._h, int(Domain)))
+        else:
+            check(lib.hare_voxel_build_adaptive(self._h, int(Domain), int(Avg_polys)))
+        info = self.info()
+        self.Char_Step = info.char_step
+        self.VoxelCt = info.ct
+
+    def info(self) -> capi.VoxelInfo:
+        i = capi.VoxelInfo()
+        check(lib.hare_voxel_get_info(self._h, C.addressof(i)))
+        return i
+
+    # public members of the reference class
+    @property
+    def Xdim(self):
+        return self.info().box_dims[0]
+
+    @property
+    def Ydim(self):
+        return self.info().box_dims[1]
+
+    @property
+    def Zdim(self):
+        return self.info().box_dims[2]
+
+    @property
+    def MinPt(self):
+        return tuple(self.info().obox_min)
+
+    def PointInVoxel(self, Pt):
+        """Voxel_Grid.PointInVoxel(Point, out X, out Y, out Z) (Voxel_Grid.cs:322-327)."""
+        i = self.info()
+        return tuple(int(np.floor((Pt[a] - i.obox_min[a]) / i.voxel_dims[a])) for a in range(3))
+
+    def VoxelCode(self, X: int, Y: int, Z: int) -> int:
+        """Voxel_Grid.VoxelCode (Voxel_Grid.cs:264-267): XYTot * Z + VoxelCtY * X + Y."""
+        ct = self.VoxelCt
+        return ct * ct * Z + ct * X + Y
+
+    def Voxel_Inv(self, top_index: int = 0):
+        """Voxel_Inv[x,y,z,top] as CSR (cell = (x*ct + y)*ct + z)."""
+        i = self.info()
+        n = i.ct ** 3
+        start = np.zeros(n + 1, np.uint32)
+        check(lib.hare_voxel_get_lists(self._h, int(top_index), ptr(start), None))
+        items = np.zeros(max(1, int(start[-1])), np.int32)
+        check(lib.hare_voxel_get_lists(self._h, int(top_index), ptr(start), ptr(items)))
+        return start, items[: int(start[-1])]
+
+
+class Octree(Spatial_Partition):
+    """Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) ("Octree - alt.cs":45)."""
+
+    _kind = KIND_OCTREE
+
+    def __init__(self, Model_In, maxDepth: int, maxPolygonsPerNode: int, device: int = 0):
+        super().__init__(Model_In, device)
+        check(lib.hare_octree_build(self._h, int(maxDepth), int(maxPolygonsPerNode)))
+
+    def info(self) -> capi.TreeInfo:
+        i = capi.TreeInfo()
+        check(lib.hare_octree_get_info(self._h, C.addressof(i)))
+        return i
+
+    def nodes(self):
+        i = self.info()
+        n, tot = i.n_nodes, int(i.total_items)
+        boxes = np.zeros((n, 6))
+        fc = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        cn = np.zeros(n, np.int32)
+        items = np.zeros(max(tot, 1), np.int32)
+        check(lib.hare_octree_get_nodes(self._h, ptr(boxes), ptr(fc), ptr(st), ptr(cn), ptr(items)))
+        return boxes, fc, st, cn, items[:tot]
+
+
+class KDTree(Spatial_Partition):
+    """KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) (KDTree.cs:51)."""
+
+    _kind = KIND_KDTREE
+
+    def __init__(self, Model_In, maxDepth: int, maxPolygonsPerNode: int, device: int = 0):
+        super().__init__(Model_In, device)
+        check(lib.hare_kdtree_build(self._h, int(maxDepth), int(maxPolygonsPerNode)))
+
+    def info(self) -> capi.TreeInfo:
+        i = capi.TreeInfo()
+        check(lib.hare_kdtree_get_info(self._h, C.addressof(i)))
+        return i
+
+    def nodes(self):
+        i = self.info()
+        n, tot = i.n_nodes, int(i.total_items)
+        boxes = np.zeros((n, 6))
+        split = np.zeros(n)
+        axis = np.zeros(n, np.int32)
+        left = np.zeros(n, np.int32)
+        right = np.zeros(n, np.int32)
+        st = np.zeros(n, np.int32)
+        cn = np.zeros(n, np.int32)
+        items = np.zeros(max(tot, 1), np.int32)
+        check(lib.hare_kdtree_get_nodes(self._h, ptr(boxes), ptr(split), ptr(axis), ptr(left), ptr(right), ptr(st),
+                                        ptr(cn), ptr(items)))
+        return boxes, split, axis, left, right, st, cn, items[:tot]

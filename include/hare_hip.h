@@ -1,0 +1,190 @@
+/*
+ * hare_hip.h -- C-ABI of libhare_hip.so: the MI355X (gfx950) implementation of Hare's ray-cast
+ * hot path, Spatial_Partition.Shoot.
+ *
+ * The reference (PachydermAcoustic/Hare, C#) has NO native boundary; its seam is the abstract
+ * class Hare.Geometry.Spatial_Partition (Spatial_Partition.cs:27-35).  A drop-in is a C# class
+ * deriving from it that P/Invokes the functions below (bindings/csharp/).  Each
+ * entry point names the reference member it stands in for (file:line into the reference).
+ *
+ * Conventions
+ *   - extern "C", cdecl, plain pointers and sizes; no C++/torch types cross this boundary.
+ *   - every function returns HARE_OK (0) or a negative HARE_E_* code; the message of the last
+ *     failure on the calling thread is hare_last_error().  No exception crosses the ABI.
+ *   - the caller owns every host buffer; the library never keeps a host pointer after a call
+ *     returns.  Everything behind hare_scene* belongs to the library until hare_scene_destroy.
+ *   - per-ray conditions (origin outside the grid, NaN direction, ...) are not errors: they give
+ *     the miss record X_Event() (Hare_Geometry_Primitives.cs:454-462).
+ *   - threading: build/destroy calls are single-caller; hare_shoot_batch may be called from
+ *     several host threads on one scene (calls are serialised on an internal mutex per scene);
+ *     hare_shoot_device is stream-ordered and takes no lock.
+ *   - there is NO CPU fallback: every shoot runs the HIP kernels and fails with HARE_E_NODEVICE
+ *     when no gfx950 device / HIP runtime is available.
+ */
+#ifndef HARE_HIP_H
+#define HARE_HIP_H
+
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define HARE_API __attribute__((visibility("default")))
+#else
+#define HARE_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HARE_OK 0
+#define HARE_E_INVALID (-1)     /* bad argument                                   */
+#define HARE_E_NOMEM (-2)       /* host or device allocation failed               */
+#define HARE_E_HIP (-3)         /* a HIP runtime call failed                      */
+#define HARE_E_NODEVICE (-4)    /* no HIP runtime / no usable GPU                 */
+#define HARE_E_STATE (-5)       /* partition not built, scene not uploaded, ...   */
+#define HARE_E_UNSUPPORTED (-6) /* e.g. polygon with more than 4 corners          */
+
+/* Which Spatial_Partition subclass a shoot goes through */
+#define HARE_KIND_VOXEL 0   /* Voxel_Grid  (Voxel_Grid.cs)       */
+#define HARE_KIND_OCTREE 1  /* Octree      ("Octree - alt.cs")   */
+#define HARE_KIND_KDTREE 2  /* KDTree      (KDTree.cs)           */
+
+/* hare_shoot_* flags */
+#define HARE_SHOOT_WRITEBACK_ORIGIN 1u /* also apply AABB.Intersect's origin move to rays[] (AABB_Main.cs:254-257) */
+#define HARE_SHOOT_COUNT_WORK 2u       /* fill cells/entries/tests of hare_counters (slower diagnostic kernel)       */
+
+/* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
+ * only serve the reference's mailbox pool and are not needed here. 48 bytes. */
+typedef struct hare_ray {
+    double x, y, z;
+    double dx, dy, dz;
+} hare_ray;
+
+/* Hare.Geometry.X_Event (Hare_Geometry_Primitives.cs:435-481). 56 bytes.
+ * Miss == X_Event(): t=u=v=0, X_Point null (0,0,0 here), Poly_id=-1, Hit=false. */
+typedef struct hare_xevent {
+    double t, u, v;
+    double x, y, z;   /* X_Point */
+    int32_t poly_id;  /* Poly_id */
+    int32_t hit;      /* Hit     */
+} hare_xevent;
+
+/* Batch counters.  hits is what a multi-GPU run reduces across ranks. */
+typedef struct hare_counters {
+    uint64_t rays, hits;
+    uint64_t cells;    /* grid cells / tree nodes visited (HARE_SHOOT_COUNT_WORK)           */
+    uint64_t entries;  /* candidate-list entries scanned  (HARE_SHOOT_COUNT_WORK)           */
+    uint64_t tests;    /* polygon tests performed; the GPU has no mailbox, so this counts   */
+                       /* re-tests the reference's mailbox would skip                       */
+    uint64_t reserved[3];
+} hare_counters;
+
+/* One Hare.Geometry.Topology as read back from the managed object:
+ *   verts   = Model[m][poly, corner]          (Hare_Geometry_Topology.cs:418-424), P x 4 x 3 doubles,
+ *             corner 3 ignored for triangles
+ *   nverts  = Model[m].Polys[p].VertextCT     (Hare_Geometry_Polygons.cs:196), 3 or 4
+ *   normals = Model[m].Normal(p)              (Hare_Geometry_Topology.cs:539), P x 3 doubles
+ *   min/max = Model[m].Min / Model[m].Max     (Hare_Geometry_Topology.cs:50,58) after Finish_Topology() */
+typedef struct hare_topology_desc {
+    int32_t P;
+    int32_t reserved;
+    const double *verts;
+    const int32_t *nverts;
+    const double *normals;
+    double min[3];
+    double max[3];
+} hare_topology_desc;
+
+typedef struct hare_scene hare_scene;
+
+/* ---- library / device ---- */
+HARE_API const char *hare_version(void);
+HARE_API const char *hare_last_error(void);
+HARE_API int hare_device_count(int32_t *count);
+/* Path of the HIP runtime the library bound to (diagnostics). */
+HARE_API const char *hare_hip_runtime_path(void);
+
+/* ---- helpers for hosts that do not go through the managed Topology ----
+ * Polygon ctor normal (Hare_Geometry_Polygons.cs:159-171) and Finish_Topology bounds
+ * (Hare_Geometry_Topology.cs:148-167), bit-identical to what the managed object would hold. */
+HARE_API int hare_polygon_normals(const double *verts, const int32_t *nverts, int32_t P, double *normals_out);
+HARE_API int hare_topology_bounds(const double *verts, const int32_t *nverts, int32_t P, double min_out[3], double max_out[3]);
+
+/* ---- scene = Spatial_Partition.Model (Spatial_Partition.cs:29) ----
+ * Copies the topologies; `device` is the HIP device ordinal that will hold the scene. */
+HARE_API int hare_scene_create(const hare_topology_desc *topos, int32_t n_topos, int32_t device, hare_scene **out);
+HARE_API void hare_scene_destroy(hare_scene *s);
+
+/* ---- partition constructors ----
+ * Voxel_Grid(Topology[] Model_in, int Domain)                      Voxel_Grid.cs:48-121  */
+HARE_API int hare_voxel_build(hare_scene *s, int32_t domain);
+/* Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys)    Voxel_Grid.cs:128-254 */
+HARE_API int hare_voxel_build_adaptive(hare_scene *s, int32_t max_domain, int32_t avg_polys);
+/* Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) "Octree - alt.cs":45-89 */
+HARE_API int hare_octree_build(hare_scene *s, int32_t max_depth, int32_t max_polys);
+/* KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) KDTree.cs:51-88 */
+HARE_API int hare_kdtree_build(hare_scene *s, int32_t max_depth, int32_t max_polys);
+
+/* ---- partition introspection (Voxel_Grid public members + what the parity tests compare) ---- */
+typedef struct hare_voxel_info {
+    int32_t ct;              /* VoxelCtX = VoxelCtY = VoxelCtZ                          */
+    int32_t n_topos;
+    double obox_min[3];      /* MinPt (Voxel_Grid.cs:785-791)                            */
+    double obox_max[3];
+    double box_dims[3];      /* Xdim / Ydim / Zdim (Voxel_Grid.cs:763-783)               */
+    double voxel_dims[3];
+    double char_step;        /* Spatial_Partition.Char_Step (Spatial_Partition.cs:31)    */
+    uint64_t total_items;    /* sum of Voxel_Inv[x,y,z,m].Count over the grid, topology 0 */
+} hare_voxel_info;
+HARE_API int hare_voxel_get_info(const hare_scene *s, hare_voxel_info *out);
+/* Voxel_Inv[x,y,z,top] (Voxel_Grid.cs:33) as CSR: cell = (x*ct + y)*ct + z; cell_start has
+ * ct^3 + 1 entries, items has cell_start[ct^3] entries (ascending polygon index per cell).
+ * items may be NULL to fetch cell_start only (its last entry sizes the items buffer). */
+HARE_API int hare_voxel_get_lists(const hare_scene *s, int32_t top_index, uint32_t *cell_start, int32_t *items);
+
+typedef struct hare_tree_info {
+    int32_t n_nodes;
+    int32_t max_depth;
+    int32_t max_polys;
+    int32_t reserved;
+    uint64_t total_items;
+} hare_tree_info;
+HARE_API int hare_octree_get_info(const hare_scene *s, hare_tree_info *out);
+/* nodes in creation order (root, then each split's 8 children, depth-first):
+ * boxes n x 6 (min xyz, max xyz), first_child (-1 = leaf), item_start/item_count into items */
+HARE_API int hare_octree_get_nodes(const hare_scene *s, double *boxes, int32_t *first_child, int32_t *item_start,
+                          int32_t *item_count, int32_t *items);
+HARE_API int hare_kdtree_get_info(const hare_scene *s, hare_tree_info *out);
+HARE_API int hare_kdtree_get_nodes(const hare_scene *s, double *boxes, double *split, int32_t *axis, int32_t *left,
+                          int32_t *right, int32_t *item_start, int32_t *item_count, int32_t *items);
+
+/* ---- Shoot ----
+ * bool Shoot(Ray R, int top_index, out X_Event Ret_event)                                  Spatial_Partition.cs:32
+ * bool Shoot(Ray R, int top_index, out X_Event Ret_event, int poly_origin1, int poly_origin2 = -1)   :33
+ * for n rays at once.  excl1/excl2 (nullable) are poly_origin1/poly_origin2 per ray, -1 = none.
+ * rays is read (and, with HARE_SHOOT_WRITEBACK_ORIGIN, updated like the reference mutates R).
+ * Host buffers; the call copies to the scene's device, runs the kernel and copies back. */
+HARE_API int hare_shoot_batch(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, hare_ray *rays,
+                     const int32_t *excl1, const int32_t *excl2, uint32_t flags, hare_xevent *out,
+                     hare_counters *ctr /* nullable */);
+
+/* Same with DEVICE pointers on the scene's device and a caller stream (hipStream_t as void*,
+ * NULL = default stream); stream-ordered, does not synchronise.  d_counters (nullable) points to
+ * a device hare_counters that the kernel ACCUMULATES into. */
+HARE_API int hare_shoot_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
+                      const void *d_excl1, const void *d_excl2, uint32_t flags, void *d_out,
+                      void *d_counters, void *stream);
+
+/* ---- specular bounce (harness-defined; the reference leaves reflection to its caller, which
+ * re-shoots with poly_origin1 = the previous Poly_id -- Voxel_Grid.cs:351,477) ----
+ * For every ray with events[i].hit: origin <- X_Point, direction <- d - (2*(d.n))*n with
+ * n = Model[top].Normal(Poly_id), excl_out[i] <- Poly_id.  Rays that missed keep their record
+ * and get excl_out[i] = -2 (dead: a later shoot reports a miss for them immediately).
+ * Device pointers, stream-ordered. */
+HARE_API int hare_reflect_device(hare_scene *s, int32_t top_index, int64_t n, void *d_rays, const void *d_events,
+                        void *d_excl_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HARE_HIP_H */
