@@ -44,6 +44,7 @@ const HipApi* api_or_err()
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
             set_error(std::string(#expr) + " failed: " + (H->GetErrorString ? H->GetErrorString(_e) : "?")); \
+            (void)H->GetLastError();                                                           \
             return (_e == hipErrorOutOfMemory) ? HARE_E_NOMEM : HARE_E_HIP;                    \
         }                                                                                      \
     } while (0)
@@ -78,6 +79,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         hipError_t e = H->ModuleGetFunction(t.fn, m->mod, t.name);
         if (e != hipSuccess) *t.fn = nullptr;   // optional kernels may be absent in a given build
     }
+    (void)H->GetLastError();   // a failed lookup must not stay behind as the host's "last error"
     if (!m->voxel_tri || !m->voxel_quad) {
         set_error("embedded code object lacks hare_voxel_shoot_* (not a gfx950 device?)");
         return HARE_E_HIP;

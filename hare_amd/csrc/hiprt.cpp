@@ -70,7 +70,7 @@ void do_bind()
               bind(h, "hipModuleLoadData", g_api.ModuleLoadData, e) && bind(h, "hipModuleUnload", g_api.ModuleUnload, e) &&
               bind(h, "hipModuleGetFunction", g_api.ModuleGetFunction, e) &&
               bind(h, "hipModuleLaunchKernel", g_api.ModuleLaunchKernel, e) &&
-              bind(h, "hipGetErrorString", g_api.GetErrorString, e) && bind(h, "hipEventCreate", g_api.EventCreate, e) &&
+              bind(h, "hipGetErrorString", g_api.GetErrorString, e) && bind(h, "hipGetLastError", g_api.GetLastError, e) && bind(h, "hipEventCreate", g_api.EventCreate, e) &&
               bind(h, "hipEventDestroy", g_api.EventDestroy, e) && bind(h, "hipEventRecord", g_api.EventRecord, e) &&
               bind(h, "hipEventSynchronize", g_api.EventSynchronize, e) &&
               bind(h, "hipEventElapsedTime", g_api.EventElapsedTime, e) && bind(h, "hipHostMalloc", g_api.HostMalloc, e) &&

@@ -32,6 +32,7 @@ struct HipApi {
     hipError_t (*ModuleLaunchKernel)(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned,
                                      unsigned, hipStream_t, void**, void**);
     const char* (*GetErrorString)(hipError_t);
+    hipError_t (*GetLastError)(void);
     hipError_t (*EventCreate)(hipEvent_t*);
     hipError_t (*EventDestroy)(hipEvent_t);
     hipError_t (*EventRecord)(hipEvent_t, hipStream_t);

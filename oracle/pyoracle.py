@@ -180,8 +180,8 @@ class VoxelGrid:
         L.ho_voxel_geometry(self.h, _p(self.obox_min), _p(self.obox_max), _p(self.voxel_dims))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ho_voxel_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ho_voxel_free(self.h)
             self.h = None
 
     def lists(self, m: int = 0):
@@ -225,8 +225,8 @@ class VoxelPool:
         self.h = lib().ho_voxel_pool_new(grid.h, grid.models.arr)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ho_voxel_pool_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ho_voxel_pool_free(self.h)
             self.h = None
 
     def shoot(self, ray, ray_id, top_index=0, po1=-1, po2=-1):
@@ -246,8 +246,8 @@ class Octree:
         self.n_nodes = int(L.ho_octree_node_count(self.h))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ho_octree_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ho_octree_free(self.h)
             self.h = None
 
     def export(self):
@@ -285,8 +285,8 @@ class KDTree:
         self.n_nodes = int(L.ho_kdtree_node_count(self.h))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().ho_kdtree_free(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.ho_kdtree_free(self.h)
             self.h = None
 
     def export(self):
