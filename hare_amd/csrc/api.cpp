@@ -271,8 +271,13 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             set_error("hare_shoot: octree kernel missing from code object");
             return HARE_E_STATE;
         }
+        // one frame per interior level and lane in LDS: 24 bytes x levels x block
+        const unsigned levels = (unsigned)std::max(1, g.max_depth);
+        unsigned ob = 256;
+        while (ob > 64 && (size_t)levels * ob * 24 > 64 * 1024) ob >>= 1;
+        const unsigned lds = levels * ob * 24;
         void* args[] = {&g, &io};
-        return launch(H, f, grid, block, 0, st, args);
+        return launch(H, f, (unsigned)((n + ob - 1) / ob), ob, lds, st, args);
     }
     if (kind == HARE_KIND_KDTREE) {
         if (!s.kd.built || !s.d_kd_nodes) {
@@ -291,8 +296,12 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             set_error("hare_shoot: kd-tree kernel missing from code object");
             return HARE_E_STATE;
         }
+        // node stack in LDS: at most depth + 2 entries per lane
+        const unsigned slots = (unsigned)g.max_depth + 2;
+        const unsigned kb = 256;
+        const unsigned lds = slots * kb * 4;
         void* args[] = {&g, &io};
-        return launch(H, f, grid, block, 0, st, args);
+        return launch(H, f, (unsigned)((n + kb - 1) / kb), kb, lds, st, args);
     }
     set_error("hare_shoot: unknown partition kind");
     return HARE_E_INVALID;

@@ -185,13 +185,15 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
     XEventRec ev;
     set_miss(ev);
     Work w = {0, 0, 0};
+    bool live = false;
     if (valid) {
         const RayRec r = io.rays[i];
         V3 o = {r.x, r.y, r.z};
         const V3 d = {r.dx, r.dy, r.dz};
         const int e1 = io.excl1 ? io.excl1[i] : -1;
         const int e2 = io.excl2 ? io.excl2[i] : -1;
-        const bool moved = trace_voxel<QUADS, COUNT>(g, o, d, e1, e2, ev, w);
+        live = e1 != -2;   // -2 marks a ray the bounce loop retired (hare_reflect)
+        const bool moved = live && trace_voxel<QUADS, COUNT>(g, o, d, e1, e2, ev, w);
         io.out[i] = ev;
         if (moved && (io.flags & SHOOT_WRITEBACK_ORIGIN)) {
             io.rays[i].x = o.x;
@@ -199,7 +201,253 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
             io.rays[i].z = o.z;
         }
     }
-    flush_counters(io.ctr, valid, ev.hit != 0, w, COUNT);
+    flush_counters(io.ctr, valid && live, ev.hit != 0, w, COUNT);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Octree.Shoot: "Octree - alt.cs":159-284.
+//
+// The reference keeps a LIFO Stack<(node,tmin,tmax)>: an interior node pushes its surviving children
+// in ComputeTraversalOrder order (:286-306) and they pop in reverse.  Whether a child is pushed
+// (:268) depends only on the ray, the child's box and the parent's interval -- never on the hit
+// found so far -- so the same visit sequence is produced by a depth-first walk that keeps ONE frame
+// per level {first_child, cursor, parent interval} and enumerates children lazily from order[7]
+// down to order[0].  That needs (max_depth) frames per lane instead of 7*max_depth+1 stack entries;
+// frames live in LDS, laid out [level][lane] so that a wave's accesses never bank-conflict.
+// order[k] = k ^ mask with mask = (dx<0)<<2 | (dy<0)<<1 | (dz<0).
+struct OctFrames {
+    int* first;      // [levels][blockDim]
+    int* cursor;     // [levels][blockDim]
+    double* a;       // [levels][blockDim]
+    double* b;       // [levels][blockDim]
+};
+
+template <bool COUNT>
+__device__ __forceinline__ void trace_octree(const OctreeArgs& g, const OctFrames& fr, const V3& o, const V3& d,
+                                             int e1, int e2, XEventRec& ev, Work& w)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double invDx = fabs(d.x) > 1e-16 ? 1.0 / d.x : 1e16;   // :165-167
+    const double invDy = fabs(d.y) > 1e-16 ? 1.0 / d.y : 1e16;
+    const double invDz = fabs(d.z) > 1e-16 ? 1.0 / d.z : 1e16;
+    const bool nx = invDx < 0, ny = invDy < 0, nz = invDz < 0;
+    const int mask = ((d.x >= 0 ? 0 : 1) << 2) | ((d.y >= 0 ? 0 : 1) << 1) | (d.z >= 0 ? 0 : 1);
+
+    auto slab = [&](const OctNode& n, double& tmin, double& tmax) {
+        double tx0 = (n.bmin[0] - o.x) * invDx, tx1 = (n.bmax[0] - o.x) * invDx;
+        double ty0 = (n.bmin[1] - o.y) * invDy, ty1 = (n.bmax[1] - o.y) * invDy;
+        double tz0 = (n.bmin[2] - o.z) * invDz, tz1 = (n.bmax[2] - o.z) * invDz;
+        if (nx) { const double s = tx0; tx0 = tx1; tx1 = s; }
+        if (ny) { const double s = ty0; ty0 = ty1; ty1 = s; }
+        if (nz) { const double s = tz0; tz0 = tz1; tz1 = s; }
+        tmin = net_max(net_max(tx0, ty0), tz0);
+        tmax = net_min(net_min(tx1, ty1), tz1);
+    };
+
+    set_miss(ev);
+    double rmin, rmax;
+    slab(g.nodes[0], rmin, rmax);
+    if (rmax < rmin || rmax < 0) return;                          // :185
+
+    bool hit = false;
+    double closestT = kDblMax;
+    int lvl = -1;                  // top frame
+    // the item "popped" next: starts with the root
+    int cur = 0;
+    double ca = rmin, cb = rmax;
+    bool have_item = true;
+
+    for (;;) {
+        if (!have_item) {
+            // pop: next surviving child of the deepest open frame, scanning order[7] .. order[0]
+            while (lvl >= 0) {
+                int k = fr.cursor[lvl * nt + tid];
+                const int first = fr.first[lvl * nt + tid];
+                const double pa = fr.a[lvl * nt + tid], pb = fr.b[lvl * nt + tid];
+                while (k >= 0) {
+                    const int c = first + (k ^ mask);
+                    --k;
+                    double tmn, tmx;
+                    slab(g.nodes[c], tmn, tmx);
+                    if (tmx < tmn || tmx < 0 || tmn > pb || tmx < pa) continue;      // :268
+                    cur = c;
+                    ca = net_max(tmn, pa);                                            // :271
+                    cb = net_min(tmx, pb);
+                    have_item = true;
+                    break;
+                }
+                fr.cursor[lvl * nt + tid] = k;
+                if (have_item) break;
+                --lvl;
+            }
+            if (!have_item) break;   // stack empty
+        }
+        have_item = false;
+        if (cb < ca || cb < 0) continue;                          // :207
+        if (hit && closestT <= ca) continue;                      // :210
+        if (COUNT) w.cells++;
+        const OctNode& node = g.nodes[cur];
+        const int fc = node.first_child;
+        if (fc < 0) {
+            const int is = node.item_start, ic = node.item_count;
+            if (COUNT) w.entries += ic;
+            for (int q = is; q < is + ic; ++q) {
+                const int i = g.items[q];
+                if (i == e1 || i == e2) continue;                 // :218
+                if (COUNT) w.tests++;
+                const PolyRec& p = g.polys[i];
+                double t, u, v;
+                if (poly_full(p, p.nverts == 4, o, d, t, u, v) && t > kTMin) {   // :224
+                    if (t < closestT) {
+                        closestT = t;
+                        ev.t = t; ev.u = u; ev.v = v;
+                        ev.x = o.x + d.x * t; ev.y = o.y + d.y * t; ev.z = o.z + d.z * t;
+                        ev.poly_id = i;
+                        ev.hit = 1;
+                        hit = true;
+                        if (closestT <= ca) return;               // :233 early termination
+                    }
+                }
+            }
+        } else {
+            ++lvl;
+            fr.first[lvl * nt + tid] = fc;
+            fr.cursor[lvl * nt + tid] = 7;
+            fr.a[lvl * nt + tid] = ca;
+            fr.b[lvl * nt + tid] = cb;
+        }
+    }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void octree_shoot_body(const OctreeArgs& g, const ShootIO& io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nt = blockDim.x;
+    const int levels = g.max_depth > 0 ? g.max_depth : 1;
+    OctFrames fr;
+    fr.a = reinterpret_cast<double*>(lds);
+    fr.b = fr.a + (size_t)levels * nt;
+    fr.first = reinterpret_cast<int*>(fr.b + (size_t)levels * nt);
+    fr.cursor = fr.first + (size_t)levels * nt;
+
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < io.n;
+    XEventRec ev;
+    set_miss(ev);
+    Work w = {0, 0, 0};
+    bool live = false;
+    if (valid) {
+        const RayRec r = io.rays[i];
+        const V3 o = {r.x, r.y, r.z};
+        const V3 d = {r.dx, r.dy, r.dz};
+        const int e1 = io.excl1 ? io.excl1[i] : -1;
+        const int e2 = io.excl2 ? io.excl2[i] : -1;
+        live = e1 != -2;
+        if (live) trace_octree<COUNT>(g, fr, o, d, e1, e2, ev, w);
+        io.out[i] = ev;
+    }
+    flush_counters(io.ctr, valid && live, ev.hit != 0, w, COUNT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// KDTree.Shoot: KDTree.cs:204-361.  Both children of every interior node are pushed (:355-356), so
+// every leaf is visited; the split-plane logic only fixes the ORDER, which decides
+// exact-t ties.  Explicit node stack in LDS, [slot][lane].
+template <bool COUNT>
+__device__ __forceinline__ void trace_kdtree(const KdArgs& g, int* stack, const V3& o, const V3& d, int e1, int e2,
+                                             XEventRec& ev, Work& w)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    set_miss(ev);
+    double closestT = kDblMax;
+    int sp = 0;
+    stack[tid] = 0;
+    sp = 1;
+    const double oo[3] = {o.x, o.y, o.z};
+    const double dd[3] = {d.x, d.y, d.z};
+    while (sp > 0) {
+        --sp;
+        const KdNodeRec& cur = g.nodes[stack[sp * nt + tid]];
+        if (COUNT) w.cells++;
+        if (cur.left < 0 && cur.right < 0) {
+            const int is = cur.item_start, ic = cur.item_count;
+            if (COUNT) w.entries += ic;
+            for (int q = is; q < is + ic; ++q) {
+                const int i = g.items[q];
+                if (i == e1 || i == e2) continue;                 // :221
+                if (COUNT) w.tests++;
+                const PolyRec& p = g.polys[i];
+                double t, u, v;
+                if (poly_full(p, p.nverts == 4, o, d, t, u, v) && t > kTMin) {   // :233
+                    if (t < closestT) {
+                        closestT = t;
+                        ev.t = t; ev.u = u; ev.v = v;
+                        ev.x = o.x + d.x * t; ev.y = o.y + d.y * t; ev.z = o.z + d.z * t;
+                        ev.poly_id = i;
+                        ev.hit = 1;
+                    }
+                }
+            }
+        } else {
+            // :249-353: the three SplitAxis branches are one pattern; the other two axes are checked
+            // in ascending axis order
+            const int a = cur.axis;
+            const int b = (a == 0) ? 1 : 0, c = (a == 2) ? 1 : 2;
+            double oa, da, ob, db, oc, dc, bmaxb, bminb, bmaxc, bminc;
+            // select without dynamic register indexing
+            oa = a == 0 ? oo[0] : (a == 1 ? oo[1] : oo[2]);
+            da = a == 0 ? dd[0] : (a == 1 ? dd[1] : dd[2]);
+            ob = b == 0 ? oo[0] : oo[1];
+            db = b == 0 ? dd[0] : dd[1];
+            oc = c == 1 ? oo[1] : oo[2];
+            dc = c == 1 ? dd[1] : dd[2];
+            bmaxb = b == 0 ? cur.bmax[0] : cur.bmax[1];
+            bminb = b == 0 ? cur.bmin[0] : cur.bmin[1];
+            bmaxc = c == 1 ? cur.bmax[1] : cur.bmax[2];
+            bminc = c == 1 ? cur.bmin[1] : cur.bmin[2];
+            const double side = oa - cur.split;
+            const double tSplit = -side / da;
+            const double bS = ob + tSplit * db;
+            const double cS = oc + tSplit * dc;
+            int first, second;
+            if (bS <= bmaxb && bS >= bminb && cS <= bmaxc && cS >= bminc) {
+                if (side >= 0) { first = cur.right; second = cur.left; }
+                else { first = cur.left; second = cur.right; }
+            } else {
+                if (side >= 0) { first = cur.left; second = cur.right; }
+                else { first = cur.right; second = cur.left; }
+            }
+            stack[sp * nt + tid] = second;
+            stack[(sp + 1) * nt + tid] = first;
+            sp += 2;
+        }
+    }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void kdtree_shoot_body(const KdArgs& g, const ShootIO& io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int* stack = reinterpret_cast<int*>(lds);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < io.n;
+    XEventRec ev;
+    set_miss(ev);
+    Work w = {0, 0, 0};
+    bool live = false;
+    if (valid) {
+        const RayRec r = io.rays[i];
+        const V3 o = {r.x, r.y, r.z};
+        const V3 d = {r.dx, r.dy, r.dz};
+        const int e1 = io.excl1 ? io.excl1[i] : -1;
+        const int e2 = io.excl2 ? io.excl2[i] : -1;
+        live = e1 != -2;
+        if (live) trace_kdtree<COUNT>(g, stack, o, d, e1, e2, ev, w);
+        io.out[i] = ev;
+    }
+    flush_counters(io.ctr, valid && live, ev.hit != 0, w, COUNT);
 }
 
 }  // namespace
@@ -220,6 +468,39 @@ __global__ __launch_bounds__(256) void hare_voxel_shoot_quad(VoxelArgs g, ShootI
 __global__ __launch_bounds__(256) void hare_voxel_shoot_count(VoxelArgs g, ShootIO io)
 {
     voxel_shoot_body<true, true>(g, io);
+}
+
+// K2: Octree.Shoot ("Octree - alt.cs":159-284); dynamic LDS = levels * blockDim * 24 bytes
+__global__ void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }
+__global__ void hare_octree_shoot_count(OctreeArgs g, ShootIO io) { octree_shoot_body<true>(g, io); }
+
+// KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
+__global__ void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }
+__global__ void hare_kdtree_shoot_count(KdArgs g, ShootIO io) { kdtree_shoot_body<true>(g, io); }
+
+// K3: specular bounce (harness-defined): o' = X_Point, d' = d - (2*(d.n))*n,
+// next exclusion = the polygon just hit; rays that missed are marked dead (-2).
+__global__ __launch_bounds__(256) void hare_reflect(const PolyRec* polys, RayRec* rays, const XEventRec* ev,
+                                                    int32_t* excl_out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const XEventRec e = ev[i];
+    if (!e.hit) {
+        excl_out[i] = -2;
+        return;
+    }
+    const RayRec r = rays[i];
+    const PolyRec& p = polys[e.poly_id];
+    const double dn = dot3(r.dx, r.dy, r.dz, p.n[0], p.n[1], p.n[2]);
+    const double k = 2.0 * dn;
+    RayRec o;
+    o.x = e.x; o.y = e.y; o.z = e.z;
+    o.dx = r.dx - k * p.n[0];
+    o.dy = r.dy - k * p.n[1];
+    o.dz = r.dz - k * p.n[2];
+    rays[i] = o;
+    excl_out[i] = e.poly_id;
 }
 
 }  // extern "C"

@@ -115,10 +115,10 @@ def shoebox(nface: int = 9, size=(10.0, 7.0, 4.0)) -> Mesh:
     return _finish("shoebox-1k", parts, tuple(size))
 
 
-def hall(edge: float = 0.3125, size=(40.0, 25.0, 18.0)) -> Mesh:
+def hall(edge: float = 83.0 / 256.0, size=(40.0, 25.0, 18.0)) -> Mesh:
     """S2 'hall-100k': 40 x 25 x 18 m shell with a sinusoidally displaced ceiling, two balcony
-    slabs, 12 square columns, a stage box and a raked-floor wedge; ~100k triangles at the
-    default edge."""
+    slabs, 12 square columns, a stage box and a raked-floor wedge; 100,908 triangles at the
+    default edge (83/256 m)."""
     Lx, Ly, Lz = size
     parts = []
     nx, ny, nz = _n(Lx, edge), _n(Ly, edge), _n(Lz, edge)
@@ -159,9 +159,9 @@ def hall(edge: float = 0.3125, size=(40.0, 25.0, 18.0)) -> Mesh:
     return _finish("hall-100k", parts, tuple(size))
 
 
-def cathedral(edge: float = 0.1796875, size=(90.0, 40.0, 35.0)) -> Mesh:
-    """S3 'cathedral-1M': 90 x 40 x 35 m shell, barrel-vault ceiling, 2 x 14 columns; ~1M
-    triangles at the default edge."""
+def cathedral(edge: float = 51.0 / 256.0, size=(90.0, 40.0, 35.0)) -> Mesh:
+    """S3 'cathedral-1M': 90 x 40 x 35 m shell, barrel-vault ceiling, 2 x 14 columns; 986,416
+    triangles at the default edge (51/256 m)."""
     Lx, Ly, Lz = size
     parts = []
     nx, ny, nz = _n(Lx, edge), _n(Ly, edge), _n(Lz, edge)

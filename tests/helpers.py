@@ -1,0 +1,46 @@
+"""Shared test inputs (seeded, small)."""
+import numpy as np
+
+import hare_amd.scenes as scenes
+
+FIELDS = ("hit", "poly_id", "t", "u", "v", "x", "y", "z")
+
+
+def soup(n_tri=400, n_quad=100, seed=3, size=(6.0, 5.0, 4.0)):
+    """Random small triangles and planar quads in a box, lattice-snapped; min corner near the origin."""
+    rng = np.random.default_rng(seed)
+    P = n_tri + n_quad
+    verts = np.zeros((P, 4, 3))
+    nverts = np.full(P, 3, np.int32)
+    c = rng.uniform(0.4, 1.0, (P, 3)) * (np.asarray(size) - 0.8)
+    e1 = rng.uniform(-0.6, 0.6, (P, 3))
+    e2 = rng.uniform(-0.6, 0.6, (P, 3))
+    verts[:, 0] = c
+    verts[:, 1] = c + e1
+    verts[:, 2] = c + e1 + e2
+    verts[n_tri:, 3] = (c + e2)[n_tri:]          # parallelogram: planar, convex
+    nverts[n_tri:] = 4
+    verts = scenes.snap(verts)
+    # anchor the bounds so that the octree root covers the model
+    verts[0, 0] = (0.0, 0.0, 0.0)
+    verts[:n_tri, 3] = 0.0
+    # re-derive the 4th corner after snapping so quads stay exactly planar
+    verts[n_tri:, 3] = verts[n_tri:, 0] + (verts[n_tri:, 2] - verts[n_tri:, 1])
+    perm = rng.permutation(P)                     # interleave quads and triangles
+    return np.ascontiguousarray(verts[perm]), np.ascontiguousarray(nverts[perm]), size
+
+
+def soup_rays(n, size, seed=11):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.5, 1.0, (n, 3)) * (np.asarray(size) + 1.0)   # some origins outside the grid
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.ascontiguousarray(np.concatenate([o, d], axis=1))
+
+
+def assert_events_equal(a, b, fields=FIELDS, what=""):
+    for f in fields:
+        if not np.array_equal(a[f], b[f]):
+            bad = np.nonzero(a[f] != b[f])[0]
+            raise AssertionError(f"{what} X_Event.{f} differs on {bad.size} of {len(a)} rays; first {bad[:5]}: "
+                                 f"{a[bad[:3]]} vs {b[bad[:3]]}")

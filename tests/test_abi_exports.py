@@ -1,0 +1,76 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol include/hare_hip.h declares;
+wire structs have the documented sizes; argument errors follow the ABI's error convention.
+No compute call is made here (those are the -m gpu tests)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import hare_amd as H
+from hare_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hare_hip.h")).read()
+    return sorted(set(re.findall(r"HARE_API[^;(]*?\b(hare_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 20
+    raw = C.CDLL(capi.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"libhare_hip.so does not export {n}"
+    assert sorted(capi.SYMBOLS) == names, "hare_amd/capi.py and include/hare_hip.h disagree"
+
+
+def test_header_compiles_as_c_and_struct_sizes(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text(
+        '#include "hare_hip.h"\n#include <stdio.h>\n'
+        "int main(void){printf(\"%zu %zu %zu %zu\\n\", sizeof(hare_ray), sizeof(hare_xevent),"
+        " sizeof(hare_counters), sizeof(hare_topology_desc)); return 0;}\n")
+    exe = tmp_path / "t"
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).split()
+    assert [int(x) for x in out] == [48, 56, 64, C.sizeof(capi.TopologyDesc)]
+    assert capi.RAY_DTYPE.itemsize == 48 and capi.XEVENT_DTYPE.itemsize == 56 and C.sizeof(capi.Counters) == 64
+
+
+def test_library_does_not_link_a_hip_runtime_or_the_oracle():
+    import subprocess
+    needed = subprocess.check_output(["readelf", "-d", capi.LIB_PATH]).decode()
+    libs = re.findall(r"NEEDED.*\[(.*?)\]", needed)
+    assert not any("amdhip" in l or "oracle" in l or "torch" in l for l in libs), libs
+
+
+def test_argument_errors_use_error_codes_not_exceptions():
+    h = C.c_void_p()
+    assert capi.lib.hare_scene_create(None, 1, 0, C.byref(h)) == capi.HARE_E_INVALID
+    assert "hare_scene_create" in capi.last_error()
+    assert capi.lib.hare_voxel_build(None, 8) == capi.HARE_E_INVALID
+    # a pentagon is refused like Topology does (Hare_Geometry_Topology.cs:298)
+    v = np.zeros((1, 4, 3))
+    with pytest.raises(H.HareError) as ei:
+        H.Voxel_Grid([H.Topology(v, np.array([5], np.int32), normals=np.zeros((1, 3)), Min=np.zeros(3), Max=np.ones(3))], 4)
+    assert ei.value.code == capi.HARE_E_UNSUPPORTED and "more than 4 sides" in str(ei.value)
+    m = H.scenes.shoebox()
+    with pytest.raises(H.HareError) as ei:
+        H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 0)
+    assert ei.value.code == capi.HARE_E_INVALID
+
+
+def test_shoot_without_partition_or_gpu_fails_loudly(gpu_available):
+    m = H.scenes.shoebox()
+    part = H.Spatial_Partition([H.Topology(m.verts, m.nverts)])
+    part._kind = capi.KIND_VOXEL
+    rays = H.scenes.random_rays(4, m.size)
+    with pytest.raises(H.HareError) as ei:
+        part.Shoot_batch(rays)
+    # no GPU -> HARE_E_NODEVICE; GPU but nothing built -> HARE_E_STATE.  Never a silent CPU answer.
+    assert ei.value.code == (capi.HARE_E_STATE if gpu_available else capi.HARE_E_NODEVICE)

@@ -1,0 +1,207 @@
+"""GPU parity tests proper: the HIP kernels, called through the C-ABI, against the oracle on the same
+seeded inputs.  Bar (BASELINE.json north_star): Hit and Poly_id bit-exact, t/u/v/X_Point within 1e-5
+relative -- these tests demand bit equality on every field, which FP64 with contraction off and the
+reference's operand order delivers."""
+import numpy as np
+import pytest
+
+import hare_amd as H
+from oracle import pyoracle as po
+from tests.helpers import assert_events_equal, soup, soup_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hall():
+    m = H.scenes.hall()
+    return m, H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+
+
+def test_voxel_full_size_c2_1M_rays_100k_tris(hall):
+    """BASELINE config[1] at full size: 1M burst rays, 100k-tri hall, Voxel_Grid D=64."""
+    m, T, To = hall
+    assert 98000 <= m.P <= 102000
+    rays = H.scenes.burst_rays(1 << 20, m.size)
+    g = H.Voxel_Grid([T], 64)
+    o = po.VoxelGrid([To], domain=64)
+    s, i = g.Voxel_Inv()
+    so, io = o.lists()
+    assert np.array_equal(s, so) and np.array_equal(i, io)
+    ev, ctr = g.Shoot_batch(rays, count_work=True)
+    ref, rc = o.shoot(rays, nthreads=16)
+    assert_events_equal(ev, ref, what="C2 voxel")
+    assert ctr["hits"] == rc["hits"] == 1 << 20          # closed room: every primary ray hits
+    assert ctr["cells"] == rc["cells"] and ctr["entries"] == rc["entries"]
+    assert ctr["tests"] >= rc["tests"]                   # no mailbox on the GPU: duplicates are re-tested
+    # size-independent properties: t * |d| is the distance from the source to X_Point; u = v = 0
+    p = np.stack([ev["x"], ev["y"], ev["z"]], 1)
+    np.testing.assert_allclose(np.linalg.norm(p - rays[:, :3], axis=1), ev["t"], rtol=1e-12)
+    assert not ev["u"].any() and not ev["v"].any()
+
+
+@pytest.mark.parametrize("domain", [1, 7, 32, 128])
+def test_voxel_domains(hall, domain):
+    m, T, To = hall
+    rays = H.scenes.burst_rays(200_000, m.size)
+    ev, _ = H.Voxel_Grid([T], domain).Shoot_batch(rays)
+    ref, _ = po.VoxelGrid([To], domain=domain).shoot(rays, nthreads=16)
+    assert_events_equal(ev, ref, what=f"voxel D={domain}")
+
+
+def test_voxel_adaptive_grid(hall):
+    m, T, To = hall
+    rays = H.scenes.burst_rays(100_000, m.size)
+    g = H.Voxel_Grid([T], 7, 12)
+    o = po.VoxelGrid([To], max_domain=7, avg_polys=12)
+    assert g.VoxelCt == o.ct
+    assert_events_equal(g.Shoot_batch(rays)[0], o.shoot(rays, nthreads=16)[0], what="adaptive voxel")
+
+
+def test_voxel_quads_outside_origins_exclusions_and_origin_writeback():
+    v, nv, size = soup()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = soup_rays(20000, size)
+    g = H.Voxel_Grid([T], 8)
+    o = po.VoxelGrid([To], domain=8)
+    ev, _ = g.Shoot_batch(rays)
+    ref, _ = o.shoot(rays)
+    assert_events_equal(ev, ref, what="soup voxel")
+    assert 0 < ref["hit"].sum() < len(ref)              # both hits and misses are exercised
+    # exclusion overload (Voxel_Grid.cs:351,477): exclude what was hit first, and a second id
+    e1 = ref["poly_id"].astype(np.int32)
+    e2 = np.roll(e1, 1)
+    ev2, _ = g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)
+    ref2, _ = o.shoot(rays, excl1=e1, excl2=e2)
+    assert_events_equal(ev2, ref2, what="soup voxel excl")
+    # F11: rays that start outside are moved to the OBox entry, exactly like the reference mutates R
+    mine = rays.copy()
+    ev3, _ = g.Shoot_batch(mine, writeback_origin=True)
+    ref3, _, moved = o.shoot(rays, mutate=True)
+    assert_events_equal(ev3, ref3, what="soup voxel writeback")
+    assert np.array_equal(mine, moved) and not np.array_equal(mine, rays)
+
+
+def test_voxel_two_topologies():
+    m = H.scenes.shoebox()
+    v, nv, size = soup(150, 40)
+    rays = soup_rays(5000, size)
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts), H.Topology(v, nv)], 8)
+    o = po.VoxelGrid([po.Topology(m.verts, m.nverts), po.Topology(v, nv)], domain=8)
+    for top in (0, 1):
+        assert_events_equal(g.Shoot_batch(rays, top)[0], o.shoot(rays, top)[0], what=f"top {top}")
+
+
+def test_single_ray_shoot_mirrors_reference_signature():
+    m = H.scenes.shoebox(nface=8, size=(8.0, 4.0, 2.0))
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    R = H.Ray(3.0, 1.0, 0.75, 1.0, 0.0, 0.0, 0, 1)
+    hit, e = g.Shoot(R, 0)
+    assert hit and e.Hit and e.t == 5.0 and e.X_Point == (8.0, 1.0, 0.75) and e.u == 0 and e.v == 0
+    hit2, e2 = g.Shoot(R, 0, e.Poly_id)                  # poly_origin1 = the wall just hit
+    assert not hit2 and e2.Poly_id == -1 and e2.X_Point is None
+    R2 = H.Ray(-5.0, 1.125, 0.75, 1.0, 0.0, 0.0, 0, 2)
+    hit3, e3 = g.Shoot(R2, 0)
+    assert hit3 and abs(e3.t - 5.0) < 1e-12 and R2.x != -5.0   # R was moved (F11)
+
+
+def test_octree_c3_parity_and_voxel_agreement(hall):
+    """BASELINE config[2]: same 1M rays and mesh through the octree; hit parity vs the voxel path."""
+    m, T, To = hall
+    rays = H.scenes.burst_rays(1 << 20, m.size)
+    g = H.Octree([T], 8, 16)
+    o = po.Octree([To], 8, 16)
+    for x, y in zip(g.nodes(), o.export()):
+        assert np.array_equal(x, y)
+    ev, ctr = g.Shoot_batch(rays, count_work=True)
+    ref, rc = o.shoot(rays, nthreads=16)
+    assert_events_equal(ev, ref, what="C3 octree")
+    assert (ctr["cells"], ctr["entries"], ctr["tests"]) == (rc["cells"], rc["entries"], rc["tests"])
+    vx, _ = H.Voxel_Grid([T], 64).Shoot_batch(rays)
+    assert np.array_equal(ev["hit"], vx["hit"])
+    same = ev["poly_id"] == vx["poly_id"]
+    assert same.mean() > 0.999                            # only exact-t ties may differ
+    assert np.array_equal(ev["t"], vx["t"])               # ties have equal t; same poly => same formula
+    assert np.all((ev["u"] >= 0) & (ev["v"] >= 0) & (ev["u"] + ev["v"] <= 1 + 1e-12))
+
+
+@pytest.mark.parametrize("depth,maxp", [(0, 4), (3, 2), (6, 8), (12, 64)])
+def test_octree_shapes_quads_and_exclusions(depth, maxp):
+    v, nv, size = soup()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = soup_rays(20000, size)
+    g, o = H.Octree([T], depth, maxp), po.Octree([To], depth, maxp)
+    ref, _ = o.shoot(rays)
+    assert_events_equal(g.Shoot_batch(rays)[0], ref, what="soup octree")
+    e1 = ref["poly_id"].astype(np.int32)
+    assert_events_equal(g.Shoot_batch(rays, poly_origin1=e1)[0], o.shoot(rays, excl1=e1)[0], what="soup octree excl")
+
+
+def test_kdtree_parity_small():
+    m = H.scenes.shoebox()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    rays = H.scenes.random_rays(4000, m.size)
+    for depth, maxp in ((0, 1), (6, 8), (14, 4)):
+        ev, ctr = H.KDTree([T], depth, maxp).Shoot_batch(rays, count_work=True)
+        ref, rc = po.KDTree([To], depth, maxp).shoot(rays)
+        assert_events_equal(ev, ref, what=f"kd {depth},{maxp}")
+        assert ctr["cells"] == rc["cells"] and ctr["entries"] == rc["entries"]
+    v, nv, size = soup()
+    rays = soup_rays(3000, size)
+    ev, _ = H.KDTree([H.Topology(v, nv)], 9, 6).Shoot_batch(rays)
+    ref, _ = po.KDTree([po.Topology(v, nv)], 9, 6).shoot(rays)
+    assert_events_equal(ev, ref, what="kd soup")
+
+
+def test_empty_and_ragged_batches(hall):
+    m, T, To = hall
+    g = H.Voxel_Grid([T], 16)
+    ev, ctr = g.Shoot_batch(np.zeros((0, 6)))
+    assert len(ev) == 0 and ctr["rays"] == 0
+    o = po.VoxelGrid([To], domain=16)
+    for n in (1, 63, 64, 65, 257, 1000):                  # partial waves / partial blocks
+        rays = H.scenes.burst_rays(n, m.size)
+        assert_events_equal(g.Shoot_batch(rays)[0], o.shoot(rays)[0], what=f"n={n}")
+
+
+def test_bounce_loop_device_resident(hall):
+    """Config-5 style loop at reduced size: shoot -> reflect -> shoot with poly_origin1 = last hit,
+    all device-resident; every bounce equals the oracle's (closest hit + the same reflect lines)."""
+    import torch
+    m, T, To = hall
+    n, bounces = 100_000, 4
+    rays = H.scenes.burst_rays(n, m.size)
+    g = H.Voxel_Grid([T], 64)
+    o = po.VoxelGrid([To], domain=64)
+    d_rays = torch.from_numpy(rays.copy()).cuda()
+    d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    d_ex = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cur = rays.copy()
+    excl = None
+    for b in range(bounces):
+        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)
+        ref, _ = o.shoot(cur, excl1=excl, nthreads=16)
+        assert_events_equal(ev, ref, what=f"bounce {b}")
+        g.reflect_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_ex.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        nxt = po.reflect(To, cur, ref)
+        alive = ref["hit"] == 1
+        assert alive.mean() > 0.99
+        got = d_rays.cpu().numpy()
+        assert np.array_equal(got[alive], nxt[alive])
+        gex = d_ex.cpu().numpy()
+        assert np.array_equal(gex[alive], ref["poly_id"][alive]) and np.all(gex[~alive] == -2)
+        # the oracle has no "dead ray" notion: keep dead rays where they are and exclude nothing
+        cur = np.where(alive[:, None], nxt, cur)
+        excl = np.where(alive, ref["poly_id"], -1).astype(np.int32)
+        if (~alive).any():
+            # retired rays must come back as misses from the kernel; mirror that in the expectation
+            keep = alive.copy()
+            cur, excl = cur[keep], excl[keep]
+            d_rays = d_rays[torch.from_numpy(keep).cuda()].contiguous()
+            d_ex = d_ex[torch.from_numpy(keep).cuda()].contiguous()
+            n = int(keep.sum())
+            d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")

@@ -1,0 +1,101 @@
+"""The product's partition builders (hare_amd/csrc/build_host.cpp) against the oracle's restatement
+of the reference constructors: identical candidate lists, node boxes and ordering.  Order decides
+exact-t ties, so equality is required, not equivalence.  CPU only."""
+import numpy as np
+import pytest
+
+import hare_amd as H
+from oracle import pyoracle as po
+from tests.helpers import soup
+
+
+def topo_pair(verts, nverts):
+    return H.Topology(verts, nverts), po.Topology(verts, nverts)
+
+
+@pytest.fixture(scope="module")
+def scenes3():
+    m = H.scenes.shoebox()
+    v, nv, _ = soup()
+    hall = H.scenes.hall(edge=1.0)   # ~11k triangles: displaced ceiling, solids
+    return [("shoebox", m.verts, m.nverts), ("soup", v, nv), ("hall-coarse", hall.verts, hall.nverts)]
+
+
+def test_normals_and_bounds_match_polygon_ctor_and_finish_topology(scenes3):
+    for name, v, nv in scenes3:
+        a, b = topo_pair(v, nv)
+        assert np.array_equal(a.normals, b.normals), name
+        assert np.array_equal(np.signbit(a.normals), np.signbit(b.normals)), name
+        assert np.array_equal(a.Min, b.min) and np.array_equal(a.Max, b.max), name
+
+
+@pytest.mark.parametrize("domain", [1, 5, 8, 16])
+def test_fixed_voxel_lists_identical(scenes3, domain):
+    for name, v, nv in scenes3:
+        a, b = topo_pair(v, nv)
+        g = H.Voxel_Grid([a], domain)
+        # the oracle's literal D^3 x P loop is the reference's own algorithm; use it where it is cheap
+        o = po.VoxelGrid([b], domain=domain, build_mode=0 if (domain ** 3) * b.P < 3e7 else 1)
+        s, i = g.Voxel_Inv()
+        so, io = o.lists()
+        assert np.array_equal(s, so) and np.array_equal(i, io), (name, domain)
+        info = g.info()
+        assert info.ct == o.ct and g.Char_Step == o.char_step
+        assert tuple(info.obox_min) == tuple(o.obox_min) and tuple(info.obox_max) == tuple(o.obox_max)
+        assert tuple(info.voxel_dims) == tuple(o.voxel_dims)
+        assert (g.Xdim, g.Ydim, g.Zdim) == tuple(o.obox_max - o.obox_min)
+
+
+def test_adaptive_voxel_lists_identical(scenes3):
+    for name, v, nv in scenes3:
+        a, b = topo_pair(v, nv)
+        for max_domain, avg in ((3, 4), (5, 10), (6, 40)):
+            g = H.Voxel_Grid([a], max_domain, avg)
+            o = po.VoxelGrid([b], max_domain=max_domain, avg_polys=avg)
+            assert g.VoxelCt == o.ct, (name, max_domain, avg)
+            s, i = g.Voxel_Inv()
+            so, io = o.lists()
+            assert np.array_equal(s, so) and np.array_equal(i, io), (name, max_domain, avg)
+
+
+def test_two_topologies_share_one_grid():
+    m = H.scenes.shoebox()
+    v, nv, _ = soup(100, 30)
+    a0, b0 = topo_pair(m.verts, m.nverts)
+    a1, b1 = topo_pair(v, nv)
+    g = H.Voxel_Grid([a0, a1], 6)
+    o = po.VoxelGrid([b0, b1], domain=6, build_mode=0)
+    for top in (0, 1):
+        s, i = g.Voxel_Inv(top)
+        so, io = o.lists(top)
+        assert np.array_equal(s, so) and np.array_equal(i, io)
+
+
+def test_octree_nodes_identical(scenes3):
+    for name, v, nv in scenes3:
+        a, b = topo_pair(v, nv)
+        for depth, mp in ((3, 4), (5, 16)):
+            g = H.Octree([a], depth, mp)
+            o = po.Octree([b], depth, mp)
+            for x, y in zip(g.nodes(), o.export()):
+                assert np.array_equal(x, y), (name, depth, mp)
+
+
+def test_kdtree_nodes_identical(scenes3):
+    for name, v, nv in scenes3:
+        a, b = topo_pair(v, nv)
+        for depth, mp in ((4, 8), (10, 4)):
+            g = H.KDTree([a], depth, mp)
+            o = po.KDTree([b], depth, mp)
+            for x, y in zip(g.nodes(), o.export()):
+                assert np.array_equal(x, y), (name, depth, mp)
+
+
+def test_public_members_of_voxel_grid():
+    m = H.scenes.shoebox()
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    info = g.info()
+    assert g.MinPt == tuple(info.obox_min)
+    x, y, z = g.PointInVoxel((5.0, 3.5, 2.0))
+    assert (x, y, z) == tuple(int(np.floor((p - info.obox_min[a]) / info.voxel_dims[a])) for a, p in enumerate((5.0, 3.5, 2.0)))
+    assert g.VoxelCode(1, 2, 3) == 64 * 3 + 8 * 1 + 2      # XYTot*Z + VoxelCtY*X + Y (Voxel_Grid.cs:264-267)

@@ -1,0 +1,132 @@
+"""Properties the oracle must satisfy internally (SURVEY.md 4 "Property" level): the partitions agree
+with a brute-force nearest hit (same RayXtri, strict '<', ascending index) except for the documented
+tie / exit cases."""
+import numpy as np
+import pytest
+
+import hare_amd.scenes as scenes
+from oracle import pyoracle as po
+from tests.helpers import soup, soup_rays
+
+
+@pytest.fixture(scope="module")
+def box():
+    m = scenes.shoebox()
+    return m, po.Topology(m.verts, m.nverts)
+
+
+def test_literal_and_triangle_major_builds_give_identical_lists(box):
+    m, T = box
+    for D in (1, 3, 8):
+        a = po.VoxelGrid([T], domain=D, build_mode=0).lists()
+        b = po.VoxelGrid([T], domain=D, build_mode=1).lists()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    v, nv, size = soup(150, 50)
+    S = po.Topology(v, nv)
+    a = po.VoxelGrid([S], domain=6, build_mode=0).lists()
+    b = po.VoxelGrid([S], domain=6, build_mode=1).lists()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # ascending polygon index per cell
+    st, it = a
+    for c in range(len(st) - 1):
+        seg = it[st[c]:st[c + 1]]
+        assert np.all(np.diff(seg) > 0)
+
+
+def test_voxel_equals_brute_force_inside_closed_room(box):
+    m, T = box
+    rays = scenes.random_rays(3000, m.size)
+    for D in (4, 8, 16):
+        ev, ctr = po.VoxelGrid([T], domain=D).shoot(rays)
+        bf = po.brute(T, rays)
+        assert ev["hit"].all()
+        same = ev["poly_id"] == bf["poly_id"]
+        # any disagreement must be an exact-t tie (first-tested wins; test order differs)
+        assert np.array_equal(ev["t"], bf["t"])
+        assert same.mean() > 0.995
+        assert np.array_equal(ev["x"][same], bf["x"][same])
+        assert ctr["tests"] <= ctr["entries"]
+
+
+def test_adaptive_grid_stops_on_average_list_length(box):
+    m, T = box
+    g = po.VoxelGrid([T], max_domain=6, avg_polys=10)
+    assert g.ct in (8, 16, 32, 64)
+    st, it = g.lists()
+    cnt = np.diff(st)
+    assert cnt[cnt > 0].mean() < 10 or g.ct == 64
+    g2 = po.VoxelGrid([T], max_domain=2, avg_polys=1)   # k never exceeds 1: runs all levels
+    assert g2.ct == 4
+    rays = scenes.random_rays(1000, m.size)
+    ev, _ = g.shoot(rays)
+    bf = po.brute(T, rays)
+    assert np.array_equal(ev["t"], bf["t"])
+
+
+def test_octree_matches_voxel_t_bit_for_bit(box):
+    m, T = box
+    rays = scenes.random_rays(3000, m.size)
+    vx, _ = po.VoxelGrid([T], domain=8).shoot(rays)
+    oc, ctr = po.Octree([T], 5, 8).shoot(rays)
+    assert np.array_equal(oc["hit"], vx["hit"])
+    same = oc["poly_id"] == vx["poly_id"]
+    assert same.mean() > 0.995
+    assert np.array_equal(oc["t"][same], vx["t"][same])          # same formula, same operands
+    assert np.array_equal(oc["t"], vx["t"])                        # ties have equal t by definition
+    # octree returns real barycentrics; voxel returns zeros
+    assert np.any(oc["u"] != 0) and not np.any(vx["u"] != 0)
+    assert np.all((oc["u"] >= 0) & (oc["v"] >= 0) & (oc["u"] + oc["v"] <= 1 + 1e-12))
+
+
+def test_octree_full_uv_brute_force(box):
+    m, T = box
+    rays = scenes.random_rays(1500, m.size)
+    oc, _ = po.Octree([T], 4, 4).shoot(rays)
+    bf = po.brute(T, rays, full_uv=True)
+    same = oc["poly_id"] == bf["poly_id"]
+    assert same.mean() > 0.995
+    for f in ("t", "u", "v", "x", "y", "z"):
+        assert np.array_equal(oc[f][same], bf[f][same])
+
+
+def test_kdtree_visits_everything_equals_brute_force(box):
+    m, T = box
+    rays = scenes.random_rays(800, m.size)
+    kd, ctr = po.KDTree([T], 8, 8).shoot(rays)
+    bf = po.brute(T, rays, full_uv=True)
+    assert np.array_equal(kd["t"], bf["t"]) and np.array_equal(kd["hit"], bf["hit"])
+    # F4: every leaf is visited -> every polygon is tested once per ray (mailbox dedupes)
+    assert ctr["tests"] == 800 * T.P
+
+
+def test_soup_with_quads_and_outside_origins():
+    v, nv, size = soup()
+    T = po.Topology(v, nv)
+    rays = soup_rays(3000, size)
+    g = po.VoxelGrid([T], domain=8)
+    ev, _ = g.shoot(rays)
+    bf = po.brute(T, rays)
+    # rays that start inside the grid and hit: t equals brute force unless the hit is lost on exit (F12)
+    hit = ev["hit"] == 1
+    assert hit.sum() > 150
+    inside = np.all((rays[:, :3] > g.obox_min) & (rays[:, :3] < g.obox_max), axis=1)
+    both = hit & inside
+    assert np.array_equal(ev["t"][both], bf["t"][both])
+    # a voxel hit is always a brute-force hit too
+    assert np.all(bf["hit"][hit] == 1)
+    # outside origins: t includes t_start, so it matches brute force to rounding only (A.8)
+    out = hit & ~inside
+    assert out.sum() > 20
+    np.testing.assert_allclose(ev["t"][out], bf["t"][out], rtol=1e-12)
+
+
+def test_reflect_is_specular(box):
+    m, T = box
+    rays = scenes.random_rays(500, m.size)
+    ev, _ = po.VoxelGrid([T], domain=8).shoot(rays)
+    r2 = po.reflect(T, rays, ev)
+    n = T.normals[ev["poly_id"]]
+    d, d2 = rays[:, 3:], r2[:, 3:]
+    np.testing.assert_allclose(np.einsum("ij,ij->i", d2, n), -np.einsum("ij,ij->i", d, n), atol=1e-15)
+    np.testing.assert_allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-14)
+    assert np.array_equal(r2[:, 0], ev["x"])
