@@ -95,9 +95,9 @@ def test_voxel_two_topologies():
 def test_single_ray_shoot_mirrors_reference_signature():
     m = H.scenes.shoebox(nface=8, size=(8.0, 4.0, 2.0))
     g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
-    R = H.Ray(3.0, 1.0, 0.75, 1.0, 0.0, 0.0, 0, 1)
+    R = H.Ray(3.0, 1.3125, 0.8125, 1.0, 0.0, 0.0, 0, 1)    # aims strictly inside one wall triangle
     hit, e = g.Shoot(R, 0)
-    assert hit and e.Hit and e.t == 5.0 and e.X_Point == (8.0, 1.0, 0.75) and e.u == 0 and e.v == 0
+    assert hit and e.Hit and e.t == 5.0 and e.X_Point == (8.0, 1.3125, 0.8125) and e.u == 0 and e.v == 0
     hit2, e2 = g.Shoot(R, 0, e.Poly_id)                  # poly_origin1 = the wall just hit
     assert not hit2 and e2.Poly_id == -1 and e2.X_Point is None
     R2 = H.Ray(-5.0, 1.125, 0.75, 1.0, 0.0, 0.0, 0, 2)
@@ -120,8 +120,13 @@ def test_octree_c3_parity_and_voxel_agreement(hall):
     vx, _ = H.Voxel_Grid([T], 64).Shoot_batch(rays)
     assert np.array_equal(ev["hit"], vx["hit"])
     same = ev["poly_id"] == vx["poly_id"]
-    assert same.mean() > 0.999                            # only exact-t ties may differ
-    assert np.array_equal(ev["t"], vx["t"])               # ties have equal t; same poly => same formula
+    assert np.array_equal(ev["t"][same], vx["t"][same])   # same polygon => same formula => same bits
+    # The reference Octree is NOT a closest-hit query on such a scene: children pop far -> near (LIFO)
+    # and the early return of "Octree - alt.cs":233 fires as soon as a hit lies in front of the current
+    # leaf's entry, before nearer leaves were visited (finding F15).  Where the two paths
+    # disagree the octree's hit is therefore strictly FARTHER than the voxel path's, never nearer.
+    assert same.mean() > 0.8
+    assert np.all(ev["t"][~same] > vx["t"][~same])
     assert np.all((ev["u"] >= 0) & (ev["v"] >= 0) & (ev["u"] + ev["v"] <= 1 + 1e-12))
 
 

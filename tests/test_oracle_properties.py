@@ -78,6 +78,23 @@ def test_octree_matches_voxel_t_bit_for_bit(box):
     assert np.all((oc["u"] >= 0) & (oc["v"] >= 0) & (oc["u"] + oc["v"] <= 1 + 1e-12))
 
 
+def test_octree_early_return_can_report_a_farther_hit():
+    """Finding F15: children are pushed near->far and pop far->near; the early return at
+    "Octree - alt.cs":233 fires when a hit lies in front of the current (far) leaf's entry, before
+    nearer leaves are visited.  On a scene with interior solids the octree then reports a hit that
+    is strictly farther than the true closest one -- never a nearer one, and Hit itself agrees."""
+    hall = scenes.hall(edge=1.0)
+    T = po.Topology(hall.verts, hall.nverts)
+    rays = scenes.burst_rays(20000, hall.size)
+    vx, _ = po.VoxelGrid([T], domain=32).shoot(rays, nthreads=4)
+    oc, _ = po.Octree([T], 6, 16).shoot(rays, nthreads=4)
+    assert np.array_equal(oc["hit"], vx["hit"])
+    diff = oc["poly_id"] != vx["poly_id"]
+    assert 0.01 < diff.mean() < 0.5
+    assert np.all(oc["t"][diff] > vx["t"][diff])
+    assert np.array_equal(oc["t"][~diff], vx["t"][~diff])
+
+
 def test_octree_full_uv_brute_force(box):
     m, T = box
     rays = scenes.random_rays(1500, m.size)
