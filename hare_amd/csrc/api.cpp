@@ -174,7 +174,7 @@ int upload_voxel(Scene& s, const HipApi* H)
     s.occ_words = (int32_t)((ncell + 31) / 32);
     for (size_t m = 0; m < M; ++m) {
         std::vector<CellRec> cells(ncell);
-        std::vector<uint32_t> occ((size_t)s.occ_words, 0u);
+        std::vector<uint32_t> occ((size_t)((s.occ_words + 3) / 4) * 4, 0u);   // padded to 16 bytes for uint4 staging
         for (size_t c = 0; c < ncell; ++c) {
             cells[c].start = g.start[m][c];
             cells[c].count = g.start[m][c + 1] - g.start[m][c];
@@ -246,13 +246,30 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             g.omax[a] = s.vox.omax[a];
             g.vd[a] = s.vox.vd[a];
         }
-        hipFunction_t f = count ? M.voxel_count : (quads ? M.voxel_quad : M.voxel_tri);
-        if (!f) {
-            set_error("hare_shoot: kernel missing from code object");
-            return HARE_E_STATE;
+        const bool simple = count || (flags & HARE_SHOOT_SIMPLE_KERNEL) || !M.voxel_persist_tri || !M.voxel_persist_quad;
+        if (simple) {
+            hipFunction_t f = count ? M.voxel_count : (quads ? M.voxel_quad : M.voxel_tri);
+            if (!f) {
+                set_error("hare_shoot: kernel missing from code object");
+                return HARE_E_STATE;
+            }
+            void* args[] = {&g, &io};
+            return launch(H, f, grid, block, 0, st, args);
         }
+        // persistent kernel: a grid that just fills the chip; waves draw ray chunks from a ticket
+        const size_t occ_bytes = (size_t)((s.occ_words + 3) / 4) * 16;
+        g.occ_in_lds = occ_bytes <= 64 * 1024 ? 1 : 0;
+        const unsigned lds = g.occ_in_lds ? (unsigned)occ_bytes : 0u;
+        unsigned per_cu = 4;
+        if (lds) per_cu = std::min<unsigned>(4u, (unsigned)(160 * 1024 / lds));
+        unsigned pgrid = (unsigned)std::max(1, M.cu_count) * std::max(1u, per_cu);
+        pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
+        if (pgrid == 0) pgrid = 1;
+        const unsigned slot = s.work_slot.fetch_add(1) % 64u;
+        io.work = (unsigned int*)s.d_work + slot;
+        HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
         void* args[] = {&g, &io};
-        return launch(H, f, grid, block, 0, st, args);
+        return launch(H, quads ? M.voxel_persist_quad : M.voxel_persist_tri, pgrid, block, lds, st, args);
     }
     if (kind == HARE_KIND_OCTREE) {
         if (!s.oct.built || !s.d_oct_nodes) {

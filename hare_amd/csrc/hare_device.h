@@ -26,6 +26,7 @@ struct CellRec {           // one grid cell: [start, start+count) into items
 
 enum : uint32_t {
     SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
+    SHOOT_SIMPLE_KERNEL = 4u,     // use the one-ray-per-lane kernel instead of the persistent one (A/B, diagnostics)
     SHOOT_ALL_TRIS = 1u << 16,    // internal: topology has no quads
 };
 
@@ -39,6 +40,8 @@ struct VoxelArgs {
     const uint32_t* occ;       // ct^3 bits: cell non-empty
     int32_t ct;
     int32_t occ_words;
+    int32_t occ_in_lds;        // persistent kernel: stage `occ` in LDS (it fits)
+    int32_t pad;
     double omin[3], omax[3];   // OBox
     double vd[3];              // VoxelDims
 };

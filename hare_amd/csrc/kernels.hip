@@ -206,6 +206,238 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 
 
 // ------------------------------------------------------------------------------------------------
+// K1p: Voxel_Grid.Shoot as a persistent, wave-scheduled kernel.
+//
+// Why: in the straightforward kernel a wave executes, for EVERY cell step, the longest candidate list
+// any of its 64 lanes holds -- SIMD utilisation of the polygon test was ~1.5 % on the 100k-tri hall.
+// Here every lane is a small state machine and the wave alternates two uniform phases:
+//   A. lanes whose candidate list is exhausted run up to STEPS_PER_ROUND DDA steps (pending-hit
+//      check, step, occupancy test of the new cell);
+//   B. every lane that holds a candidate tests exactly ONE polygon.
+// Lanes that finish are refilled from a chunk of rays the wave drew with one atomic ticket
+// (ballot + popcount compaction of the idle lanes), so waves stay full until the batch drains.
+// The cell-occupancy bitmap (1 bit per voxel) is staged in LDS once per workgroup, so the ~90 % of
+// DDA steps that cross empty voxels never leave the CU.
+//
+// The arithmetic and the ORDER of candidate tests per ray are exactly those of trace_voxel /
+// Voxel_Grid.cs:561-761; only the interleaving between different rays changes.
+constexpr int STEPS_PER_ROUND = 4;
+constexpr int REFILL_MIN_IDLE = 16;
+constexpr int RAY_CHUNK = 128;
+
+template <bool QUADS>
+__device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t* occ = g.occ;
+    if (g.occ_in_lds) {
+        uint32_t* locc = reinterpret_cast<uint32_t*>(lds_raw);
+        const int nw4 = (g.occ_words + 3) >> 2;           // the device buffer is padded to 16 bytes
+        const uint4* src = reinterpret_cast<const uint4*>(g.occ);
+        uint4* dst = reinterpret_cast<uint4*>(locc);
+        for (int k = threadIdx.x; k < nw4; k += blockDim.x) dst[k] = src[k];
+        __syncthreads();
+        occ = locc;
+    }
+
+    const int ct = g.ct;
+    const double fct = (double)ct;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    // wave-uniform work chunk [cn, ce)
+    long long cn = 0, ce = 0;
+    bool drained = false;
+
+    // ---- per-lane ray state
+    bool alive = false;
+    long long ray = -1;
+    V3 o = {0, 0, 0}, d = {0, 0, 0};
+    double t_start = 0;
+    double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0;
+    int X = 0, Y = 0, Z = 0, cell = 0;
+    int stepX = 1, stepY = 1, stepZ = 1;
+    int e1 = -1, e2 = -1;
+    unsigned int q = 0, qe = 0;
+    int nexti = -1;
+    double tmin = kDblMax;
+    int pid = -1;
+    unsigned int nhits = 0, nrays = 0;
+
+    auto finish = [&](bool hit) {
+        XEventRec ev;
+        if (hit) {
+            ev.t = tmin + t_start;                               // Voxel_Grid.cs:707
+            ev.u = 0; ev.v = 0;
+            ev.x = o.x + d.x * tmin;                             // Polygons.cs:652 (same operands => same bits)
+            ev.y = o.y + d.y * tmin;
+            ev.z = o.z + d.z * tmin;
+            ev.poly_id = pid;
+            ev.hit = 1;
+            nhits++;
+        } else {
+            set_miss(ev);
+        }
+        io.out[ray] = ev;
+        alive = false;
+    };
+    auto enter_cell = [&]() {   // candidate list of the cell just entered
+        q = 0; qe = 0;
+        if ((occ[cell >> 5] >> (cell & 31)) & 1u) {
+            const CellRec c = g.cells[cell];
+            q = c.start;
+            qe = c.start + c.count;
+            nexti = g.items[q];
+        }
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill idle lanes
+        const unsigned long long idle = __ballot(!alive);
+        if (!drained && (__popcll(idle) >= REFILL_MIN_IDLE || idle == ~0ull)) {
+            bool want = !alive;
+            while (true) {
+                const unsigned long long wm = __ballot(want);
+                if (wm == 0) break;
+                if (cn >= ce) {   // draw a new chunk: one atomic per RAY_CHUNK rays per wave
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(io.work, (unsigned int)RAY_CHUNK);
+                    base = __shfl(base, 0, 64);
+                    cn = (long long)base;
+                    ce = cn + RAY_CHUNK < io.n ? cn + RAY_CHUNK : io.n;
+                    if (cn >= io.n) { drained = true; break; }
+                }
+                const int rank = __popcll(wm & lane_lt);
+                const long long mine = cn + rank;
+                const bool got = want && mine < ce;
+                const int taken = __popcll(__ballot(got));
+                cn += taken;
+                if (got) {
+                    want = false;
+                    ray = mine;
+                    // ---------------- per-ray setup: Voxel_Grid.cs:563-632
+                    const RayRec r = io.rays[ray];
+                    o.x = r.x; o.y = r.y; o.z = r.z;
+                    d.x = r.dx; d.y = r.dy; d.z = r.dz;
+                    e1 = io.excl1 ? io.excl1[ray] : -1;
+                    e2 = io.excl2 ? io.excl2[ray] : -1;
+                    t_start = 0;
+                    tmin = kDblMax;
+                    pid = -1;
+                    alive = true;
+                    if (e1 == -2) {           // retired by the bounce loop: miss, not counted
+                        finish(false);
+                    } else {
+                        nrays++;
+                        double fx = floor((o.x - g.omin[0]) / g.vd[0]);
+                        double fy = floor((o.y - g.omin[1]) / g.vd[1]);
+                        double fz = floor((o.z - g.omin[2]) / g.vd[2]);
+                        bool inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
+                        if (!inside) {
+                            if (!aabb_clip_move(g.omin, g.omax, o, d, t_start)) {
+                                finish(false);
+                            } else {
+                                if (io.flags & SHOOT_WRITEBACK_ORIGIN) {
+                                    io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z;
+                                }
+                                fx = floor((o.x - g.omin[0] + d.x * 1E-6) / g.vd[0]);
+                                fy = floor((o.y - g.omin[1] + d.y * 1E-6) / g.vd[1]);
+                                fz = floor((o.z - g.omin[2] + d.z * 1E-6) / g.vd[2]);
+                                inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
+                                if (!inside) finish(false);
+                            }
+                        }
+                        if (alive) {
+                            X = (int)fx; Y = (int)fy; Z = (int)fz;
+                            cell = (X * ct + Y) * ct + Z;
+                            if (d.x < 0) { stepX = -1; tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
+                            else         { stepX = 1;  tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
+                            if (d.y < 0) { stepY = -1; tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
+                            else         { stepY = 1;  tMaxY = (voxel_hi(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * 1.0; }
+                            if (d.z < 0) { stepZ = -1; tMaxZ = (voxel_lo(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * -1.0; }
+                            else         { stepZ = 1;  tMaxZ = (voxel_hi(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * 1.0; }
+                            enter_cell();
+                        }
+                    }
+                }
+                // lanes that asked but found the chunk exhausted loop once more (new chunk)
+            }
+        }
+        if (__ballot(alive) == 0) {
+            if (drained) break;
+            continue;
+        }
+
+        // ------------------------------------------------------------------ phase A: DDA steps
+#pragma unroll 1
+        for (int k = 0; k < STEPS_PER_ROUND; ++k) {
+            const bool walk = alive && q == qe;
+            if (__ballot(walk) == 0) break;
+            if (walk) {
+                // Voxel_Grid.cs:705: pending hit inside the CURRENT padded voxel?
+                bool done = false;
+                if (pid >= 0) {
+                    const double hx = o.x + d.x * tmin, hy = o.y + d.y * tmin, hz = o.z + d.z * tmin;
+                    const double lox = voxel_lo(X, g.vd[0], g.omin[0]), hix = voxel_hi(X, g.vd[0], g.omin[0]);
+                    const double loy = voxel_lo(Y, g.vd[1], g.omin[1]), hiy = voxel_hi(Y, g.vd[1], g.omin[1]);
+                    const double loz = voxel_lo(Z, g.vd[2], g.omin[2]), hiz = voxel_hi(Z, g.vd[2], g.omin[2]);
+                    if (!(hx < lox) && !(hy < loy) && !(hz < loz) && !(hx > hix) && !(hy > hiy) && !(hz > hiz)) {
+                        finish(true);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    // Voxel_Grid.cs:713-759
+                    bool out;
+                    if (tMaxX < tMaxY) {
+                        if (tMaxX < tMaxZ) { X += stepX; out = (X < 0 || X >= ct); tMaxX = tMaxX + tDeltaX; cell += stepX * ct * ct; }
+                        else               { Z += stepZ; out = (Z < 0 || Z >= ct); tMaxZ = tMaxZ + tDeltaZ; cell += stepZ; }
+                    } else {
+                        if (tMaxY < tMaxZ) { Y += stepY; out = (Y < 0 || Y >= ct); tMaxY = tMaxY + tDeltaY; cell += stepY * ct; }
+                        else               { Z += stepZ; out = (Z < 0 || Z >= ct); tMaxZ = tMaxZ + tDeltaZ; cell += stepZ; }
+                    }
+                    if (out) finish(false);     // leaving the grid: miss, even with a pending hit (F12)
+                    else enter_cell();
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ phase B: one polygon test
+        if (alive && q < qe) {
+            const int i = nexti;
+            ++q;
+            if (q < qe) nexti = g.items[q];
+            if (i != e1 && i != e2) {                                       // Voxel_Grid.cs:477
+                const PolyRec& p = g.polys[i];
+                // Ray_Side picks the corner order (Polygons.cs:641-648): (P0,P1,P2) or (P2,P1,P0)
+                const bool side = ray_side(d, p.n);
+                double a[3], c[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { a[m] = side ? p.v0[m] : p.v2[m]; c[m] = side ? p.v2[m] : p.v0[m]; }
+                double t = 0;
+                bool ok = tri_fast(o, d, a, p.v1, c, t);
+                if (QUADS) {
+                    if (!ok && p.nverts == 4) ok = tri_fast(o, d, c, p.v3, a, t);   // (P2,P3,P0) / (P0,P3,P2)
+                }
+                if (ok && t > kTMin && t < tmin) {                          // :691-693
+                    tmin = t;
+                    pid = i;
+                }
+            }
+        }
+    }
+
+    // batch counters: one atomic pair per wave
+    if (io.ctr) {
+        const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
+        if (lane == 0) {
+            atomicAdd(&io.ctr[CTR_RAYS], r);
+            atomicAdd(&io.ctr[CTR_HITS], h);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Octree.Shoot: "Octree - alt.cs":159-284.
 //
 // The reference keeps a LIFO Stack<(node,tmin,tmax)>: an interior node pushes its surviving children
@@ -469,6 +701,10 @@ __global__ __launch_bounds__(256) void hare_voxel_shoot_count(VoxelArgs g, Shoot
 {
     voxel_shoot_body<true, true>(g, io);
 }
+
+// K1p: persistent Voxel_Grid.Shoot (default voxel kernel); dynamic LDS = occupancy bitmap when it fits
+__global__ __launch_bounds__(256) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true>(g, io); }
 
 // K2: Octree.Shoot ("Octree - alt.cs":159-284); dynamic LDS = levels * blockDim * 24 bytes
 __global__ void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }

@@ -2,6 +2,7 @@
 // Product code; nothing from oracle/.
 #pragma once
 #include <stdint.h>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -69,7 +70,8 @@ struct Scene {
     void* d_oct_items = nullptr;
     void* d_kd_nodes = nullptr;
     void* d_kd_items = nullptr;
-    void* d_work = nullptr;                      // ticket counters for persistent kernels (256 B)
+    void* d_work = nullptr;                      // ticket counters for persistent kernels (64 x u32)
+    std::atomic<unsigned> work_slot{0};
 
     // staging for hare_shoot_batch (guarded by mu)
     std::mutex mu;

@@ -148,7 +148,7 @@ class Spatial_Partition:
         return e.Hit, e
 
     def Shoot_batch(self, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
-                    writeback_origin: bool = False, count_work: bool = False):
+                    writeback_origin: bool = False, count_work: bool = False, simple_kernel: bool = False):
         """n rays [n,6] through the HIP kernel (host buffers).  Returns (events, counters dict).
         With writeback_origin the rays array is updated in place like the reference mutates R."""
         if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
@@ -161,7 +161,8 @@ class Spatial_Partition:
         for e in (e1, e2):
             if e is not None and e.shape != (n,):
                 raise ValueError("poly_origin arrays must have one entry per ray")
-        flags = (capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0) | (capi.SHOOT_COUNT_WORK if count_work else 0)
+        flags = ((capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0) | (capi.SHOOT_COUNT_WORK if count_work else 0)
+                 | (capi.SHOOT_SIMPLE_KERNEL if simple_kernel else 0))
         ctr = capi.Counters()
         check(lib.hare_shoot_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), flags,
                                    ptr(out), C.addressof(ctr)))

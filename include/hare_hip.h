@@ -52,6 +52,7 @@ extern "C" {
 /* hare_shoot_* flags */
 #define HARE_SHOOT_WRITEBACK_ORIGIN 1u /* also apply AABB.Intersect's origin move to rays[] (AABB_Main.cs:254-257) */
 #define HARE_SHOOT_COUNT_WORK 2u       /* fill cells/entries/tests of hare_counters (slower diagnostic kernel)       */
+#define HARE_SHOOT_SIMPLE_KERNEL 4u    /* voxel: one-ray-per-lane kernel instead of the persistent one (A/B testing) */
 
 /* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
  * only serve the reference's mailbox pool and are not needed here. 48 bytes. */

@@ -28,9 +28,14 @@ def test_voxel_full_size_c2_1M_rays_100k_tris(hall):
     s, i = g.Voxel_Inv()
     so, io = o.lists()
     assert np.array_equal(s, so) and np.array_equal(i, io)
-    ev, ctr = g.Shoot_batch(rays, count_work=True)
+    ev, ctr = g.Shoot_batch(rays, count_work=True)          # diagnostic one-ray-per-lane kernel + work counters
     ref, rc = o.shoot(rays, nthreads=16)
-    assert_events_equal(ev, ref, what="C2 voxel")
+    assert_events_equal(ev, ref, what="C2 voxel (counting kernel)")
+    evp, cp = g.Shoot_batch(rays)                           # the default, persistent kernel
+    assert_events_equal(evp, ref, what="C2 voxel (persistent kernel)")
+    assert cp["hits"] == rc["hits"] and cp["rays"] == 1 << 20
+    evs, _ = g.Shoot_batch(rays, simple_kernel=True)
+    assert_events_equal(evs, ref, what="C2 voxel (simple kernel)")
     assert ctr["hits"] == rc["hits"] == 1 << 20          # closed room: every primary ray hits
     assert ctr["cells"] == rc["cells"] and ctr["entries"] == rc["entries"]
     assert ctr["tests"] >= rc["tests"]                   # no mailbox on the GPU: duplicates are re-tested
@@ -67,6 +72,7 @@ def test_voxel_quads_outside_origins_exclusions_and_origin_writeback():
     ev, _ = g.Shoot_batch(rays)
     ref, _ = o.shoot(rays)
     assert_events_equal(ev, ref, what="soup voxel")
+    assert_events_equal(g.Shoot_batch(rays, simple_kernel=True)[0], ref, what="soup voxel (simple kernel)")
     assert 0 < ref["hit"].sum() < len(ref)              # both hits and misses are exercised
     # exclusion overload (Voxel_Grid.cs:351,477): exclude what was hit first, and a second id
     e1 = ref["poly_id"].astype(np.int32)

@@ -38,3 +38,8 @@ for _ in range(K): g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=c
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / K
 print("D=%d N=%d: %.3f ms/launch = %.1f Mrays/s" % (D, N, ms, N / ms / 1e3), "ctr", ctr_d.tolist()[:2])
+e0.record()
+for _ in range(K): g.shoot_device(N, dr.data_ptr(), out.data_ptr(), stream=st, flags=4)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / K
+print("simple kernel: %.3f ms/launch = %.1f Mrays/s" % (ms, N / ms / 1e3))
