@@ -1,5 +1,8 @@
 // api.cpp -- the C-ABI of include/hare_hip.h: scene lifetime, device upload, kernel launches.
 // Product code; nothing from oracle/.  There is deliberately no CPU shoot path here.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -69,11 +72,15 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_shoot_count", &m->voxel_count},
         {"hare_voxel_persist_tri", &m->voxel_persist_tri},
         {"hare_voxel_persist_quad", &m->voxel_persist_quad},
+        {"hare_voxel_persist_tri_g", &m->voxel_persist_tri_g},
+        {"hare_voxel_persist_quad_g", &m->voxel_persist_quad_g},
         {"hare_octree_shoot", &m->octree},
         {"hare_octree_shoot_count", &m->octree_count},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
+        {"hare_cull_audit", &m->cull_audit},
+        {"hare_voxel_persist_prof", &m->voxel_persist_prof},
     };
     for (auto& t : table) {
         hipError_t e = H->ModuleGetFunction(t.fn, m->mod, t.name);
@@ -136,28 +143,59 @@ int ensure_device(Scene& s, const HipApi*& H)
     return HARE_OK;
 }
 
+// next float >= |x| * (1 + 2^-20): error-bound factors must never be rounded down
+float up(double x)
+{
+    float f = (float)(fabs(x) * 1.00000095367431640625);
+    while ((double)f < fabs(x)) f = nextafterf(f, INFINITY);
+    return f;
+}
+
 int upload_polys(Scene& s, const HipApi* H)
 {
     if (s.d_polys.size() == s.topos.size()) return HARE_OK;
     s.d_polys.assign(s.topos.size(), nullptr);
+    s.d_quads.assign(s.topos.size(), nullptr);
     for (size_t m = 0; m < s.topos.size(); ++m) {
         const Topo& T = s.topos[m];
         std::vector<PolyRec> rec((size_t)std::max(T.P, 1));
         memset(rec.data(), 0, rec.size() * sizeof(PolyRec));
+        std::vector<QuadRec> quads;
+        if (T.has_quads) {
+            quads.resize((size_t)T.P);
+            memset(quads.data(), 0, quads.size() * sizeof(QuadRec));
+        }
         for (int32_t p = 0; p < T.P; ++p) {
             const double* V = &T.verts[(size_t)p * 12];
             PolyRec& r = rec[p];
+            double e1[3], e2[3], n1 = 0, emax = 0;
             for (int a = 0; a < 3; ++a) {
                 r.v0[a] = V[a];
                 r.v1[a] = V[3 + a];
                 r.v2[a] = V[6 + a];
-                r.v3[a] = T.nverts[p] == 4 ? V[9 + a] : 0.0;
                 r.n[a] = T.normals[(size_t)p * 3 + a];
+                e1[a] = V[3 + a] - V[a];            // edge1 / edge2 of RayXtri (Polygons.cs:452-457)
+                e2[a] = V[6 + a] - V[a];
+                r.e1f[a] = (float)e1[a];
+                r.e2f[a] = (float)e2[a];
+                n1 += fabs(e1[a]);
+                emax = std::max(emax, std::max(fabs(e1[a]), fabs(e2[a])));
             }
-            r.nverts = T.nverts[p];
+            r.emax = up(emax);
+            r.ee = up(n1 * (double)r.emax);
+            if (T.nverts[p] == 4) {
+                r.emax = INFINITY;                  // quadrilaterals are never pre-culled
+                r.ee = INFINITY;
+                for (int a = 0; a < 3; ++a) quads[p].v3[a] = V[9 + a];
+            }
+            if (T.has_quads) quads[p].nverts = T.nverts[p];
         }
         int rc = upload(H, &s.d_polys[m], rec.data(), rec.size() * sizeof(PolyRec));
         if (rc) return rc;
+        if (T.has_quads) {
+            rc = upload(H, &s.d_quads[m], quads.data(), quads.size() * sizeof(QuadRec));
+            if (rc) return rc;
+        }
     }
     return HARE_OK;
 }
@@ -178,6 +216,8 @@ int upload_voxel(Scene& s, const HipApi* H)
         for (size_t c = 0; c < ncell; ++c) {
             cells[c].start = g.start[m][c];
             cells[c].count = g.start[m][c + 1] - g.start[m][c];
+            cells[c].i0 = cells[c].count > 0 ? g.items[m][cells[c].start] : -1;
+            cells[c].i1 = cells[c].count > 1 ? g.items[m][cells[c].start + 1] : -1;
             if (cells[c].count) occ[c >> 5] |= 1u << (c & 31);
         }
         int rc = upload(H, &s.d_cells[m], cells.data(), cells.size() * sizeof(CellRec));
@@ -221,7 +261,23 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.ctr = (unsigned long long*)d_ctr;
     io.work = (unsigned int*)s.d_work;
     io.n = n;
-    io.flags = flags & 0xFFFFu;
+    io.flags = flags & 0x3FFFu;
+    io.steps_per_round = 4;
+    io.refill_min_idle = 16;
+    io.ray_chunk = 128;
+    io.exact_min_parked = 24;
+    io.audit_polys = s.topos[top].P;
+    unsigned tune_blocks_per_cu = 0;
+    if (getenv("HARE_TUNE")) {   // developer knob sweep: HARE_TUNE=steps,refill,chunk,blocks_per_cu
+        int a = 0, b = 0, c = 0, d = 0, e = 0;
+        if (sscanf(getenv("HARE_TUNE"), "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e) >= 3 && a > 0 && b > 0 && b <= 64 && c > 0) {
+            io.steps_per_round = a;
+            io.refill_min_idle = b;
+            io.ray_chunk = c;
+            tune_blocks_per_cu = d > 0 ? (unsigned)d : 0u;
+            if (e > 0 && e <= 64) io.exact_min_parked = e;
+        }
+    }
     const bool quads = s.topos[top].has_quads;
     const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0;
     const DeviceModule& M = *s.module;
@@ -236,6 +292,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         VoxelArgs g;
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
+        g.quads = (const QuadRec*)s.d_quads[top];
         g.cells = (const CellRec*)s.d_cells[top];
         g.items = (const int32_t*)s.d_items[top];
         g.occ = (const uint32_t*)s.d_occ[top];
@@ -246,7 +303,16 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             g.omax[a] = s.vox.omax[a];
             g.vd[a] = s.vox.vd[a];
         }
-        const bool simple = count || (flags & HARE_SHOOT_SIMPLE_KERNEL) || !M.voxel_persist_tri || !M.voxel_persist_quad;
+        if (flags & 0x8000u) {   // tests only: FP32-cull audit (counters 5..7)
+            if (!M.cull_audit || quads) {
+                set_error("hare_shoot: cull audit needs an all-triangle topology and the audit kernel");
+                return HARE_E_STATE;
+            }
+            void* args[] = {&g, &io};
+            return launch(H, M.cull_audit, grid, block, 0, st, args);
+        }
+        const bool simple = count || (flags & HARE_SHOOT_SIMPLE_KERNEL) || !M.voxel_persist_tri || !M.voxel_persist_quad ||
+                            !M.voxel_persist_tri_g || !M.voxel_persist_quad_g;
         if (simple) {
             hipFunction_t f = count ? M.voxel_count : (quads ? M.voxel_quad : M.voxel_tri);
             if (!f) {
@@ -261,7 +327,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.occ_in_lds = occ_bytes <= 64 * 1024 ? 1 : 0;
         const unsigned lds = g.occ_in_lds ? (unsigned)occ_bytes : 0u;
         unsigned per_cu = 4;
-        if (lds) per_cu = std::min<unsigned>(4u, (unsigned)(160 * 1024 / lds));
+        if (tune_blocks_per_cu) per_cu = tune_blocks_per_cu;
+        if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(160 * 1024 / lds));
         unsigned pgrid = (unsigned)std::max(1, M.cu_count) * std::max(1u, per_cu);
         pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
         if (pgrid == 0) pgrid = 1;
@@ -269,7 +336,14 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         io.work = (unsigned int*)s.d_work + slot;
         HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
         void* args[] = {&g, &io};
-        return launch(H, quads ? M.voxel_persist_quad : M.voxel_persist_tri, pgrid, block, lds, st, args);
+        hipFunction_t pf = g.occ_in_lds ? (quads ? M.voxel_persist_quad : M.voxel_persist_tri)
+                                        : (quads ? M.voxel_persist_quad_g : M.voxel_persist_tri_g);
+        if ((flags & 0x4000u) && M.voxel_persist_prof && g.occ_in_lds && !quads && d_ctr) {
+            // developer profiling: phase statistics land in the 17 u64 words FOLLOWING the counters block
+            io.prof = (unsigned long long*)d_ctr + CTR_WORDS;
+            pf = M.voxel_persist_prof;
+        }
+        return launch(H, pf, pgrid, block, lds, st, args);
     }
     if (kind == HARE_KIND_OCTREE) {
         if (!s.oct.built || !s.d_oct_nodes) {
@@ -279,6 +353,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         OctreeArgs g;
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
+        g.quads = (const QuadRec*)s.d_quads[top];
         g.nodes = (const OctNode*)s.d_oct_nodes;
         g.items = (const int32_t*)s.d_oct_items;
         g.n_nodes = (int32_t)s.oct.nodes.size();
@@ -304,6 +379,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         KdArgs g;
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
+        g.quads = (const QuadRec*)s.d_quads[top];
         g.nodes = (const KdNodeRec*)s.d_kd_nodes;
         g.items = (const int32_t*)s.d_kd_items;
         g.n_nodes = (int32_t)s.kd.nodes.size();
@@ -433,7 +509,7 @@ void hare_scene_destroy(hare_scene* s)
     if (H && (s->module || s->stream)) {
         (void)H->SetDevice(s->device);
         if (s->stream) (void)H->StreamSynchronize(s->stream);
-        for (auto* v : {&s->d_polys, &s->d_cells, &s->d_items, &s->d_occ})
+        for (auto* v : {&s->d_polys, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_rays,
                          &s->d_e1, &s->d_e2, &s->d_out, &s->d_ctr})

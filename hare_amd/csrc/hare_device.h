@@ -19,10 +19,12 @@ struct XEventRec {         // Hare.Geometry.X_Event: Hare_Geometry_Primitives.cs
 static_assert(sizeof(RayRec) == 48, "ray wire size");
 static_assert(sizeof(XEventRec) == 56, "x_event wire size");
 
-struct CellRec {           // one grid cell: [start, start+count) into items
+struct CellRec {           // one grid cell: [start, start+count) into items; 16 bytes = one load
     uint32_t start;
     uint32_t count;
+    int32_t i0, i1;        // items[start], items[start+1] inlined: entering a cell costs ONE dependent load
 };
+static_assert(sizeof(CellRec) == 16, "cell record size");
 
 enum : uint32_t {
     SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
@@ -35,6 +37,7 @@ enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4
 
 struct VoxelArgs {
     const PolyRec* polys;
+    const QuadRec* quads;      // null when the topology is all triangles
     const CellRec* cells;      // ct^3, cell = (x*ct + y)*ct + z
     const int32_t* items;
     const uint32_t* occ;       // ct^3 bits: cell non-empty
@@ -57,6 +60,7 @@ static_assert(sizeof(OctNode) == 64, "octree node size");
 
 struct OctreeArgs {
     const PolyRec* polys;
+    const QuadRec* quads;
     const OctNode* nodes;
     const int32_t* items;
     int32_t n_nodes;
@@ -74,6 +78,7 @@ struct KdNodeRec {             // 80 bytes
 
 struct KdArgs {
     const PolyRec* polys;
+    const QuadRec* quads;
     const KdNodeRec* nodes;
     const int32_t* items;
     int32_t n_nodes;
@@ -87,9 +92,14 @@ struct ShootIO {
     XEventRec* out;            // n
     unsigned long long* ctr;   // nullable: CTR_WORDS counters, atomically accumulated
     unsigned int* work;        // persistent kernels: next-ray ticket (zeroed before launch)
+    unsigned long long* prof;  // developer profiling kernel: 17 x u64 phase statistics (else null)
     int64_t n;
     uint32_t flags;
-    uint32_t pad;
+    int32_t steps_per_round;   // persistent kernel: DDA steps per scheduling round
+    int32_t refill_min_idle;   // persistent kernel: refill when this many lanes are idle
+    int32_t ray_chunk;         // persistent kernel: rays drawn per ticket
+    int32_t exact_min_parked;  // persistent kernel: run the FP64 phase when this many lanes hold a survivor
+    int32_t audit_polys;       // hare_cull_audit: polygon count
 };
 
 }  // namespace hare

@@ -20,16 +20,29 @@ struct V3 {
     double x, y, z;
 };
 
-// One polygon = one 128-byte record = one L2 line: a lane that tests polygon i touches exactly
-// one line.  Triangles only need the first 96 bytes (v0 v1 v2 n).
+// One polygon = one 128-byte record = one L2 line: a lane that tests polygon i touches exactly one
+// line.  The first 56 bytes serve the conservative FP32 pre-cull (v0 + the two edges from v0 as
+// floats + two error-bound factors); the exact FP64 test reads the rest.
 struct alignas(128) PolyRec {
-    double v0[3], v1[3], v2[3];
-    double n[3];
+    double v0[3];      //   0
+    float e1f[3];      //  24  (float)(v1 - v0)
+    float e2f[3];      //  36  (float)(v2 - v0)
+    float ee;          //  48  |e1|_1 * emax, rounded up (margin factor of the determinant)
+    float emax;        //  52  max(|e1|_inf, |e2|_inf), rounded up; +inf: never cull (quadrilaterals)
+    double v1[3];      //  56
+    double v2[3];      //  80
+    double n[3];       // 104  Polygon.Normal
+};
+static_assert(sizeof(PolyRec) == 128, "PolyRec must be one 128-byte line");
+
+// Fourth corner + corner count, kept in a side array that only exists for topologies with
+// quadrilaterals (Hare's room meshes are almost always triangles).
+struct QuadRec {
     double v3[3];
     int32_t nverts;
     int32_t pad;
 };
-static_assert(sizeof(PolyRec) == 128, "PolyRec must be one 128-byte line");
+static_assert(sizeof(QuadRec) == 32, "QuadRec size");
 
 // Hare_math.Dot: Hare_Geometry_Math.cs:43-46
 HARE_HD double dot3(double ax, double ay, double az, double bx, double by, double bz)
@@ -132,29 +145,67 @@ HARE_HD bool ray_side(const V3& d, const double* n)
 
 // Triangle.Intersect fast (Polygons.cs:637-660) / Quadrilateral.Intersect fast (:784-823).
 // On a hit returns t; the caller forms the hit point O + d*t (:652).
-HARE_HD bool poly_fast(const PolyRec& p, bool quad, const V3& o, const V3& d, double& t)
+// v3 = fourth corner for a quadrilateral, nullptr for a triangle.
+HARE_HD bool poly_fast(const PolyRec& p, const double* v3, const V3& o, const V3& d, double& t)
 {
     t = 0;
     if (ray_side(d, p.n)) {
         if (tri_fast(o, d, p.v0, p.v1, p.v2, t)) return true;
-        return quad && tri_fast(o, d, p.v2, p.v3, p.v0, t);
+        return v3 && tri_fast(o, d, p.v2, v3, p.v0, t);
     }
     if (tri_fast(o, d, p.v2, p.v1, p.v0, t)) return true;
-    return quad && tri_fast(o, d, p.v0, p.v3, p.v2, t);
+    return v3 && tri_fast(o, d, p.v0, v3, p.v2, t);
 }
 
 // Triangle.Intersect full (Polygons.cs:662-688) / Quadrilateral.Intersect full (:731-782).
-HARE_HD bool poly_full(const PolyRec& p, bool quad, const V3& o, const V3& d, double& t, double& u, double& v)
+HARE_HD bool poly_full(const PolyRec& p, const double* v3, const V3& o, const V3& d, double& t, double& u, double& v)
 {
     u = 0;
     v = 0;
     t = 0;
     if (ray_side(d, p.n)) {
         if (tri_full(o, d, p.v0, p.v1, p.v2, t, u, v)) return true;
-        return quad && tri_full(o, d, p.v2, p.v3, p.v0, t, u, v);
+        return v3 && tri_full(o, d, p.v2, v3, p.v0, t, u, v);
     }
     if (tri_full(o, d, p.v2, p.v1, p.v0, t, u, v)) return true;
-    return quad && tri_full(o, d, p.v0, p.v3, p.v2, t, u, v);
+    return v3 && tri_full(o, d, p.v0, v3, p.v2, t, u, v);
+}
+
+// ---- conservative FP32 pre-cull of one ray/triangle pair -------------------------------------
+// Not in the reference: a filter in front of RayXtri.  It may only reject a candidate the exact
+// FP64 test is certain to reject, so the set of accepted hits -- and therefore every X_Event -- is
+// unchanged.  RayXtri accepts iff |det| > 1e-6 and the three barycentric weights
+// (det-u-v)/det, u/det, v/det are all >= 0 (for either corner order Ray_Side picks: reversing the
+// order maps (u,v,det) to (-u, u+v-det, -det), the same three weights).  u, v and det are triple
+// products a.(b x c): six terms, each a product of three components.  Evaluated in FP32 from
+// inputs rounded to FP32, each term carries at most ~7 roundings of 2^-24; the sum of the |terms|
+// is at most 2*|a|_1*|b|_inf*|c|_inf.  With G = 2^-18 (>= 4x the worst case) the margins are
+//   M_uv  = G * |tv|_1 * |d|_1 * emax          (u, v;   emax >= |e1|_inf, |e2|_inf)
+//   M_det = G * |d|_1 * ee                     (det;    ee   >= |e1|_1 * emax)
+// plus 1e-30 against underflow.  Candidates whose determinant sign is not certain (|det| <= M_det)
+// are kept.  NaN/inf anywhere makes every comparison false: the candidate is kept.
+HARE_HD bool cull_fp32(float tvx, float tvy, float tvz, float dx, float dy, float dz, float dm /*|d|_1*/,
+                       const float* e1, const float* e2, float ee, float emax)
+{
+    const float G = 3.814697265625e-06f;   // 2^-18
+    const float px = dy * e2[2] - dz * e2[1];
+    const float py = dz * e2[0] - dx * e2[2];
+    const float pz = dx * e2[1] - dy * e2[0];
+    const float det = e1[0] * px + e1[1] * py + e1[2] * pz;
+    const float u = tvx * px + tvy * py + tvz * pz;
+    const float qx = tvy * e1[2] - tvz * e1[1];
+    const float qy = tvz * e1[0] - tvx * e1[2];
+    const float qz = tvx * e1[1] - tvy * e1[0];
+    const float v = dx * qx + dy * qy + dz * qz;
+    const float tvm = fabsf(tvx) + fabsf(tvy) + fabsf(tvz);
+    const float muv = G * tvm * dm * emax + 1e-30f;
+    const float md = G * dm * ee + 1e-30f;
+    const float adet = fabsf(det);
+    const float su = det < 0.0f ? -u : u;
+    const float sv = det < 0.0f ? -v : v;
+    const bool certain = adet > md;
+    const bool out = (adet < 0.000001f - md) | (su < -muv) | (sv < -muv) | (adet - su - sv < -(md + 2.0f * muv));
+    return certain & out;   // true = safe to skip the FP64 test
 }
 
 // AABB.Intersect(ref Ray, ref tmin): AABB_Main.cs:173-260.  Moves the origin on success.
@@ -194,6 +245,26 @@ HARE_HD bool aabb_clip_move(const double* bmin, const double* bmax, V3& o, const
 // Padded voxel box along one axis: Voxel_Grid.cs:283-285 (+ Point + Point, Primitives.cs:156-159)
 HARE_HD double voxel_lo(int i, double vd, double omin) { return (i * vd - 0.001) + omin; }
 HARE_HD double voxel_hi(int i, double vd, double omin) { return ((i + 1) * vd + 0.001) + omin; }
+
+// Index range [imin, imax] of the voxels (along one axis) whose padded box contains coordinate h under
+// AABB.IsPointInBox's own comparisons (AABB_Main.cs:75-84: reject if h < Min or h > Max), evaluated
+// with the exact padded-box arithmetic above.  voxel_lo / voxel_hi are monotone non-decreasing in i
+// (each is a chain of correctly rounded monotone operations), so {i : lo(i) <= h} is a prefix and
+// {i : hi(i) >= h} a suffix of 0..ct-1; their intersection is what this returns (imin > imax: empty).
+// NaN h passes every comparison, like the reference: the range is 0..ct-1.
+HARE_HD void voxel_accept_range(double h, double vd, double omin, int ct, int& imin, int& imax)
+{
+    double gf = floor((h - omin) / vd);
+    int g = (gf >= 0.0) ? ((gf < (double)ct) ? (int)gf : ct - 1) : 0;   // NaN -> 0
+    int hi_i = g;
+    while (hi_i + 1 < ct && !(h < voxel_lo(hi_i + 1, vd, omin))) ++hi_i;
+    while (hi_i >= 0 && (h < voxel_lo(hi_i, vd, omin))) --hi_i;
+    int lo_i = g;
+    while (lo_i - 1 >= 0 && !(h > voxel_hi(lo_i - 1, vd, omin))) --lo_i;
+    while (lo_i < ct && (h > voxel_hi(lo_i, vd, omin))) ++lo_i;
+    imin = lo_i;
+    imax = hi_i;
+}
 
 // ---- AABB.PolyBoxOverlap: AABB_Tri_Int.cs:165-260 (Akenine-Moller SAT as Hare translated it) ----
 // One fan triangle against a box given by centre c and half-width h (AABB ctor, AABB_Main.cs:64-67).

@@ -124,8 +124,8 @@ __device__ __forceinline__ bool trace_voxel(const VoxelArgs& g, V3& o, const V3&
             if (COUNT) w.tests++;
             const PolyRec& p = g.polys[i];
             double t;
-            const bool quad = QUADS && p.nverts == 4;
-            if (poly_fast(p, quad, o, d, t) && t > kTMin) {       // :691
+            const double* v3 = (QUADS && g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
+            if (poly_fast(p, v3, o, d, t) && t > kTMin) {         // :691
                 if (t < tmin) {                                   // :693
                     have = true;
                     hx = o.x + d.x * t;                           // Polygons.cs:652
@@ -209,41 +209,56 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 // K1p: Voxel_Grid.Shoot as a persistent, wave-scheduled kernel.
 //
 // Why: in the straightforward kernel a wave executes, for EVERY cell step, the longest candidate list
-// any of its 64 lanes holds -- SIMD utilisation of the polygon test was ~1.5 % on the 100k-tri hall.
-// Here every lane is a small state machine and the wave alternates two uniform phases:
-//   A. lanes whose candidate list is exhausted run up to STEPS_PER_ROUND DDA steps (pending-hit
-//      check, step, occupancy test of the new cell);
-//   B. every lane that holds a candidate tests exactly ONE polygon.
+// any of its 64 lanes holds -- SIMD utilisation of the polygon test was ~1.5 % on the 100k-tri hall --
+// and every candidate costs a full FP64 Moller-Trumbore (~90 quarter-rate instructions) although
+// ~17 of 18 candidates per ray are misses.  Here every lane is a small state machine and the wave
+// alternates uniform phases:
+//   A.  lanes whose candidate list is exhausted run up to `steps_per_round` DDA steps (pending-hit
+//       check, step, occupancy test of the new cell);
+//   B1. every lane that holds a candidate runs the conservative FP32 pre-cull (cull_fp32,
+//       hare_math.h) on it; rejected candidates are dropped, survivors park the lane;
+//   B2. when enough lanes are parked (or nothing else can progress) the parked lanes run the exact
+//       FP64 test -- the reference's RayXtri, the only thing that decides a hit.
 // Lanes that finish are refilled from a chunk of rays the wave drew with one atomic ticket
 // (ballot + popcount compaction of the idle lanes), so waves stay full until the batch drains.
 // The cell-occupancy bitmap (1 bit per voxel) is staged in LDS once per workgroup, so the ~90 % of
-// DDA steps that cross empty voxels never leave the CU.
+// DDA steps that cross empty voxels never leave the CU.  Each polygon is one 128-byte line; the
+// cull reads its first 64 bytes, the exact test the rest, both requested one phase before use.
 //
-// The arithmetic and the ORDER of candidate tests per ray are exactly those of trace_voxel /
-// Voxel_Grid.cs:561-761; only the interleaving between different rays changes.
-constexpr int STEPS_PER_ROUND = 4;
-constexpr int REFILL_MIN_IDLE = 16;
-constexpr int RAY_CHUNK = 128;
-
-template <bool QUADS>
+// Per ray, the sequence of EXACT tests is the reference's candidate sequence with some certain
+// misses removed; accepted hits, their order and their arithmetic are unchanged (Voxel_Grid.cs:561-761).
+template <bool QUADS, bool OCC_LDS, bool PROF = false>
 __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
 {
+    // PROF: developer build with s_memtime stamps per phase (never the timed kernel)
+    unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tstamp = 0;
+    auto stamp = [&](int slot) {
+        if (PROF) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            pf[slot] += now - tstamp;
+            tstamp = now;
+        }
+    };
+    if (PROF) tstamp = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint32_t* occ = g.occ;
-    if (g.occ_in_lds) {
-        uint32_t* locc = reinterpret_cast<uint32_t*>(lds_raw);
+    uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);   // address space known: ds_read, not flat
+    if (OCC_LDS) {
         const int nw4 = (g.occ_words + 3) >> 2;           // the device buffer is padded to 16 bytes
         const uint4* src = reinterpret_cast<const uint4*>(g.occ);
         uint4* dst = reinterpret_cast<uint4*>(locc);
         for (int k = threadIdx.x; k < nw4; k += blockDim.x) dst[k] = src[k];
         __syncthreads();
-        occ = locc;
     }
 
     const int ct = g.ct;
     const double fct = (double)ct;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int STEPS_PER_ROUND = io.steps_per_round;
+    const int REFILL_MIN_IDLE = io.refill_min_idle;
+    const int RAY_CHUNK = io.ray_chunk;
+    const int EXACT_MIN_PARKED = io.exact_min_parked;
 
     // wave-uniform work chunk [cn, ce)
     long long cn = 0, ce = 0;
@@ -251,22 +266,29 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 
     // ---- per-lane ray state
     bool alive = false;
-    long long ray = -1;
+    bool parked = false;             // holds a candidate that survived the cull, waiting for phase B2
+    bool moved = false;              // origin was clipped to OBox: t_start is parked in out[ray].t
+    unsigned int ray = 0;
     V3 o = {0, 0, 0}, d = {0, 0, 0};
-    double t_start = 0;
     double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0;
     int X = 0, Y = 0, Z = 0, cell = 0;
-    int stepX = 1, stepY = 1, stepZ = 1;
     int e1 = -1, e2 = -1;
-    unsigned int q = 0, qe = 0;
-    int nexti = -1;
+    unsigned int q = 0, qe = 0;      // q: position of the CURRENT candidate `idx` in items
+    int idx = -1, nexti = -1;        // current / following candidate polygon
+    int done1 = -1, done2 = -1;      // the two polygons this ray tested last (register mailbox)
     double tmin = kDblMax;
     int pid = -1;
     unsigned int nhits = 0, nrays = 0;
 
+    // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the ones
+    // this ray has just tested is exact; it replaces the reference's Poly_Ray_ID mailbox
+    // (Voxel_Grid.cs:687-689) for the common case of a polygon listed in consecutive voxels.
+    auto skip = [&](int i) { return i == e1 || i == e2 || i == done1 || i == done2; };
     auto finish = [&](bool hit) {
         XEventRec ev;
         if (hit) {
+            double t_start = 0;
+            if (moved) t_start = io.out[ray].t;                  // parked there by the setup
             ev.t = tmin + t_start;                               // Voxel_Grid.cs:707
             ev.u = 0; ev.v = 0;
             ev.x = o.x + d.x * tmin;                             // Polygons.cs:652 (same operands => same bits)
@@ -281,21 +303,33 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
         io.out[ray] = ev;
         alive = false;
     };
-    auto enter_cell = [&]() {   // candidate list of the cell just entered
-        q = 0; qe = 0;
-        if ((occ[cell >> 5] >> (cell & 31)) & 1u) {
+    // the voxel just entered: occupancy bit from LDS; only a non-empty voxel touches memory
+    auto enter_cell = [&]() {
+        const uint32_t word = OCC_LDS ? locc[cell >> 5] : g.occ[cell >> 5];
+        if ((word >> (cell & 31)) & 1u) {
             const CellRec c = g.cells[cell];
             q = c.start;
             qe = c.start + c.count;
-            nexti = g.items[q];
+            idx = c.i0;
+            nexti = c.i1;
+        }
+    };
+    auto next_candidate = [&]() {
+        ++q;
+        if (q < qe) {
+            idx = nexti;
+            if (q + 1 < qe) nexti = g.items[q + 1];
         }
     };
 
+    stamp(0);
     for (;;) {
+        if (PROF) pf[5]++;
         // ------------------------------------------------------------------ refill idle lanes
         const unsigned long long idle = __ballot(!alive);
         if (!drained && (__popcll(idle) >= REFILL_MIN_IDLE || idle == ~0ull)) {
             bool want = !alive;
+            if (PROF) { pf[12]++; pf[13] += __popcll(idle); }
             while (true) {
                 const unsigned long long wm = __ballot(want);
                 if (wm == 0) break;
@@ -314,16 +348,19 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                 cn += taken;
                 if (got) {
                     want = false;
-                    ray = mine;
+                    ray = (unsigned int)mine;
                     // ---------------- per-ray setup: Voxel_Grid.cs:563-632
                     const RayRec r = io.rays[ray];
                     o.x = r.x; o.y = r.y; o.z = r.z;
                     d.x = r.dx; d.y = r.dy; d.z = r.dz;
                     e1 = io.excl1 ? io.excl1[ray] : -1;
                     e2 = io.excl2 ? io.excl2[ray] : -1;
-                    t_start = 0;
                     tmin = kDblMax;
                     pid = -1;
+                    done1 = -1; done2 = -1;
+                    q = 0; qe = 0;
+                    parked = false;
+                    moved = false;
                     alive = true;
                     if (e1 == -2) {           // retired by the bounce loop: miss, not counted
                         finish(false);
@@ -334,9 +371,12 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                         double fz = floor((o.z - g.omin[2]) / g.vd[2]);
                         bool inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
                         if (!inside) {
+                            double t_start = 0;
                             if (!aabb_clip_move(g.omin, g.omax, o, d, t_start)) {
                                 finish(false);
                             } else {
+                                moved = true;
+                                io.out[ray].t = t_start;          // read back by finish(); keeps 2 VGPRs free
                                 if (io.flags & SHOOT_WRITEBACK_ORIGIN) {
                                     io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z;
                                 }
@@ -350,12 +390,12 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                         if (alive) {
                             X = (int)fx; Y = (int)fy; Z = (int)fz;
                             cell = (X * ct + Y) * ct + Z;
-                            if (d.x < 0) { stepX = -1; tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
-                            else         { stepX = 1;  tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
-                            if (d.y < 0) { stepY = -1; tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
-                            else         { stepY = 1;  tMaxY = (voxel_hi(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * 1.0; }
-                            if (d.z < 0) { stepZ = -1; tMaxZ = (voxel_lo(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * -1.0; }
-                            else         { stepZ = 1;  tMaxZ = (voxel_hi(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * 1.0; }
+                            if (d.x < 0) { tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
+                            else         { tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
+                            if (d.y < 0) { tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
+                            else         { tMaxY = (voxel_hi(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * 1.0; }
+                            if (d.z < 0) { tMaxZ = (voxel_lo(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * -1.0; }
+                            else         { tMaxZ = (voxel_hi(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * 1.0; }
                             enter_cell();
                         }
                     }
@@ -363,16 +403,19 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                 // lanes that asked but found the chunk exhausted loop once more (new chunk)
             }
         }
+        stamp(1);
         if (__ballot(alive) == 0) {
             if (drained) break;
             continue;
         }
+        if (PROF) pf[14] += __popcll(__ballot(alive));
 
         // ------------------------------------------------------------------ phase A: DDA steps
 #pragma unroll 1
         for (int k = 0; k < STEPS_PER_ROUND; ++k) {
             const bool walk = alive && q == qe;
             if (__ballot(walk) == 0) break;
+            if (PROF) { pf[6]++; pf[7] += __popcll(__ballot(walk)); }
             if (walk) {
                 // Voxel_Grid.cs:705: pending hit inside the CURRENT padded voxel?
                 bool done = false;
@@ -387,43 +430,107 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     }
                 }
                 if (!done) {
-                    // Voxel_Grid.cs:713-759
-                    bool out;
-                    if (tMaxX < tMaxY) {
-                        if (tMaxX < tMaxZ) { X += stepX; out = (X < 0 || X >= ct); tMaxX = tMaxX + tDeltaX; cell += stepX * ct * ct; }
-                        else               { Z += stepZ; out = (Z < 0 || Z >= ct); tMaxZ = tMaxZ + tDeltaZ; cell += stepZ; }
-                    } else {
-                        if (tMaxY < tMaxZ) { Y += stepY; out = (Y < 0 || Y >= ct); tMaxY = tMaxY + tDeltaY; cell += stepY * ct; }
-                        else               { Z += stepZ; out = (Z < 0 || Z >= ct); tMaxZ = tMaxZ + tDeltaZ; cell += stepZ; }
-                    }
+                    // Voxel_Grid.cs:713-759, written with selects instead of the nested branches (same
+                    // booleans, same order): X iff (tMaxX<tMaxY && tMaxX<tMaxZ); Y iff (!(tMaxX<tMaxY) &&
+                    // tMaxY<tMaxZ); otherwise Z.  Step direction = sign of d (:589-632).
+                    const bool cxy = tMaxX < tMaxY, cxz = tMaxX < tMaxZ, cyz = tMaxY < tMaxZ;
+                    const bool sx = cxy & cxz;
+                    const bool sy = (!cxy) & cyz;
+                    const bool sz = !(sx | sy);
+                    const int dx1 = d.x < 0 ? -1 : 1, dy1 = d.y < 0 ? -1 : 1, dz1 = d.z < 0 ? -1 : 1;
+                    const double nX = tMaxX + tDeltaX, nY = tMaxY + tDeltaY, nZ = tMaxZ + tDeltaZ;
+                    X += sx ? dx1 : 0;
+                    Y += sy ? dy1 : 0;
+                    Z += sz ? dz1 : 0;
+                    tMaxX = sx ? nX : tMaxX;
+                    tMaxY = sy ? nY : tMaxY;
+                    tMaxZ = sz ? nZ : tMaxZ;
+                    cell += sx ? dx1 * ct * ct : (sy ? dy1 * ct : dz1);
+                    const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
                     if (out) finish(false);     // leaving the grid: miss, even with a pending hit (F12)
                     else enter_cell();
                 }
             }
         }
 
-        // ------------------------------------------------------------------ phase B: one polygon test
-        if (alive && q < qe) {
-            const int i = nexti;
-            ++q;
-            if (q < qe) nexti = g.items[q];
-            if (i != e1 && i != e2) {                                       // Voxel_Grid.cs:477
-                const PolyRec& p = g.polys[i];
-                // Ray_Side picks the corner order (Polygons.cs:641-648): (P0,P1,P2) or (P2,P1,P0)
-                const bool side = ray_side(d, p.n);
-                double a[3], c[3];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) { a[m] = side ? p.v0[m] : p.v2[m]; c[m] = side ? p.v2[m] : p.v0[m]; }
-                double t = 0;
-                bool ok = tri_fast(o, d, a, p.v1, c, t);
-                if (QUADS) {
-                    if (!ok && p.nverts == 4) ok = tri_fast(o, d, c, p.v3, a, t);   // (P2,P3,P0) / (P0,P3,P2)
-                }
-                if (ok && t > kTMin && t < tmin) {                          // :691-693
-                    tmin = t;
-                    pid = i;
+        stamp(2);
+        // ------------------------------------------------------------------ phase B1: FP32 cull
+        if (PROF) { const unsigned long long m = __ballot(alive && !parked && q < qe); if (m) { pf[8]++; pf[9] += __popcll(m); } }
+        if (alive && !parked && q < qe) {
+            if (skip(idx)) {                                                // Voxel_Grid.cs:477 (+ mailbox)
+                next_candidate();
+            } else {
+                // first 56 bytes of the record: v0 (FP64) + e1f e2f ee emax (FP32)
+                const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + idx);
+                const double2 c0 = *reinterpret_cast<const double2*>(rec);
+                const double c1x = *reinterpret_cast<const double*>(rec + 16);
+                const float2 fa = *reinterpret_cast<const float2*>(rec + 24);
+                const float4 fb = *reinterpret_cast<const float4*>(rec + 32);
+                const float2 fc = *reinterpret_cast<const float2*>(rec + 48);
+                const float e1f[3] = {fa.x, fa.y, fb.x}, e2f[3] = {fb.y, fb.z, fb.w};
+                const float tvx = (float)(o.x - c0.x), tvy = (float)(o.y - c0.y), tvz = (float)(o.z - c1x);
+                const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
+                const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                if (cull_fp32(tvx, tvy, tvz, dfx, dfy, dfz, dm, e1f, e2f, fc.x, fc.y)) {
+                    done2 = done1;       // a certain miss counts as tested
+                    done1 = idx;
+                    next_candidate();
+                } else {
+                    parked = true;
                 }
             }
+        }
+
+        stamp(3);
+        // ------------------------------------------------------------------ phase B2: exact FP64 test
+        {
+            const unsigned long long pm = __ballot(alive && parked);
+            const unsigned long long busy = __ballot(alive && !parked);   // lanes that can still walk or cull
+            if (pm != 0 && (__popcll(pm) >= EXACT_MIN_PARKED || busy == 0)) {
+                if (PROF) { pf[10]++; pf[11] += __popcll(pm); }
+                if (alive && parked) {
+                    const int i = idx;
+                    const PolyRec& p = g.polys[i];
+                    const double v0[3] = {p.v0[0], p.v0[1], p.v0[2]}, v1[3] = {p.v1[0], p.v1[1], p.v1[2]};
+                    const double v2[3] = {p.v2[0], p.v2[1], p.v2[2]}, nn[3] = {p.n[0], p.n[1], p.n[2]};
+                    double q3x = 0, q3y = 0, q3z = 0;
+                    int qnv = 3;
+                    if (QUADS) {
+                        if (g.quads) {
+                            const QuadRec& qr = g.quads[i];
+                            q3x = qr.v3[0]; q3y = qr.v3[1]; q3z = qr.v3[2];
+                            qnv = qr.nverts;
+                        }
+                    }
+                    // Ray_Side picks the corner order (Polygons.cs:641-648): (P0,P1,P2) or (P2,P1,P0)
+                    const bool side = ray_side(d, nn);
+                    double a[3], c[3];
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) { a[m] = side ? v0[m] : v2[m]; c[m] = side ? v2[m] : v0[m]; }
+                    double t = 0;
+                    bool ok = tri_fast(o, d, a, v1, c, t);
+                    if (QUADS) {
+                        const double v3[3] = {q3x, q3y, q3z};
+                        if (!ok && qnv == 4) ok = tri_fast(o, d, c, v3, a, t);     // (P2,P3,P0) / (P0,P3,P2)
+                    }
+                    if (ok && t > kTMin && t < tmin) {                      // :691-693
+                        tmin = t;
+                        pid = i;
+                    }
+                    done2 = done1;
+                    done1 = i;
+                    parked = false;
+                    next_candidate();
+                }
+            }
+        }
+        stamp(4);
+    }
+    if (PROF) {
+        if (lane == 0 && io.prof) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) atomicAdd(&io.prof[k], pf[k]);
+            atomicAdd(&io.prof[16], 1ull);
         }
     }
 
@@ -433,6 +540,45 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
         if (lane == 0) {
             atomicAdd(&io.ctr[CTR_RAYS], r);
             atomicAdd(&io.ctr[CTR_HITS], h);
+        }
+    }
+}
+
+// Filter audit (tests only): for every candidate the reference algorithm would test, run BOTH the FP32
+// cull and the exact test and count (culled && exact test accepts) -- must be zero.  ctr[5] += violations,
+// ctr[6] += culled candidates, ctr[7] += candidates.
+__device__ __forceinline__ void audit_body(const VoxelArgs& g, const ShootIO& io)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned int viol = 0, culled = 0, cands = 0;
+    if (i < io.n) {
+        const RayRec r = io.rays[i];
+        const V3 o = {r.x, r.y, r.z};
+        const V3 d = {r.dx, r.dy, r.dz};
+        const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
+        const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+        // brute force over every polygon of the topology (n_polys in io.pad): the audit is about the
+        // filter, not the traversal
+        const int P = io.audit_polys;
+        for (int k = 0; k < P; ++k) {
+            const PolyRec& p = g.polys[k];
+            const bool c = cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
+                                     p.e1f, p.e2f, p.ee, p.emax);
+            double t;
+            const bool hit = poly_fast(p, nullptr, o, d, t);
+            cands++;
+            if (c) {
+                culled++;
+                if (hit) viol++;
+            }
+        }
+    }
+    if (io.ctr) {
+        const unsigned long long v = wave_sum_u32(viol), c = wave_sum_u32(culled), n = wave_sum_u32(cands);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&io.ctr[5], v);
+            atomicAdd(&io.ctr[6], c);
+            atomicAdd(&io.ctr[7], n);
         }
     }
 }
@@ -530,7 +676,8 @@ __device__ __forceinline__ void trace_octree(const OctreeArgs& g, const OctFrame
                 if (COUNT) w.tests++;
                 const PolyRec& p = g.polys[i];
                 double t, u, v;
-                if (poly_full(p, p.nverts == 4, o, d, t, u, v) && t > kTMin) {   // :224
+                const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
+                if (poly_full(p, v3, o, d, t, u, v) && t > kTMin) {              // :224
                     if (t < closestT) {
                         closestT = t;
                         ev.t = t; ev.u = u; ev.v = v;
@@ -612,7 +759,8 @@ __device__ __forceinline__ void trace_kdtree(const KdArgs& g, int* stack, const 
                 if (COUNT) w.tests++;
                 const PolyRec& p = g.polys[i];
                 double t, u, v;
-                if (poly_full(p, p.nverts == 4, o, d, t, u, v) && t > kTMin) {   // :233
+                const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
+                if (poly_full(p, v3, o, d, t, u, v) && t > kTMin) {              // :233
                     if (t < closestT) {
                         closestT = t;
                         ev.t = t; ev.u = u; ev.v = v;
@@ -703,8 +851,17 @@ __global__ __launch_bounds__(256) void hare_voxel_shoot_count(VoxelArgs g, Shoot
 }
 
 // K1p: persistent Voxel_Grid.Shoot (default voxel kernel); dynamic LDS = occupancy bitmap when it fits
-__global__ __launch_bounds__(256) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
+// same with the occupancy bitmap left in global memory (grids whose bitmap exceeds 64 KB of LDS)
+__global__ __launch_bounds__(256) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false>(g, io); }
+
+// developer profiling build of the persistent kernel (phase stamps into ShootIO::prof)
+__global__ __launch_bounds__(256) void hare_voxel_persist_prof(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true, true>(g, io); }
+
+// tests only: FP32-cull audit against the exact test, all polygons x all rays
+__global__ __launch_bounds__(256) void hare_cull_audit(VoxelArgs g, ShootIO io) { audit_body(g, io); }
 
 // K2: Octree.Shoot ("Octree - alt.cs":159-284); dynamic LDS = levels * blockDim * 24 bytes
 __global__ void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }

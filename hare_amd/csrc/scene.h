@@ -49,9 +49,12 @@ struct DeviceModule {
     hipModule_t mod = nullptr;
     hipFunction_t voxel_tri = nullptr, voxel_quad = nullptr, voxel_count = nullptr;
     hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
+    hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr;
+    hipFunction_t cull_audit = nullptr;
+    hipFunction_t voxel_persist_prof = nullptr;
     int cu_count = 0;
 };
 
@@ -64,6 +67,7 @@ struct Scene {
 
     // device residents (all on `device`)
     std::vector<void*> d_polys;                  // per topo: PolyRec[P]
+    std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
     int32_t occ_words = 0;
     void* d_oct_nodes = nullptr;

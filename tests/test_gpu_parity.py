@@ -216,3 +216,41 @@ def test_bounce_loop_device_resident(hall):
             d_ex = d_ex[torch.from_numpy(keep).cuda()].contiguous()
             n = int(keep.sum())
             d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+
+
+def test_fp32_cull_never_rejects_a_hit():
+    """The persistent kernel's conservative FP32 pre-cull (cull_fp32, hare_math.h) may only drop
+    candidates RayXtri is certain to reject.  Audit kernel: every ray x every polygon, count
+    (culled AND the exact test accepts) -- must be zero -- on meshes of very different scale."""
+    import ctypes as C
+    from hare_amd import capi
+    rng = np.random.default_rng(5)
+    cases = []
+    m = H.scenes.shoebox()
+    cases.append((m.verts, m.nverts, H.scenes.random_rays(3000, m.size)))
+    hall = H.scenes.hall(edge=1.0)
+    cases.append((hall.verts, hall.nverts, H.scenes.burst_rays(2000, hall.size)))
+    for scale, shift in ((1e-3, 0.0), (1.0, 5000.0), (300.0, -1e5), (1e-6, 1e3)):
+        P = 600
+        c = rng.uniform(0, 10, (P, 1, 3))
+        tri = (c + rng.uniform(-1, 1, (P, 3, 3))) * scale + shift
+        tri[::7, 2] = tri[::7, 0] + (tri[::7, 1] - tri[::7, 0]) * 1.000001      # slivers
+        o = rng.uniform(0, 10, (3000, 3)) * scale + shift
+        tgt = tri[rng.integers(0, P, 3000)]
+        w = rng.dirichlet([0.3, 0.3, 0.3], 3000)                                  # many aim points on edges/corners
+        w[::5] = np.eye(3)[rng.integers(0, 3, 600)]                               # exactly at a vertex
+        aim = np.einsum("nk,nkc->nc", w, tgt)
+        d = aim - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        cases.append((tri, None, np.concatenate([o, d], 1)))
+    for verts, nverts, rays in cases:
+        g = H.Voxel_Grid([H.Topology(verts, nverts)], 2)
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), capi.XEVENT_DTYPE)
+        ctr = (C.c_uint64 * 8)()
+        capi.check(capi.lib.hare_shoot_batch(g._h, 0, 0, len(rays), rays.ctypes.data, None, None, 0x8000,
+                                             out.ctypes.data, C.addressof(ctr)))
+        viol, culled, cands = ctr[5], ctr[6], ctr[7]
+        assert cands == len(rays) * g.Model[0].Polygon_Count
+        assert viol == 0, f"FP32 cull rejected {viol} true hits"
+        assert culled > 0.5 * cands          # and it is actually doing something
