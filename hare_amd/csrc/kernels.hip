@@ -255,10 +255,12 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     const double fct = (double)ct;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int STEPS_PER_ROUND = io.steps_per_round;
-    const int REFILL_MIN_IDLE = io.refill_min_idle;
-    const int RAY_CHUNK = io.ray_chunk;
-    const int EXACT_MIN_PARKED = io.exact_min_parked;
+    // scheduling knobs: compile-time in the production kernels (fewer live SGPRs), run-time in the
+    // developer profiling build so that sweeps need no rebuild
+    const int STEPS_PER_ROUND = PROF ? io.steps_per_round : 3;
+    const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : 8;
+    const int RAY_CHUNK = PROF ? io.ray_chunk : 128;
+    const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : 8;
 
     // wave-uniform work chunk [cn, ce)
     long long cn = 0, ce = 0;
@@ -272,6 +274,9 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     V3 o = {0, 0, 0}, d = {0, 0, 0};
     double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0;
     int X = 0, Y = 0, Z = 0, cell = 0;
+    int dx1 = 1, dy1 = 1, dz1 = 1;   // stepX/Y/Z (Voxel_Grid.cs:589-632)
+    int dcx = 0, dcy = 0, dcz = 0;   // the same steps as cell-index strides
+    float dfx = 0, dfy = 0, dfz = 0, dm = 0;   // (float)d and |d|_1 for the cull
     int e1 = -1, e2 = -1;
     unsigned int q = 0, qe = 0;      // q: position of the CURRENT candidate `idx` in items
     int idx = -1, nexti = -1;        // current / following candidate polygon
@@ -327,7 +332,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
         if (PROF) pf[5]++;
         // ------------------------------------------------------------------ refill idle lanes
         const unsigned long long idle = __ballot(!alive);
-        if (!drained && (__popcll(idle) >= REFILL_MIN_IDLE || idle == ~0ull)) {
+        if (__builtin_expect(!drained && (__popcll(idle) >= REFILL_MIN_IDLE || idle == ~0ull), 0)) {
             bool want = !alive;
             if (PROF) { pf[12]++; pf[13] += __popcll(idle); }
             while (true) {
@@ -390,6 +395,10 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                         if (alive) {
                             X = (int)fx; Y = (int)fy; Z = (int)fz;
                             cell = (X * ct + Y) * ct + Z;
+                            dx1 = d.x < 0 ? -1 : 1; dy1 = d.y < 0 ? -1 : 1; dz1 = d.z < 0 ? -1 : 1;
+                            dcx = dx1 * ct * ct; dcy = dy1 * ct; dcz = dz1;
+                            dfx = (float)d.x; dfy = (float)d.y; dfz = (float)d.z;
+                            dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
                             if (d.x < 0) { tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
                             else         { tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
                             if (d.y < 0) { tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
@@ -437,7 +446,6 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     const bool sx = cxy & cxz;
                     const bool sy = (!cxy) & cyz;
                     const bool sz = !(sx | sy);
-                    const int dx1 = d.x < 0 ? -1 : 1, dy1 = d.y < 0 ? -1 : 1, dz1 = d.z < 0 ? -1 : 1;
                     const double nX = tMaxX + tDeltaX, nY = tMaxY + tDeltaY, nZ = tMaxZ + tDeltaZ;
                     X += sx ? dx1 : 0;
                     Y += sy ? dy1 : 0;
@@ -445,7 +453,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     tMaxX = sx ? nX : tMaxX;
                     tMaxY = sy ? nY : tMaxY;
                     tMaxZ = sz ? nZ : tMaxZ;
-                    cell += sx ? dx1 * ct * ct : (sy ? dy1 * ct : dz1);
+                    cell += sx ? dcx : (sy ? dcy : dcz);
                     const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
                     if (out) finish(false);     // leaving the grid: miss, even with a pending hit (F12)
                     else enter_cell();
@@ -462,15 +470,13 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             } else {
                 // first 56 bytes of the record: v0 (FP64) + e1f e2f ee emax (FP32)
                 const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + idx);
-                const double2 c0 = *reinterpret_cast<const double2*>(rec);
-                const double c1x = *reinterpret_cast<const double*>(rec + 16);
-                const float2 fa = *reinterpret_cast<const float2*>(rec + 24);
-                const float4 fb = *reinterpret_cast<const float4*>(rec + 32);
-                const float2 fc = *reinterpret_cast<const float2*>(rec + 48);
-                const float e1f[3] = {fa.x, fa.y, fb.x}, e2f[3] = {fb.y, fb.z, fb.w};
+                const double2 c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
+                const uint4 r1 = *reinterpret_cast<const uint4*>(rec + 16);          // v0.z | e1f.x e1f.y
+                const float4 fb = *reinterpret_cast<const float4*>(rec + 32);        // e1f.z e2f.x e2f.y e2f.z
+                const float2 fc = *reinterpret_cast<const float2*>(rec + 48);        // ee emax
+                const double c1x = __hiloint2double((int)r1.y, (int)r1.x);
+                const float e1f[3] = {__uint_as_float(r1.z), __uint_as_float(r1.w), fb.x}, e2f[3] = {fb.y, fb.z, fb.w};
                 const float tvx = (float)(o.x - c0.x), tvy = (float)(o.y - c0.y), tvz = (float)(o.z - c1x);
-                const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
-                const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
                 if (cull_fp32(tvx, tvy, tvz, dfx, dfy, dfz, dm, e1f, e2f, fc.x, fc.y)) {
                     done2 = done1;       // a certain miss counts as tested
                     done1 = idx;
