@@ -1,0 +1,194 @@
+// Gpu_Spatial_Partition.cs -- drop-in Spatial_Partition subclasses that run Shoot on an MI355X through
+// libhare_hip.so.  Same constructor signatures as the reference classes:
+//   Voxel_Grid(Topology[] Model_in, int Domain)                        Voxel_Grid.cs:48
+//   Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys)      Voxel_Grid.cs:128
+//   Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode)  "Octree - alt.cs":45
+//   KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode)  KDTree.cs:51
+// plus one new member, the batch Shoot, which is where the throughput is.  The single-ray overrides
+// are the batch path with n = 1 (correct, but one kernel launch per ray).
+//
+// The scene is read through public members only: Polygon_Count, this[poly, corner], Polys[p].VertextCT,
+// Normal(p), Min, Max -- i.e. AFTER the Topology rounded/merged vertices (Hare_Geometry_Topology.cs:342-377)
+// and AFTER Finish_Topology() set Min/Max (:148-167).  Call Finish_Topology() before constructing.
+//
+// NOT COMPILED IN THE BUILD CONTAINER (no .NET toolchain): see INTEGRATION.md.
+using System;
+using System.Runtime.InteropServices;
+
+namespace Hare
+{
+    namespace Geometry
+    {
+        public abstract class Gpu_Spatial_Partition : Spatial_Partition, IDisposable
+        {
+            protected IntPtr scene = IntPtr.Zero;
+            protected abstract int Kind { get; }
+
+            protected Gpu_Spatial_Partition(Topology[] Model_in, int device)
+            {
+                Model = Model_in;
+                var descs = new hare_topology_desc[Model.Length];
+                var pins = new GCHandle[Model.Length * 3];
+                try
+                {
+                    for (int m = 0; m < Model.Length; m++)
+                    {
+                        Topology T = Model[m];
+                        int P = T.Polygon_Count;
+                        double[] verts = new double[P * 12];
+                        int[] nverts = new int[P];
+                        double[] normals = new double[P * 3];
+                        for (int p = 0; p < P; p++)
+                        {
+                            int nv = T.Polys[p].VertextCT;
+                            nverts[p] = nv;
+                            for (int c = 0; c < nv && c < 4; c++)
+                            {
+                                Point pt = T[p, c];
+                                verts[p * 12 + 3 * c + 0] = pt.x;
+                                verts[p * 12 + 3 * c + 1] = pt.y;
+                                verts[p * 12 + 3 * c + 2] = pt.z;
+                            }
+                            Vector N = T.Normal(p);
+                            normals[p * 3 + 0] = N.dx;
+                            normals[p * 3 + 1] = N.dy;
+                            normals[p * 3 + 2] = N.dz;
+                        }
+                        pins[3 * m + 0] = GCHandle.Alloc(verts, GCHandleType.Pinned);
+                        pins[3 * m + 1] = GCHandle.Alloc(nverts, GCHandleType.Pinned);
+                        pins[3 * m + 2] = GCHandle.Alloc(normals, GCHandleType.Pinned);
+                        descs[m].P = P;
+                        descs[m].verts = pins[3 * m + 0].AddrOfPinnedObject();
+                        descs[m].nverts = pins[3 * m + 1].AddrOfPinnedObject();
+                        descs[m].normals = pins[3 * m + 2].AddrOfPinnedObject();
+                        descs[m].min0 = T.Min.x; descs[m].min1 = T.Min.y; descs[m].min2 = T.Min.z;
+                        descs[m].max0 = T.Max.x; descs[m].max1 = T.Max.y; descs[m].max2 = T.Max.z;
+                    }
+                    HareHip.Check(HareHip.hare_scene_create(descs, descs.Length, device, out scene));   // copies everything
+                }
+                finally
+                {
+                    foreach (GCHandle h in pins) if (h.IsAllocated) h.Free();
+                }
+            }
+
+            /// <summary>
+            /// Shoot for a whole batch: results[i] is what Shoot(rays[i], top_index, out ..., poly_origin1[i], poly_origin2[i])
+            /// returns.  Rays that start outside the grid are moved to the bounding-box entry, like the reference moves R
+            /// (AABB_Main.cs:254-257).  Returns the number of hits.
+            /// </summary>
+            public int Shoot(Ray[] rays, int top_index, X_Event[] results, int[] poly_origin1 = null, int[] poly_origin2 = null)
+            {
+                int n = rays.Length;
+                if (results.Length < n) throw new ArgumentException("results is shorter than rays");
+                var r = new hare_ray[n];
+                for (int i = 0; i < n; i++)
+                {
+                    r[i].x = rays[i].x; r[i].y = rays[i].y; r[i].z = rays[i].z;
+                    r[i].dx = rays[i].dx; r[i].dy = rays[i].dy; r[i].dz = rays[i].dz;
+                }
+                var ev = new hare_xevent[n];
+                hare_counters ctr;
+                HareHip.Check(HareHip.hare_shoot_batch(scene, Kind, top_index, n, r, poly_origin1, poly_origin2,
+                                                       HareHip.HARE_SHOOT_WRITEBACK_ORIGIN, ev, out ctr));
+                for (int i = 0; i < n; i++)
+                {
+                    rays[i].x = r[i].x; rays[i].y = r[i].y; rays[i].z = r[i].z;       // F11: the reference mutates R
+                    results[i] = ev[i].hit != 0
+                        ? new X_Event(new Point(ev[i].x, ev[i].y, ev[i].z), ev[i].u, ev[i].v, ev[i].t, ev[i].poly_id)
+                        : new X_Event();
+                }
+                return (int)ctr.hits;
+            }
+
+            /// <summary>Zero-copy flavour for callers that keep rays/events in flat arrays (no per-ray objects).</summary>
+            public int Shoot(hare_ray[] rays, int top_index, hare_xevent[] results, int[] poly_origin1 = null, int[] poly_origin2 = null, bool moveOrigins = false)
+            {
+                hare_counters ctr;
+                HareHip.Check(HareHip.hare_shoot_batch(scene, Kind, top_index, rays.Length, rays, poly_origin1, poly_origin2,
+                                                       moveOrigins ? HareHip.HARE_SHOOT_WRITEBACK_ORIGIN : 0u, results, out ctr));
+                return (int)ctr.hits;
+            }
+
+            public override bool Shoot(Ray R, int top_index, out X_Event Ret_event)
+            {
+                return Shoot(R, top_index, out Ret_event, -1, -1);
+            }
+
+            public override bool Shoot(Ray R, int top_index, out X_Event Ret_event, int poly_origin1, int poly_origin2 = -1)
+            {
+                var one = new X_Event[1];
+                Shoot(new Ray[] { R }, top_index, one, new int[] { poly_origin1 }, new int[] { poly_origin2 });
+                Ret_event = one[0];
+                return Ret_event.Hit;
+            }
+
+            public void Dispose()
+            {
+                if (scene != IntPtr.Zero) { HareHip.hare_scene_destroy(scene); scene = IntPtr.Zero; }
+                GC.SuppressFinalize(this);
+            }
+
+            ~Gpu_Spatial_Partition() { if (scene != IntPtr.Zero) HareHip.hare_scene_destroy(scene); }
+        }
+
+        /// <summary>Voxel_Grid on the GPU (Voxel_Grid.cs).</summary>
+        public class Gpu_Voxel_Grid : Gpu_Spatial_Partition
+        {
+            protected override int Kind { get { return HareHip.HARE_KIND_VOXEL; } }
+            hare_voxel_info info;
+
+            public Gpu_Voxel_Grid(Topology[] Model_in, int Domain, int device = 0) : base(Model_in, device)
+            {
+                HareHip.Check(HareHip.hare_voxel_build(scene, Domain));
+                Refresh();
+            }
+
+            public Gpu_Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys, int device) : base(Model_in, device)
+            {
+                HareHip.Check(HareHip.hare_voxel_build_adaptive(scene, MaxDomain, Avg_polys));
+                Refresh();
+            }
+
+            void Refresh()
+            {
+                HareHip.Check(HareHip.hare_voxel_get_info(scene, out info));
+                Char_Step = info.char_step;                                   // Voxel_Grid.cs:90
+            }
+
+            public double Xdim { get { return info.box_dims0; } }            // Voxel_Grid.cs:763-783
+            public double Ydim { get { return info.box_dims1; } }
+            public double Zdim { get { return info.box_dims2; } }
+            public Point MinPt { get { return new Point(info.obox_min0, info.obox_min1, info.obox_min2); } }   // :785-791
+
+            public void PointInVoxel(Point Pt, out int X, out int Y, out int Z)   // Voxel_Grid.cs:322-327
+            {
+                X = (int)Math.Floor((Pt.x - info.obox_min0) / info.voxel_dims0);
+                Y = (int)Math.Floor((Pt.y - info.obox_min1) / info.voxel_dims1);
+                Z = (int)Math.Floor((Pt.z - info.obox_min2) / info.voxel_dims2);
+            }
+
+            public int VoxelCode(int X, int Y, int Z) { return info.ct * info.ct * Z + info.ct * X + Y; }     // :264-267
+        }
+
+        /// <summary>Octree on the GPU ("Octree - alt.cs").</summary>
+        public class Gpu_Octree : Gpu_Spatial_Partition
+        {
+            protected override int Kind { get { return HareHip.HARE_KIND_OCTREE; } }
+            public Gpu_Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode, int device = 0) : base(Model_In, device)
+            {
+                HareHip.Check(HareHip.hare_octree_build(scene, maxDepth, maxPolygonsPerNode));
+            }
+        }
+
+        /// <summary>KDTree on the GPU (KDTree.cs).</summary>
+        public class Gpu_KDTree : Gpu_Spatial_Partition
+        {
+            protected override int Kind { get { return HareHip.HARE_KIND_KDTREE; } }
+            public Gpu_KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode, int device = 0) : base(Model_In, device)
+            {
+                HareHip.Check(HareHip.hare_kdtree_build(scene, maxDepth, maxPolygonsPerNode));
+            }
+        }
+    }
+}

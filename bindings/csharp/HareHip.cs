@@ -1,0 +1,90 @@
+// HareHip.cs -- P/Invoke surface of libhare_hip.so (include/hare_hip.h), for the drop-in
+// Spatial_Partition subclasses in this folder.  Compile these files INTO Hare.csproj (net7.0;net48,
+// AllowUnsafeBlocks not required) next to the reference sources; libhare_hip.so goes beside the
+// assembly or on LD_LIBRARY_PATH.
+//
+// NOT COMPILED IN THE BUILD CONTAINER: no .NET toolchain exists there (DESIGN.md).  The native side
+// pins the layouts with static_asserts (api.cpp) and tests/test_abi_exports.py checks every symbol.
+using System;
+using System.Runtime.InteropServices;
+
+namespace Hare
+{
+    namespace Geometry
+    {
+        /// <summary>Hare.Geometry.Ray as the native library reads it (Hare_Geometry_Primitives.cs:393-429).</summary>
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_ray
+        {
+            public double x, y, z, dx, dy, dz;
+        }
+
+        /// <summary>Hare.Geometry.X_Event as the native library writes it (Hare_Geometry_Primitives.cs:435-481). 56 bytes.</summary>
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_xevent
+        {
+            public double t, u, v, x, y, z;
+            public int poly_id;
+            public int hit;
+        }
+
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_counters
+        {
+            public ulong rays, hits, cells, entries, tests, r0, r1, r2;
+        }
+
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_topology_desc
+        {
+            public int P;
+            public int reserved;
+            public IntPtr verts;    // P x 4 x 3 doubles
+            public IntPtr nverts;   // P ints
+            public IntPtr normals;  // P x 3 doubles
+            public double min0, min1, min2;
+            public double max0, max1, max2;
+        }
+
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_voxel_info
+        {
+            public int ct, n_topos;
+            public double obox_min0, obox_min1, obox_min2;
+            public double obox_max0, obox_max1, obox_max2;
+            public double box_dims0, box_dims1, box_dims2;
+            public double voxel_dims0, voxel_dims1, voxel_dims2;
+            public double char_step;
+            public ulong total_items;
+        }
+
+        internal static class HareHip
+        {
+            const string Lib = "hare_hip";   // libhare_hip.so
+
+            public const int HARE_KIND_VOXEL = 0, HARE_KIND_OCTREE = 1, HARE_KIND_KDTREE = 2;
+            public const uint HARE_SHOOT_WRITEBACK_ORIGIN = 1;
+
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr hare_last_error();
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_device_count(out int count);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_scene_create([In] hare_topology_desc[] topos, int n_topos, int device, out IntPtr scene);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern void hare_scene_destroy(IntPtr scene);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_voxel_build(IntPtr scene, int domain);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_voxel_build_adaptive(IntPtr scene, int max_domain, int avg_polys);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_octree_build(IntPtr scene, int max_depth, int max_polys);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_kdtree_build(IntPtr scene, int max_depth, int max_polys);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_voxel_get_info(IntPtr scene, out hare_voxel_info info);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_shoot_batch(IntPtr scene, int kind, int top_index, long n, [In, Out] hare_ray[] rays,
+                                                      int[] excl1, int[] excl2, uint flags, [Out] hare_xevent[] ev, out hare_counters ctr);
+
+            public static void Check(int rc)
+            {
+                if (rc == 0) return;
+                string msg = Marshal.PtrToStringAnsi(hare_last_error()) ?? "";
+                if (rc == -6) throw new NotImplementedException(msg);          // as Topology does for > 4 corners
+                throw new InvalidOperationException("hare_hip error " + rc + ": " + msg);
+            }
+        }
+    }
+}
