@@ -59,6 +59,8 @@ def main() -> None:
     ap.add_argument("--domain", type=int, default=64, help="Voxel_Grid Domain")
     ap.add_argument("--scene", default="hall", choices=["hall", "cathedral", "shoebox"])
     ap.add_argument("--kind", default="voxel", choices=["voxel", "octree", "kdtree"])
+    ap.add_argument("--bounces", type=int, default=1,
+                    help="casts per step: >1 = device-resident specular bounce loop (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,10 +104,22 @@ def main() -> None:
     d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream()
 
+    d_rays0 = d_rays.clone() if args.bounces > 1 else None
+    d_excl = torch.full((n,), -1, dtype=torch.int32, device="cuda") if args.bounces > 1 else None
+
     def step():
         d_ctr.zero_()
-        part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(),
-                          stream=stream.cuda_stream)
+        if args.bounces > 1:     # config 5: shoot -> reflect -> shoot with poly_origin1 = the polygon just hit
+            d_rays.copy_(d_rays0)
+            d_excl.fill_(-1)
+            for b in range(args.bounces):
+                part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl1=d_excl.data_ptr(),
+                                  d_counters=d_ctr.data_ptr(), stream=stream.cuda_stream)
+                if b + 1 < args.bounces:
+                    part.reflect_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl.data_ptr(), stream=stream.cuda_stream)
+        else:
+            part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(),
+                              stream=stream.cuda_stream)
         if dist is not None:
             dist.all_reduce(d_ctr)   # RCCL: the final hit-count reduce (64 B, latency-bound)
 
@@ -160,7 +174,7 @@ def main() -> None:
     roofline = None
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and args.kind == "voxel":
+    if not args.no_cpu_baseline and args.kind == "voxel" and args.bounces == 1:
         from oracle import pyoracle as po
         cores = int(os.environ.get("HARE_CPU_THREADS", "0")) or min(len(os.sched_getaffinity(0)), 32)
         ot = po.Topology(mesh.verts, mesh.nverts)
@@ -201,13 +215,14 @@ def main() -> None:
         parity = bool(all(np.array_equal(got[f], ref[f]) for f in ("hit", "poly_id", "t", "x", "y", "z")))
 
     ms_per_step = wall * 1e3 / args.steps
-    value = n_total * args.steps / wall / 1e6
+    value = n_total * args.bounces * args.steps / wall / 1e6   # casts per second
     line = {
         "metric": "Mrays/s (primary hits) into 100k-tri mesh", "value": round(value, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"C2: {n} spherical-Fibonacci burst rays per GPU -> {mesh.name} "
-                               f"({mesh.P} triangles), {kdesc}, closest hit (X_Event)",
+        "config": {"workload": f"{n} spherical-Fibonacci burst rays per GPU -> {mesh.name} "
+                               f"({mesh.P} triangles), {kdesc}, closest hit (X_Event)"
+                               + (f", x{args.bounces} specular bounces device-resident (value = casts/s)" if args.bounces > 1 else ""),
                    "rays_per_gpu": n, "triangles": mesh.P, "partition": kdesc, "sharding": f"rays x{world}, scene replicated"},
         "device_ms_per_step": round(dev_ms / args.steps, 4), "kernel_only_mrays_s": round(n / kern_ms / 1e3, 2),
         "hits": hits_total, "rays": rays_total, "build_s": round(build_s, 3),

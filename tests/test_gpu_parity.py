@@ -254,3 +254,63 @@ def test_fp32_cull_never_rejects_a_hit():
         assert cands == len(rays) * g.Model[0].Polygon_Count
         assert viol == 0, f"FP32 cull rejected {viol} true hits"
         assert culled > 0.5 * cands          # and it is actually doing something
+
+
+@pytest.fixture(scope="module")
+def cathedral():
+    m = H.scenes.cathedral()
+    return m, H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+
+
+def test_voxel_c4_shard_2M_rays_1M_tris(cathedral):
+    """BASELINE config[3] as ONE rank sees it: its 2M-ray shard of the 16M-ray burst into the ~1M-tri
+    cathedral, Voxel_Grid D=128 (the bitmap no longer fits LDS: global-bitmap kernel variant)."""
+    m, T, To = cathedral
+    assert 980_000 <= m.P <= 1_020_000
+    from hare_amd.sharding import shard_range
+    lo, hi = shard_range(16 << 20, 3, 8)                      # rank 3 of 8
+    rays = H.scenes.burst_rays(16 << 20, m.size, start=lo, count=hi - lo)
+    g = H.Voxel_Grid([T], 128)
+    o = po.VoxelGrid([To], domain=128)
+    s, i = g.Voxel_Inv()
+    so, io = o.lists()
+    assert np.array_equal(s, so) and np.array_equal(i, io)
+    ev, ctr = g.Shoot_batch(rays)
+    ref, rc = o.shoot(rays, nthreads=16)
+    assert_events_equal(ev, ref, what="C4 shard")
+    assert ctr["hits"] == rc["hits"] == hi - lo
+
+
+def test_bounce_c5_shard_8_bounces_1M_tris(cathedral):
+    """BASELINE config[4] at a reduced ray count: 200k rays x 8 specular bounces in the 1M-tri cathedral,
+    device-resident (shoot -> reflect -> shoot with poly_origin1 = last hit); every bounce == oracle."""
+    import torch
+    m, T, To = cathedral
+    n, bounces = 200_000, 8
+    rays = H.scenes.burst_rays(8 << 20, m.size, start=5_000_000, count=n)
+    g = H.Voxel_Grid([T], 128)
+    o = po.VoxelGrid([To], domain=128)
+    d_rays = torch.from_numpy(rays.copy()).cuda()
+    d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    d_ex = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cur, excl = rays.copy(), np.full(n, -1, np.int32)
+    dead = np.zeros(n, bool)
+    for b in range(bounces):
+        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st)
+        g.reflect_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_ex.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)
+        ref, _ = o.shoot(cur, excl1=excl, nthreads=16)
+        ref = ref.copy()
+        ref[dead] = np.zeros(1, ref.dtype)                      # retired rays: the kernel reports X_Event()
+        ref["poly_id"][dead] = -1
+        assert_events_equal(ev, ref, what=f"C5 bounce {b}")
+        alive = (ref["hit"] == 1) & ~dead
+        nxt = po.reflect(To, cur, ref)
+        cur = np.where(alive[:, None], nxt, cur)
+        excl = np.where(alive, ref["poly_id"], -1).astype(np.int32)
+        dead |= ~alive
+        got = d_rays.cpu().numpy()
+        assert np.array_equal(got[alive], cur[alive])
+    assert dead.mean() < 0.01
