@@ -56,6 +56,7 @@ namespace Hare
             public double voxel_dims0, voxel_dims1, voxel_dims2;
             public double char_step;
             public ulong total_items;
+            public int built_on_device, reserved;
         }
 
         internal static class HareHip

@@ -48,7 +48,7 @@ class TopologyDesc(C.Structure):
 class VoxelInfo(C.Structure):
     _fields_ = [("ct", C.c_int32), ("n_topos", C.c_int32), ("obox_min", C.c_double * 3), ("obox_max", C.c_double * 3),
                 ("box_dims", C.c_double * 3), ("voxel_dims", C.c_double * 3), ("char_step", C.c_double),
-                ("total_items", C.c_uint64)]
+                ("total_items", C.c_uint64), ("built_on_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class TreeInfo(C.Structure):

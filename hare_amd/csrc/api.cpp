@@ -32,14 +32,19 @@ static thread_local std::string t_err;
 void set_error(const std::string& msg) { t_err = msg; }
 const char* last_error() { return t_err.c_str(); }
 
-namespace {
-
 const HipApi* api_or_err()
 {
     std::string e;
     const HipApi* h = hip_api(&e);
     if (!h) set_error(e);
     return h;
+}
+
+int hip_fail(const HipApi* H, hipError_t e, const char* what)
+{
+    set_error(std::string(what) + " failed: " + (H->GetErrorString ? H->GetErrorString(e) : "?"));
+    (void)H->GetLastError();
+    return (e == hipErrorOutOfMemory) ? HARE_E_NOMEM : HARE_E_HIP;
 }
 
 #define HIP_TRY(expr)                                                                          \
@@ -81,6 +86,17 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_reflect", &m->reflect},
         {"hare_cull_audit", &m->cull_audit},
         {"hare_voxel_persist_prof", &m->voxel_persist_prof},
+        {"hare_vb_count", &m->vb_count},
+        {"hare_vb_fill", &m->vb_fill},
+        {"hare_vb_level_count", &m->vb_level_count},
+        {"hare_vb_level_fill", &m->vb_level_fill},
+        {"hare_scan_block", &m->scan_block},
+        {"hare_scan_add", &m->scan_add},
+        {"hare_vb_sort_small", &m->vb_sort_small},
+        {"hare_vb_sort_block", &m->vb_sort_block},
+        {"hare_vb_finalize", &m->vb_finalize},
+        {"hare_vb_find_big", &m->vb_find_big},
+        {"hare_vb_fill_big", &m->vb_fill_big},
     };
     for (auto& t : table) {
         hipError_t e = H->ModuleGetFunction(t.fn, m->mod, t.name);
@@ -400,7 +416,6 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     return HARE_E_INVALID;
 }
 
-}  // namespace
 }  // namespace hare
 
 using namespace hare;
@@ -556,6 +571,25 @@ static int sync_partition_to_device(hare_scene* s, int kind)
     return upload(H, &s->d_kd_items, s->kd.items.data(), s->kd.items.size() * sizeof(int32_t));
 }
 
+// Build the grid on the GPU when a device is present (HARE_BUILD=host forces the host builder; both
+// produce identical lists).  *on_gpu = false: the caller runs the host builder.
+static int try_gpu_voxel_build(hare_scene* s, int32_t domain, int32_t max_domain, int32_t avg_polys, bool* on_gpu)
+{
+    *on_gpu = false;
+    const char* mode = getenv("HARE_BUILD");
+    if (mode && strcmp(mode, "host") == 0) return HARE_OK;
+    std::string e;
+    const HipApi* H = hip_api(&e);
+    int n = 0;
+    if (!H || H->GetDeviceCount(&n) != hipSuccess || n <= 0) return HARE_OK;
+    int rc = ensure_device(*s, H);
+    if (rc) return rc;
+    rc = upload_polys(*s, H);
+    if (rc) return rc;
+    if (domain > 0) return gpu_build_voxel_fixed(*s, H, domain, on_gpu);
+    return gpu_build_voxel_adaptive(*s, H, max_domain, avg_polys, on_gpu);
+}
+
 int hare_voxel_build(hare_scene* s, int32_t domain)
 {
     if (!s) {
@@ -563,7 +597,15 @@ int hare_voxel_build(hare_scene* s, int32_t domain)
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
-    int rc = build_voxel_fixed(*s, domain);
+    if (domain < 1 || domain > 1024) {
+        set_error("hare_voxel_build: domain must be in [1, 1024]");
+        return HARE_E_INVALID;
+    }
+    bool on_gpu = false;
+    int rc = try_gpu_voxel_build(s, domain, 0, 0, &on_gpu);
+    if (rc) return rc;
+    if (on_gpu) return HARE_OK;
+    rc = build_voxel_fixed(*s, domain);
     if (rc) return rc;
     return sync_partition_to_device(s, HARE_KIND_VOXEL);
     GUARD_END
@@ -576,7 +618,15 @@ int hare_voxel_build_adaptive(hare_scene* s, int32_t max_domain, int32_t avg_pol
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
-    int rc = build_voxel_adaptive(*s, max_domain, avg_polys);
+    if (max_domain < 1 || max_domain > 10) {
+        set_error("hare_voxel_build_adaptive: max_domain must be in [1, 10]");
+        return HARE_E_INVALID;
+    }
+    bool on_gpu = false;
+    int rc = try_gpu_voxel_build(s, 0, max_domain, avg_polys, &on_gpu);
+    if (rc) return rc;
+    if (on_gpu) return HARE_OK;
+    rc = build_voxel_adaptive(*s, max_domain, avg_polys);
     if (rc) return rc;
     return sync_partition_to_device(s, HARE_KIND_VOXEL);
     GUARD_END
@@ -629,6 +679,7 @@ int hare_voxel_get_info(const hare_scene* s, hare_voxel_info* out)
     }
     out->char_step = s->vox.char_step;
     out->total_items = s->vox.items[0].size();
+    out->built_on_device = s->vox.on_device ? 1 : 0;
     return HARE_OK;
 }
 

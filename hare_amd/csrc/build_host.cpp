@@ -88,6 +88,14 @@ void parallel_for(int64_t n, int nthreads, const std::function<void(int, int64_t
 // ctor prologue: Voxel_Grid.cs:52-90
 void grid_bounds(const Scene& s, VoxelHost& g)
 {
+    voxel_grid_bounds(s, g);
+}
+void grid_set_ct(VoxelHost& g, int32_t ct) { voxel_grid_set_ct(g, ct); }
+
+}  // namespace
+
+void voxel_grid_bounds(const Scene& s, VoxelHost& g)
+{
     double MaxPT[3] = {-INFINITY, -INFINITY, -INFINITY}, MinPT[3] = {INFINITY, INFINITY, INFINITY};
     for (const Topo& t : s.topos)
         for (int a = 0; a < 3; ++a) {
@@ -101,13 +109,15 @@ void grid_bounds(const Scene& s, VoxelHost& g)
     }
 }
 
-void grid_set_ct(VoxelHost& g, int32_t ct)
+void voxel_grid_set_ct(VoxelHost& g, int32_t ct)
 {
     g.ct = ct;
     for (int a = 0; a < 3; ++a) g.vd[a] = g.box_dims[a] / ct;
     const double* v = g.vd;
     g.char_step = (v[0] < v[1]) ? ((v[0] < v[2]) ? v[0] : v[2]) : (v[1] < v[2] ? v[1] : v[2]);  // :90
 }
+
+namespace {
 
 inline void cell_box(const VoxelHost& g, int x, int y, int z, double bmin[3], double bmax[3])
 {

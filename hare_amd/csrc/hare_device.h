@@ -85,6 +85,15 @@ struct KdArgs {
     int32_t max_depth;
 };
 
+struct BuildArgs {             // Voxel_Grid construction kernels (build_kernels.hip)
+    const PolyRec* polys;
+    const QuadRec* quads;      // null when the topology is all triangles
+    int32_t P;
+    int32_t ct;
+    double omin[3];            // OBox.Min
+    double vd[3];              // VoxelDims
+};
+
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN
     const int32_t* excl1;      // nullable: poly_origin1 per ray

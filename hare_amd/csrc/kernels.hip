@@ -630,6 +630,9 @@ __device__ __forceinline__ void trace_octree(const OctreeArgs& g, const OctFrame
     };
 
     set_miss(ev);
+    const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
+    const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the four polygons this ray tested last
     double rmin, rmax;
     slab(g.nodes[0], rmin, rmax);
     if (rmax < rmin || rmax < 0) return;                          // :185
@@ -681,6 +684,17 @@ __device__ __forceinline__ void trace_octree(const OctreeArgs& g, const OctFrame
                 if (i == e1 || i == e2) continue;                 // :218
                 if (COUNT) w.tests++;
                 const PolyRec& p = g.polys[i];
+                if (!COUNT) {
+                    // Not in the reference (its mailbox is commented out, :221-222): loose leaves overlap, so a
+                    // ray meets the same polygon in several leaves.  Skipping one it has just tested, and
+                    // candidates the conservative FP32 cull proves to be misses, cannot change any accepted
+                    // hit (strict `t < closestT`), only saves the FP64 test.
+                    if (i == m0 || i == m1 || i == m2 || i == m3) continue;
+                    m3 = m2; m2 = m1; m1 = m0; m0 = i;
+                    if (cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
+                                  p.e1f, p.e2f, p.ee, p.emax))
+                        continue;
+                }
                 double t, u, v;
                 const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
                 if (poly_full(p, v3, o, d, t, u, v) && t > kTMin) {              // :224
@@ -903,3 +917,5 @@ __global__ __launch_bounds__(256) void hare_reflect(const PolyRec* polys, RayRec
 }
 
 }  // extern "C"
+
+#include "build_kernels.hip"

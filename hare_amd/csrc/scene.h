@@ -23,6 +23,7 @@ struct Topo {
 
 struct VoxelHost {
     bool built = false;
+    bool on_device = false;   // lists were produced by the GPU builder
     int32_t ct = 0;
     double omin[3], omax[3], box_dims[3], vd[3];
     double char_step = 0;
@@ -55,6 +56,9 @@ struct DeviceModule {
     hipFunction_t reflect = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
+    hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
+    hipFunction_t scan_block = nullptr, scan_add = nullptr, vb_sort_small = nullptr, vb_sort_block = nullptr, vb_finalize = nullptr;
+    hipFunction_t vb_find_big = nullptr, vb_fill_big = nullptr;
     int cu_count = 0;
 };
 
@@ -93,6 +97,23 @@ struct Scene {
 // error plumbing (thread-local message)
 void set_error(const std::string& msg);
 const char* last_error();
+
+// device plumbing shared by api.cpp and build_gpu.cpp
+const HipApi* api_or_err();
+int ensure_device(Scene& s, const HipApi*& H);
+int upload(const HipApi* H, void** dst, const void* src, size_t bytes);
+int upload_polys(Scene& s, const HipApi* H);
+int upload_voxel(Scene& s, const HipApi* H);
+int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, void** args);
+int hip_fail(const HipApi* H, hipError_t e, const char* what);
+
+// grid geometry shared by the host and GPU builders (Voxel_Grid.cs:52-90)
+void voxel_grid_bounds(const Scene& s, VoxelHost& g);
+void voxel_grid_set_ct(VoxelHost& g, int32_t ct);
+
+// GPU builders (build_gpu.cpp); *used = false means "not applicable, use the host builder"
+int gpu_build_voxel_fixed(Scene& s, const HipApi* H, int32_t domain, bool* used);
+int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int32_t avg_polys, bool* used);
 
 // builders (host); return HARE_* codes
 int build_voxel_fixed(Scene& s, int32_t domain);

@@ -117,6 +117,8 @@ HARE_API int hare_scene_create(const hare_topology_desc *topos, int32_t n_topos,
 HARE_API void hare_scene_destroy(hare_scene *s);
 
 /* ---- partition constructors ----
+ * The voxel grid is built on the GPU when one is present (environment HARE_BUILD=host forces the host
+ * builder); both builders produce identical lists.  Octree / KDTree are built on the host.
  * Voxel_Grid(Topology[] Model_in, int Domain)                      Voxel_Grid.cs:48-121  */
 HARE_API int hare_voxel_build(hare_scene *s, int32_t domain);
 /* Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys)    Voxel_Grid.cs:128-254 */
@@ -136,6 +138,8 @@ typedef struct hare_voxel_info {
     double voxel_dims[3];
     double char_step;        /* Spatial_Partition.Char_Step (Spatial_Partition.cs:31)    */
     uint64_t total_items;    /* sum of Voxel_Inv[x,y,z,m].Count over the grid, topology 0 */
+    int32_t built_on_device; /* 1: lists came from the GPU builder, 0: from the host builder  */
+    int32_t reserved;
 } hare_voxel_info;
 HARE_API int hare_voxel_get_info(const hare_scene *s, hare_voxel_info *out);
 /* Voxel_Inv[x,y,z,top] (Voxel_Grid.cs:33) as CSR: cell = (x*ct + y)*ct + z; cell_start has

@@ -314,3 +314,45 @@ def test_bounce_c5_shard_8_bounces_1M_tris(cathedral):
         got = d_rays.cpu().numpy()
         assert np.array_equal(got[alive], cur[alive])
     assert dead.mean() < 0.01
+
+
+def test_gpu_grid_builder_equals_host_builder_and_oracle(monkeypatch):
+    """Voxel_Grid construction on the GPU (polygon-major SAT count/scan/fill/sort, and
+    the hierarchical ctor level by level).  Lists must be IDENTICAL to the host builder's and the oracle's
+    (candidate order decides exact-t ties)."""
+    v, nv, _ = soup()
+    hall = H.scenes.hall(edge=0.5)
+    box = H.scenes.shoebox()
+    for name, verts, nverts in (("soup+quads", v, nv), ("hall-45k", hall.verts, hall.nverts), ("shoebox", box.verts, box.nverts)):
+        T, To = H.Topology(verts, nverts), po.Topology(verts, nverts)
+        for domain in (1, 2, 9, 32, 64):
+            monkeypatch.delenv("HARE_BUILD", raising=False)
+            g = H.Voxel_Grid([T], domain)
+            assert g.info().built_on_device == 1, (name, domain)
+            monkeypatch.setenv("HARE_BUILD", "host")
+            h = H.Voxel_Grid([T], domain)
+            assert h.info().built_on_device == 0
+            s, i = g.Voxel_Inv()
+            sh, ih = h.Voxel_Inv()
+            so, io = po.VoxelGrid([To], domain=domain).lists()
+            assert np.array_equal(s, sh) and np.array_equal(i, ih), (name, domain, "gpu vs host")
+            assert np.array_equal(s, so) and np.array_equal(i, io), (name, domain, "gpu vs oracle")
+        for max_domain, avg in ((4, 6), (6, 12), (7, 3)):
+            monkeypatch.delenv("HARE_BUILD", raising=False)
+            g = H.Voxel_Grid([T], max_domain, avg)
+            assert g.info().built_on_device == 1
+            o = po.VoxelGrid([To], max_domain=max_domain, avg_polys=avg)
+            assert g.VoxelCt == o.ct, (name, max_domain, avg)
+            s, i = g.Voxel_Inv()
+            so, io = o.lists()
+            assert np.array_equal(s, so) and np.array_equal(i, io), (name, max_domain, avg)
+    # two topologies in one grid; rays through the GPU-built grid still match the oracle
+    monkeypatch.delenv("HARE_BUILD", raising=False)
+    g = H.Voxel_Grid([H.Topology(box.verts, box.nverts), H.Topology(v, nv)], 8)
+    o = po.VoxelGrid([po.Topology(box.verts, box.nverts), po.Topology(v, nv)], domain=8)
+    for top in (0, 1):
+        s, i = g.Voxel_Inv(top)
+        so, io = o.lists(top)
+        assert np.array_equal(s, so) and np.array_equal(i, io)
+    rays = soup_rays(5000, (6.0, 5.0, 4.0))
+    assert_events_equal(g.Shoot_batch(rays, 1)[0], o.shoot(rays, 1)[0], what="gpu-built grid, top 1")
