@@ -327,7 +327,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             void* args[] = {&g, &io};
             return launch(H, M.cull_audit, grid, block, 0, st, args);
         }
-        const bool simple = count || (flags & HARE_SHOOT_SIMPLE_KERNEL) || !M.voxel_persist_tri || !M.voxel_persist_quad ||
+        const bool simple = count || (flags & HARE_SHOOT_SIMPLE_KERNEL) || n >= 0x7FFFFF00ll || !M.voxel_persist_tri || !M.voxel_persist_quad ||
                             !M.voxel_persist_tri_g || !M.voxel_persist_quad_g;
         if (simple) {
             hipFunction_t f = count ? M.voxel_count : (quads ? M.voxel_quad : M.voxel_tri);

@@ -263,7 +263,8 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : 8;
 
     // wave-uniform work chunk [cn, ce)
-    long long cn = 0, ce = 0;
+    unsigned int cn = 0, ce = 0;                  // 32-bit: the host routes n >= 2^31 to the simple kernel
+    const unsigned int n32 = (unsigned int)io.n;
     bool drained = false;
 
     // ---- per-lane ray state
@@ -342,15 +343,14 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     unsigned int base = 0;
                     if (lane == 0) base = atomicAdd(io.work, (unsigned int)RAY_CHUNK);
                     base = __shfl(base, 0, 64);
-                    cn = (long long)base;
-                    ce = cn + RAY_CHUNK < io.n ? cn + RAY_CHUNK : io.n;
-                    if (cn >= io.n) { drained = true; break; }
+                    cn = base;
+                    if (cn >= n32) { drained = true; break; }
+                    ce = (n32 - cn > (unsigned int)RAY_CHUNK) ? cn + (unsigned int)RAY_CHUNK : n32;
                 }
-                const int rank = __popcll(wm & lane_lt);
-                const long long mine = cn + rank;
+                const unsigned int rank = (unsigned int)__popcll(wm & lane_lt);
+                const unsigned int mine = cn + rank;
                 const bool got = want && mine < ce;
-                const int taken = __popcll(__ballot(got));
-                cn += taken;
+                cn += (unsigned int)__popcll(__ballot(got));
                 if (got) {
                     want = false;
                     ray = (unsigned int)mine;
