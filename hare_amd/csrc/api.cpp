@@ -81,6 +81,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_persist_quad_g", &m->voxel_persist_quad_g},
         {"hare_octree_shoot", &m->octree},
         {"hare_octree_shoot_count", &m->octree_count},
+        {"hare_octree_persist", &m->octree_persist},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
@@ -378,6 +379,20 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         if (!f) {
             set_error("hare_shoot: octree kernel missing from code object");
             return HARE_E_STATE;
+        }
+        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && g.max_depth <= 16) {
+            // persistent kernel: frames = 20 bytes x levels x 256 lanes of LDS per workgroup
+            const unsigned plevels = (unsigned)std::max(1, g.max_depth);
+            const unsigned plds = plevels * 256u * 20u;
+            unsigned per_cu = std::min(4u, std::max(1u, (unsigned)(160 * 1024 / plds)));
+            unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
+            if (pgrid == 0) pgrid = 1;
+            const unsigned slot = s.work_slot.fetch_add(1) % 64u;
+            io.work = (unsigned int*)s.d_work + slot;
+            HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+            void* pargs[] = {&g, &io};
+            return launch(H, M.octree_persist, pgrid, 256, plds, st, pargs);
         }
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
         const unsigned levels = (unsigned)std::max(1, g.max_depth);

@@ -751,6 +751,215 @@ __device__ __forceinline__ void octree_shoot_body(const OctreeArgs& g, const Sho
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2p: Octree.Shoot as a persistent, wave-scheduled kernel (same skeleton as K1p).
+//
+// Each lane is a state machine over the depth-first walk described above (one LDS frame per level):
+//   P. a lane without a leaf examines ONE child of its top frame per step (slab test against the
+//      child's box, push-time test of "Octree - alt.cs":268, pop-time tests of :207-211), up to
+//      `steps` children per round; an accepted interior child opens a frame, an accepted leaf hands
+//      the lane its candidate list;
+//   B1. a lane in a leaf runs the conservative FP32 pre-cull on one candidate;
+//   B2. parked survivors run the exact FP64 RayXtri with u,v (the reference's full intersect), batched.
+// Same per-ray sequence of accepted hits and the same early return (:233) as the reference.
+__device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int levels = g.max_depth > 0 ? g.max_depth : 1;
+    double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] parent interval start
+    double* const fb = fa + (size_t)levels * nt;                    // [levels][nt] parent interval end
+    int* const fpk = reinterpret_cast<int*>(fb + (size_t)levels * nt);   // [levels][nt] first_child << 4 | (cursor + 1)
+
+    const int lane = tid & 63;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    const int STEPS = 4, REFILL_MIN_IDLE = 8, RAY_CHUNK = 128, EXACT_MIN_PARKED = 8;
+    const unsigned int n32 = (unsigned int)io.n;
+    unsigned int cn = 0, ce = 0;
+    bool drained = false;
+
+    bool alive = false, parked = false, hit = false;
+    unsigned int ray = 0;
+    V3 o = {0, 0, 0}, d = {0, 0, 0};
+    double invDx = 0, invDy = 0, invDz = 0;
+    float dfx = 0, dfy = 0, dfz = 0, dm = 0;
+    int mask = 0, lvl = -1;
+    int e1 = -1, e2 = -1;
+    int q = 0, qe = 0;                  // remaining candidates of the current leaf: items[q .. qe)
+    double leaf_ca = 0;                 // nodeTmin of the current leaf
+    double closestT = kDblMax, bu = 0, bv = 0;
+    int pid = -1;
+    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;
+    unsigned int nhits = 0, nrays = 0;
+
+    auto finish = [&]() {
+        XEventRec ev;
+        if (hit) {
+            ev.t = closestT; ev.u = bu; ev.v = bv;
+            ev.x = o.x + d.x * closestT; ev.y = o.y + d.y * closestT; ev.z = o.z + d.z * closestT;
+            ev.poly_id = pid;
+            ev.hit = 1;
+            nhits++;
+        } else {
+            set_miss(ev);
+        }
+        io.out[ray] = ev;
+        alive = false;
+    };
+    auto slab = [&](const double* bmin, const double* bmax, double& tmin, double& tmax) {
+        double tx0 = (bmin[0] - o.x) * invDx, tx1 = (bmax[0] - o.x) * invDx;
+        double ty0 = (bmin[1] - o.y) * invDy, ty1 = (bmax[1] - o.y) * invDy;
+        double tz0 = (bmin[2] - o.z) * invDz, tz1 = (bmax[2] - o.z) * invDz;
+        if (invDx < 0) { const double s = tx0; tx0 = tx1; tx1 = s; }
+        if (invDy < 0) { const double s = ty0; ty0 = ty1; ty1 = s; }
+        if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
+        tmin = net_max(net_max(tx0, ty0), tz0);
+        tmax = net_min(net_min(tx1, ty1), tz1);
+    };
+    // a node that passed the pop-time tests with interval [ca, cb]
+    auto visit = [&](int node, int fc, int is, int ic, double ca, double cb) {
+        if (fc < 0) {
+            q = is; qe = is + ic; leaf_ca = ca;
+        } else {
+            ++lvl;
+            fa[lvl * nt + tid] = ca;
+            fb[lvl * nt + tid] = cb;
+            fpk[lvl * nt + tid] = (fc << 4) | 8;      // cursor = 7
+        }
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill idle lanes
+        const unsigned long long idle = __ballot(!alive);
+        if (__builtin_expect(!drained && (__popcll(idle) >= REFILL_MIN_IDLE || idle == ~0ull), 0)) {
+            bool want = !alive;
+            while (true) {
+                const unsigned long long wm = __ballot(want);
+                if (wm == 0) break;
+                if (cn >= ce) {
+                    unsigned int base = 0;
+                    if (lane == 0) base = atomicAdd(io.work, (unsigned int)RAY_CHUNK);
+                    base = __shfl(base, 0, 64);
+                    cn = base;
+                    if (cn >= n32) { drained = true; break; }
+                    ce = (n32 - cn > (unsigned int)RAY_CHUNK) ? cn + (unsigned int)RAY_CHUNK : n32;
+                }
+                const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
+                const bool got = want && mine < ce;
+                cn += (unsigned int)__popcll(__ballot(got));
+                if (got) {
+                    want = false;
+                    ray = mine;
+                    const RayRec r = io.rays[ray];
+                    o.x = r.x; o.y = r.y; o.z = r.z;
+                    d.x = r.dx; d.y = r.dy; d.z = r.dz;
+                    e1 = io.excl1 ? io.excl1[ray] : -1;
+                    e2 = io.excl2 ? io.excl2[ray] : -1;
+                    hit = false; parked = false; alive = true;
+                    closestT = kDblMax; pid = -1; bu = 0; bv = 0;
+                    m0 = m1 = m2 = m3 = -1;
+                    lvl = -1; q = 0; qe = 0;
+                    if (e1 == -2) {
+                        finish();
+                    } else {
+                        nrays++;
+                        invDx = fabs(d.x) > 1e-16 ? 1.0 / d.x : 1e16;      // "Octree - alt.cs":165-167
+                        invDy = fabs(d.y) > 1e-16 ? 1.0 / d.y : 1e16;
+                        invDz = fabs(d.z) > 1e-16 ? 1.0 / d.z : 1e16;
+                        mask = ((d.x >= 0 ? 0 : 1) << 2) | ((d.y >= 0 ? 0 : 1) << 1) | (d.z >= 0 ? 0 : 1);
+                        dfx = (float)d.x; dfy = (float)d.y; dfz = (float)d.z;
+                        dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                        const OctNode& root = g.nodes[0];
+                        double rmin, rmax;
+                        slab(root.bmin, root.bmax, rmin, rmax);
+                        if (rmax < rmin || rmax < 0) finish();               // :185 (and the identical pop test :207)
+                        else visit(0, root.first_child, root.item_start, root.item_count, rmin, rmax);
+                    }
+                }
+            }
+        }
+        if (__ballot(alive) == 0) {
+            if (drained) break;
+            continue;
+        }
+
+        // ------------------------------------------------------------------ phase P: one child per step
+#pragma unroll 1
+        for (int k = 0; k < STEPS; ++k) {
+            const bool pop = alive && !parked && q == qe;
+            if (__ballot(pop) == 0) break;
+            if (pop) {
+                if (lvl < 0) {
+                    finish();                                                // stack empty: :276-283
+                } else {
+                    const int pk = fpk[lvl * nt + tid];
+                    const int cur = (pk & 15) - 1;
+                    if (cur < 0) {
+                        --lvl;                                               // frame exhausted
+                    } else {
+                        fpk[lvl * nt + tid] = pk - 1;
+                        const int c = (pk >> 4) + (cur ^ mask);
+                        const OctNode& nd = g.nodes[c];
+                        const double pa = fa[lvl * nt + tid], pb = fb[lvl * nt + tid];
+                        double tmn, tmx;
+                        slab(nd.bmin, nd.bmax, tmn, tmx);
+                        if (!(tmx < tmn || tmx < 0 || tmn > pb || tmx < pa)) {           // pushed (:268)
+                            const double ca = net_max(tmn, pa), cb = net_min(tmx, pb);  // :271
+                            if (!(cb < ca || cb < 0) && !(hit && closestT <= ca))        // popped and kept (:207-211)
+                                visit(c, nd.first_child, nd.item_start, nd.item_count, ca, cb);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ phase B1: FP32 cull (leaf candidates)
+        if (alive && !parked && q < qe) {
+            const int i = g.items[q];
+            if (i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3) {        // :218 (+ mailbox)
+                ++q;
+            } else {
+                const PolyRec& p = g.polys[i];
+                m3 = m2; m2 = m1; m1 = m0; m0 = i;
+                if (cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
+                              p.e1f, p.e2f, p.ee, p.emax))
+                    ++q;
+                else
+                    parked = true;
+            }
+        }
+
+        // ------------------------------------------------------------------ phase B2: exact test with u,v
+        {
+            const unsigned long long pm = __ballot(alive && parked);
+            const unsigned long long busy = __ballot(alive && !parked);
+            if (pm != 0 && (__popcll(pm) >= EXACT_MIN_PARKED || busy == 0)) {
+                if (alive && parked) {
+                    const int i = g.items[q];
+                    const PolyRec& p = g.polys[i];
+                    const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
+                    double t, u, v;
+                    parked = false;
+                    ++q;
+                    if (poly_full(p, v3, o, d, t, u, v) && t > kTMin && t < closestT) {   // :224-226
+                        closestT = t; bu = u; bv = v; pid = i;
+                        hit = true;
+                        if (closestT <= leaf_ca) finish();                                // :233
+                    }
+                }
+            }
+        }
+    }
+
+    if (io.ctr) {
+        const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
+        if (lane == 0) {
+            atomicAdd(&io.ctr[CTR_RAYS], r);
+            atomicAdd(&io.ctr[CTR_HITS], h);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // KDTree.Shoot: KDTree.cs:204-361.  Both children of every interior node are pushed (:355-356), so
 // every leaf is visited; the split-plane logic only fixes the ORDER, which decides
 // exact-t ties.  Explicit node stack in LDS, [slot][lane].
@@ -886,6 +1095,9 @@ __global__ __launch_bounds__(256) void hare_cull_audit(VoxelArgs g, ShootIO io) 
 // K2: Octree.Shoot ("Octree - alt.cs":159-284); dynamic LDS = levels * blockDim * 24 bytes
 __global__ void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }
 __global__ void hare_octree_shoot_count(OctreeArgs g, ShootIO io) { octree_shoot_body<true>(g, io); }
+
+// K2p: persistent Octree.Shoot (default octree kernel); dynamic LDS = levels * blockDim * 20 bytes
+__global__ __launch_bounds__(256) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }

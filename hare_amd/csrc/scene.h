@@ -51,7 +51,7 @@ struct DeviceModule {
     hipFunction_t voxel_tri = nullptr, voxel_quad = nullptr, voxel_count = nullptr;
     hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
-    hipFunction_t octree = nullptr, octree_count = nullptr;
+    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr;
     hipFunction_t cull_audit = nullptr;

@@ -119,10 +119,14 @@ def test_octree_c3_parity_and_voxel_agreement(hall):
     o = po.Octree([To], 8, 16)
     for x, y in zip(g.nodes(), o.export()):
         assert np.array_equal(x, y)
-    ev, ctr = g.Shoot_batch(rays, count_work=True)
+    ev, ctr = g.Shoot_batch(rays, count_work=True)            # one-ray-per-lane kernel with the work counters
     ref, rc = o.shoot(rays, nthreads=16)
-    assert_events_equal(ev, ref, what="C3 octree")
+    assert_events_equal(ev, ref, what="C3 octree (counting kernel)")
     assert (ctr["cells"], ctr["entries"], ctr["tests"]) == (rc["cells"], rc["entries"], rc["tests"])
+    ev, cp = g.Shoot_batch(rays)                              # the default, persistent kernel
+    assert_events_equal(ev, ref, what="C3 octree (persistent kernel)")
+    assert cp["hits"] == rc["hits"] and cp["rays"] == 1 << 20
+    assert_events_equal(g.Shoot_batch(rays, simple_kernel=True)[0], ref, what="C3 octree (simple kernel)")
     vx, _ = H.Voxel_Grid([T], 64).Shoot_batch(rays)
     assert np.array_equal(ev["hit"], vx["hit"])
     same = ev["poly_id"] == vx["poly_id"]
@@ -144,6 +148,7 @@ def test_octree_shapes_quads_and_exclusions(depth, maxp):
     g, o = H.Octree([T], depth, maxp), po.Octree([To], depth, maxp)
     ref, _ = o.shoot(rays)
     assert_events_equal(g.Shoot_batch(rays)[0], ref, what="soup octree")
+    assert_events_equal(g.Shoot_batch(rays, simple_kernel=True)[0], ref, what="soup octree (simple kernel)")
     e1 = ref["poly_id"].astype(np.int32)
     assert_events_equal(g.Shoot_batch(rays, poly_origin1=e1)[0], o.shoot(rays, excl1=e1)[0], what="soup octree excl")
 
