@@ -62,6 +62,8 @@ def main() -> None:
     ap.add_argument("--bounces", type=int, default=1,
                     help="casts per step: >1 = device-resident specular bounce loop (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -71,12 +73,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray-cast path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()   # one GPU per rank on a real node; shared only in a gloo rehearsal
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import hare_amd as H
     from hare_amd.sharding import shard_range
@@ -85,13 +91,13 @@ def main() -> None:
     topo = H.Topology(mesh.verts, mesh.nverts)
     t0 = time.time()
     if args.kind == "voxel":
-        part = H.Voxel_Grid([topo], args.domain, device=local_rank)
+        part = H.Voxel_Grid([topo], args.domain, device=device)
         kdesc = f"Voxel_Grid Domain={args.domain}"
     elif args.kind == "octree":
-        part = H.Octree([topo], 8, 16, device=local_rank)
+        part = H.Octree([topo], 8, 16, device=device)
         kdesc = "Octree maxDepth=8 maxPolys=16"
     else:
-        part = H.KDTree([topo], 12, 16, device=local_rank)
+        part = H.KDTree([topo], 12, 16, device=device)
         kdesc = "KDTree maxDepth=12 maxPolys=16"
     build_s = time.time() - t0
 
