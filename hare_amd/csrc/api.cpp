@@ -381,9 +381,9 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return HARE_E_STATE;
         }
         if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && g.max_depth <= 16) {
-            // persistent kernel: frames = 20 bytes x levels x 256 lanes of LDS per workgroup
+            // persistent kernel: frames = 24 bytes x levels x 256 lanes of LDS per workgroup
             const unsigned plevels = (unsigned)std::max(1, g.max_depth);
-            const unsigned plds = plevels * 256u * 20u;
+            const unsigned plds = plevels * 256u * 24u;
             unsigned per_cu = std::min(4u, std::max(1u, (unsigned)(160 * 1024 / plds)));
             unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);

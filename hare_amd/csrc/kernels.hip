@@ -754,25 +754,37 @@ __device__ __forceinline__ void octree_shoot_body(const OctreeArgs& g, const Sho
 // K2p: Octree.Shoot as a persistent, wave-scheduled kernel (same skeleton as K1p).
 //
 // Each lane is a state machine over the depth-first walk described above (one LDS frame per level):
-//   P. a lane without a leaf examines ONE child of its top frame per step (slab test against the
-//      child's box, push-time test of "Octree - alt.cs":268, pop-time tests of :207-211), up to
-//      `steps` children per round; an accepted interior child opens a frame, an accepted leaf hands
-//      the lane its candidate list;
+//   P. a lane without a leaf examines ONE child of its top frame per step (push-time test of
+//      "Octree - alt.cs":268, pop-time tests of :207-211), up to STEPS children per round; an accepted
+//      interior child opens a frame, an accepted leaf hands the lane its candidate list;
 //   B1. a lane in a leaf runs the conservative FP32 pre-cull on one candidate;
 //   B2. parked survivors run the exact FP64 RayXtri with u,v (the reference's full intersect), batched.
-// Same per-ray sequence of accepted hits and the same early return (:233) as the reference.
+//
+// Child boxes are not loaded.  BuildOctree derives them from the parent box ("Octree - alt.cs":96-111:
+// min = (low ? node.Min : center) - 0.1, max = (low ? center : node.Max) + 0.1, center = (Max+Min)/2),
+// so per axis the eight children share four planes.  When a frame opens, the lane computes those four
+// planes from the node's own stored box with the same expressions (bit-identical to the stored child
+// boxes -- checked on the host in tests/test_host_builders.py) and their twelve ray parameters once;
+// a child test is then six selects and the max/min of :265-266.  Only accepted children fetch their
+// 64-byte record.  Math.Max/Min are replaced by plain compare-selects that agree with them except for
+// the sign of a zero result, which is only ever compared, never returned.
+__device__ __forceinline__ double omax(double a, double b) { return (b < a || a != a) ? a : b; }   // NaN-propagating like Math.Max
+__device__ __forceinline__ double omin(double a, double b) { return (a < b || a != a) ? a : b; }
+
 __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nt = blockDim.x, tid = threadIdx.x;
     const int levels = g.max_depth > 0 ? g.max_depth : 1;
-    double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] parent interval start
-    double* const fb = fa + (size_t)levels * nt;                    // [levels][nt] parent interval end
+    double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] interval start of the frame's node
+    double* const fb = fa + (size_t)levels * nt;                    // [levels][nt] interval end
     int* const fpk = reinterpret_cast<int*>(fb + (size_t)levels * nt);   // [levels][nt] first_child << 4 | (cursor + 1)
+    int* const fnode = fpk + (size_t)levels * nt;                   // [levels][nt] node index of the frame
 
     const int lane = tid & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    const int STEPS = 4, REFILL_MIN_IDLE = 8, RAY_CHUNK = 128, EXACT_MIN_PARKED = 8;
+    // tuned on C3 (tools/sweep_oct.py): parking survivors does not pay here, several culls per round do
+    const int STEPS = 4, CULLS = 8, REFILL_MIN_IDLE = 8, RAY_CHUNK = 128, EXACT_MIN_PARKED = 1;
     const unsigned int n32 = (unsigned int)io.n;
     unsigned int cn = 0, ce = 0;
     bool drained = false;
@@ -788,8 +800,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     double leaf_ca = 0;                 // nodeTmin of the current leaf
     double closestT = kDblMax, bu = 0, bv = 0;
     int pid = -1;
-    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;
+    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the four polygons tested last (8 measured no better)
     unsigned int nhits = 0, nrays = 0;
+    // ray parameters of the top frame's child planes: [axis] low child (near, far), high child (near, far)
+    double nlx = 0, flx = 0, nhx = 0, fhx = 0, nly = 0, fly = 0, nhy = 0, fhy = 0, nlz = 0, flz = 0, nhz = 0, fhz = 0;
 
     auto finish = [&]() {
         XEventRec ev;
@@ -805,25 +819,41 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         io.out[ray] = ev;
         alive = false;
     };
-    auto slab = [&](const double* bmin, const double* bmax, double& tmin, double& tmax) {
-        double tx0 = (bmin[0] - o.x) * invDx, tx1 = (bmax[0] - o.x) * invDx;
-        double ty0 = (bmin[1] - o.y) * invDy, ty1 = (bmax[1] - o.y) * invDy;
-        double tz0 = (bmin[2] - o.z) * invDz, tz1 = (bmax[2] - o.z) * invDz;
-        if (invDx < 0) { const double s = tx0; tx0 = tx1; tx1 = s; }
-        if (invDy < 0) { const double s = ty0; ty0 = ty1; ty1 = s; }
-        if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
-        tmin = net_max(net_max(tx0, ty0), tz0);
-        tmax = net_min(net_min(tx1, ty1), tz1);
+    // child planes of a node box and their ray parameters ("Octree - alt.cs":96-111, :253-263)
+    auto planes = [&](const double* bmin, const double* bmax) {
+        {
+            const double c = (bmax[0] + bmin[0]) / 2;
+            const double a0 = ((bmin[0] - 0.1) - o.x) * invDx, a1 = ((c + 0.1) - o.x) * invDx;
+            const double b0 = ((c - 0.1) - o.x) * invDx, b1 = ((bmax[0] + 0.1) - o.x) * invDx;
+            const bool neg = invDx < 0;
+            nlx = neg ? a1 : a0; flx = neg ? a0 : a1; nhx = neg ? b1 : b0; fhx = neg ? b0 : b1;
+        }
+        {
+            const double c = (bmax[1] + bmin[1]) / 2;
+            const double a0 = ((bmin[1] - 0.1) - o.y) * invDy, a1 = ((c + 0.1) - o.y) * invDy;
+            const double b0 = ((c - 0.1) - o.y) * invDy, b1 = ((bmax[1] + 0.1) - o.y) * invDy;
+            const bool neg = invDy < 0;
+            nly = neg ? a1 : a0; fly = neg ? a0 : a1; nhy = neg ? b1 : b0; fhy = neg ? b0 : b1;
+        }
+        {
+            const double c = (bmax[2] + bmin[2]) / 2;
+            const double a0 = ((bmin[2] - 0.1) - o.z) * invDz, a1 = ((c + 0.1) - o.z) * invDz;
+            const double b0 = ((c - 0.1) - o.z) * invDz, b1 = ((bmax[2] + 0.1) - o.z) * invDz;
+            const bool neg = invDz < 0;
+            nlz = neg ? a1 : a0; flz = neg ? a0 : a1; nhz = neg ? b1 : b0; fhz = neg ? b0 : b1;
+        }
     };
     // a node that passed the pop-time tests with interval [ca, cb]
-    auto visit = [&](int node, int fc, int is, int ic, double ca, double cb) {
-        if (fc < 0) {
-            q = is; qe = is + ic; leaf_ca = ca;
+    auto visit = [&](int node, const OctNode& nd, double ca, double cb) {
+        if (nd.first_child < 0) {
+            q = nd.item_start; qe = nd.item_start + nd.item_count; leaf_ca = ca;
         } else {
             ++lvl;
             fa[lvl * nt + tid] = ca;
             fb[lvl * nt + tid] = cb;
-            fpk[lvl * nt + tid] = (fc << 4) | 8;      // cursor = 7
+            fpk[lvl * nt + tid] = (nd.first_child << 4) | 8;      // cursor = 7
+            fnode[lvl * nt + tid] = node;
+            planes(nd.bmin, nd.bmax);
         }
     };
 
@@ -869,10 +899,15 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         dfx = (float)d.x; dfy = (float)d.y; dfz = (float)d.z;
                         dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
                         const OctNode& root = g.nodes[0];
-                        double rmin, rmax;
-                        slab(root.bmin, root.bmax, rmin, rmax);
+                        double tx0 = (root.bmin[0] - o.x) * invDx, tx1 = (root.bmax[0] - o.x) * invDx;
+                        double ty0 = (root.bmin[1] - o.y) * invDy, ty1 = (root.bmax[1] - o.y) * invDy;
+                        double tz0 = (root.bmin[2] - o.z) * invDz, tz1 = (root.bmax[2] - o.z) * invDz;
+                        if (invDx < 0) { const double s = tx0; tx0 = tx1; tx1 = s; }
+                        if (invDy < 0) { const double s = ty0; ty0 = ty1; ty1 = s; }
+                        if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
+                        const double rmin = omax(omax(tx0, ty0), tz0), rmax = omin(omin(tx1, ty1), tz1);   // :182-183
                         if (rmax < rmin || rmax < 0) finish();               // :185 (and the identical pop test :207)
-                        else visit(0, root.first_child, root.item_start, root.item_count, rmin, rmax);
+                        else visit(0, root, rmin, rmax);
                     }
                 }
             }
@@ -894,18 +929,23 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     const int pk = fpk[lvl * nt + tid];
                     const int cur = (pk & 15) - 1;
                     if (cur < 0) {
-                        --lvl;                                               // frame exhausted
+                        --lvl;                                               // frame exhausted: back to the parent
+                        if (lvl >= 0) {
+                            const OctNode& pn = g.nodes[fnode[lvl * nt + tid]];
+                            planes(pn.bmin, pn.bmax);
+                        }
                     } else {
                         fpk[lvl * nt + tid] = pk - 1;
-                        const int c = (pk >> 4) + (cur ^ mask);
-                        const OctNode& nd = g.nodes[c];
+                        const int oct = cur ^ mask;                          // order[cur] (:286-306)
+                        const double tmn = omax(omax((oct & 4) ? nhx : nlx, (oct & 2) ? nhy : nly), (oct & 1) ? nhz : nlz);
+                        const double tmx = omin(omin((oct & 4) ? fhx : flx, (oct & 2) ? fhy : fly), (oct & 1) ? fhz : flz);
                         const double pa = fa[lvl * nt + tid], pb = fb[lvl * nt + tid];
-                        double tmn, tmx;
-                        slab(nd.bmin, nd.bmax, tmn, tmx);
                         if (!(tmx < tmn || tmx < 0 || tmn > pb || tmx < pa)) {           // pushed (:268)
-                            const double ca = net_max(tmn, pa), cb = net_min(tmx, pb);  // :271
-                            if (!(cb < ca || cb < 0) && !(hit && closestT <= ca))        // popped and kept (:207-211)
-                                visit(c, nd.first_child, nd.item_start, nd.item_count, ca, cb);
+                            const double ca = omax(tmn, pa), cb = omin(tmx, pb);        // :271
+                            if (!(cb < ca || cb < 0) && !(hit && closestT <= ca)) {      // popped and kept (:207-211)
+                                const int c = (pk >> 4) + oct;
+                                visit(c, g.nodes[c], ca, cb);
+                            }
                         }
                     }
                 }
@@ -913,18 +953,23 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         }
 
         // ------------------------------------------------------------------ phase B1: FP32 cull (leaf candidates)
-        if (alive && !parked && q < qe) {
-            const int i = g.items[q];
-            if (i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3) {        // :218 (+ mailbox)
-                ++q;
-            } else {
-                const PolyRec& p = g.polys[i];
-                m3 = m2; m2 = m1; m1 = m0; m0 = i;
-                if (cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
-                              p.e1f, p.e2f, p.ee, p.emax))
+#pragma unroll 1
+        for (int kc = 0; kc < CULLS; ++kc) {
+            const bool culling = alive && !parked && q < qe;
+            if (__ballot(culling) == 0) break;
+            if (culling) {
+                const int i = g.items[q];
+                if (i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3) {        // :218 (+ mailbox)
                     ++q;
-                else
-                    parked = true;
+                } else {
+                    const PolyRec& p = g.polys[i];
+                    m3 = m2; m2 = m1; m1 = m0; m0 = i;
+                    if (cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
+                                  p.e1f, p.e2f, p.ee, p.emax))
+                        ++q;
+                    else
+                        parked = true;
+                }
             }
         }
 
@@ -1096,7 +1141,7 @@ __global__ __launch_bounds__(256) void hare_cull_audit(VoxelArgs g, ShootIO io) 
 __global__ void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }
 __global__ void hare_octree_shoot_count(OctreeArgs g, ShootIO io) { octree_shoot_body<true>(g, io); }
 
-// K2p: persistent Octree.Shoot (default octree kernel); dynamic LDS = levels * blockDim * 20 bytes
+// K2p: persistent Octree.Shoot (default octree kernel); dynamic LDS = levels * blockDim * 24 bytes
 __global__ __launch_bounds__(256) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes

@@ -99,3 +99,23 @@ def test_public_members_of_voxel_grid():
     x, y, z = g.PointInVoxel((5.0, 3.5, 2.0))
     assert (x, y, z) == tuple(int(np.floor((p - info.obox_min[a]) / info.voxel_dims[a])) for a, p in enumerate((5.0, 3.5, 2.0)))
     assert g.VoxelCode(1, 2, 3) == 64 * 3 + 8 * 1 + 2      # XYTot*Z + VoxelCtY*X + Y (Voxel_Grid.cs:264-267)
+
+
+def test_octree_child_boxes_follow_from_the_parent_box():
+    """The persistent octree kernel does not load child boxes: it derives the children's planes from the
+    parent's stored box with BuildOctree's expressions ("Octree - alt.cs":96-111).  Check on the built tree
+    that this derivation reproduces every stored child box bit for bit."""
+    m = H.scenes.hall(edge=1.0)
+    g = H.Octree([H.Topology(m.verts, m.nverts)], 6, 8)
+    boxes, fc, _, _, _ = g.nodes()
+    interior = np.nonzero(fc >= 0)[0]
+    assert len(interior) > 100
+    for n in interior:
+        mn, mx = boxes[n, :3], boxes[n, 3:]
+        center = (mx + mn) / 2
+        for i in range(8):
+            bits = [(i & 4) != 0, (i & 2) != 0, (i & 1) != 0]
+            cmin = np.array([(center[a] if bits[a] else mn[a]) - 0.1 for a in range(3)])
+            cmax = np.array([(mx[a] if bits[a] else center[a]) + 0.1 for a in range(3)])
+            child = boxes[fc[n] + i]
+            assert np.array_equal(child[:3], cmin) and np.array_equal(child[3:], cmax), (n, i)
