@@ -361,3 +361,65 @@ def test_gpu_grid_builder_equals_host_builder_and_oracle(monkeypatch):
         assert np.array_equal(s, so) and np.array_equal(i, io)
     rays = soup_rays(5000, (6.0, 5.0, 4.0))
     assert_events_equal(g.Shoot_batch(rays, 1)[0], o.shoot(rays, 1)[0], what="gpu-built grid, top 1")
+
+
+def _random_scene(seed):
+    """Random soup: scale from millimetres to kilometres, optional far offset, triangles + planar quads,
+    a few huge polygons spanning many voxels and a few slivers; min corner near the origin unless shifted."""
+    rng = np.random.default_rng(seed)
+    scale = float(10.0 ** rng.integers(-3, 4))
+    shift = float(rng.choice([0.0, 0.0, 37.5, -512.0])) * scale
+    P = int(rng.integers(40, 700))
+    c = rng.uniform(0, 10, (P, 3))
+    e1 = rng.normal(0, 0.8, (P, 3))
+    e2 = rng.normal(0, 0.8, (P, 3))
+    big = rng.random(P) < 0.03
+    e1[big] *= 8
+    e2[big] *= 8
+    sliver = rng.random(P) < 0.03
+    e2[sliver] = e1[sliver] * 1.0 + rng.normal(0, 1e-3, (sliver.sum(), 3))
+    verts = np.zeros((P, 4, 3))
+    verts[:, 0] = c
+    verts[:, 1] = c + e1
+    verts[:, 2] = c + e1 + e2
+    verts[:, 3] = c + e2
+    nverts = np.where(rng.random(P) < 0.25, 4, 3).astype(np.int32)
+    verts = H.scenes.snap(verts * scale / (2.0 ** -8 * scale) * 2.0 ** -8) if scale == 1.0 else verts * scale
+    verts[nverts == 4, 3] = verts[nverts == 4, 0] + (verts[nverts == 4, 2] - verts[nverts == 4, 1])   # exact parallelograms
+    verts[nverts == 3, 3] = 0.0
+    verts[:, :, :] += shift
+    verts[nverts == 3, 3] = 0.0
+    lo = verts[:, :3].reshape(-1, 3).min(0)
+    hi = verts[:, :3].reshape(-1, 3).max(0)
+    n = 4000
+    o = rng.uniform(-0.3, 1.3, (n, 3)) * (hi - lo) + lo
+    tgt = verts[rng.integers(0, P, n), rng.integers(0, 3, n)] + rng.normal(0, 0.3 * scale, (n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::37] *= 3.5                                   # non-unit directions: t is in units of |d|
+    d[5::211, 0] = 0.0                               # axis-parallel components
+    return verts, nverts, np.ascontiguousarray(np.concatenate([o, d], 1))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_scenes_parity(seed):
+    verts, nverts, rays = _random_scene(seed)
+    T, To = H.Topology(verts, nverts), po.Topology(verts, nverts)
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([1, 3, 8, 17, 40]))
+    g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D, build_mode=1)
+    s, i = g.Voxel_Inv()
+    so, io = o.lists()
+    assert np.array_equal(s, so) and np.array_equal(i, io), (seed, D)
+    ref, _ = o.shoot(rays)
+    assert_events_equal(g.Shoot_batch(rays)[0], ref, what=f"seed {seed} voxel D={D}")
+    e1 = ref["poly_id"].astype(np.int32)
+    assert_events_equal(g.Shoot_batch(rays, poly_origin1=e1)[0], o.shoot(rays, excl1=e1)[0], what=f"seed {seed} voxel excl")
+    # trees: the octree root must cover the model (SURVEY.md F8) for the comparison to be interesting,
+    # but parity must hold either way
+    depth, maxp = int(rng.integers(1, 8)), int(rng.integers(1, 24))
+    oc, oco = H.Octree([T], depth, maxp), po.Octree([To], depth, maxp)
+    assert_events_equal(oc.Shoot_batch(rays)[0], oco.shoot(rays)[0], what=f"seed {seed} octree {depth}/{maxp}")
+    if seed % 3 == 0:
+        kd, kdo = H.KDTree([T], depth + 3, maxp), po.KDTree([To], depth + 3, maxp)
+        assert_events_equal(kd.Shoot_batch(rays[:1500])[0], kdo.shoot(rays[:1500])[0], what=f"seed {seed} kd")
