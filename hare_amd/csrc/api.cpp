@@ -285,7 +285,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.exact_min_parked = 8;
     io.audit_polys = s.topos[top].P;
     unsigned tune_blocks_per_cu = 0;
-    if (getenv("HARE_TUNE")) {   // developer knob sweep: HARE_TUNE=steps,refill,chunk,blocks_per_cu
+    if (getenv("HARE_TUNE")) {   // developer sweeps (tools/sweep.py, tools/phase_prof.py): steps,refill,chunk,blocks_per_cu,exact;
+                                 // only blocks_per_cu reaches the production kernels, the rest the profiling build
         int a = 0, b = 0, c = 0, d = 0, e = 0;
         if (sscanf(getenv("HARE_TUNE"), "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e) >= 3 && a > 0 && b > 0 && b <= 64 && c > 0) {
             io.steps_per_round = a;

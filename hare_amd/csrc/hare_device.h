@@ -29,7 +29,6 @@ static_assert(sizeof(CellRec) == 16, "cell record size");
 enum : uint32_t {
     SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
     SHOOT_SIMPLE_KERNEL = 4u,     // use the one-ray-per-lane kernel instead of the persistent one (A/B, diagnostics)
-    SHOOT_ALL_TRIS = 1u << 16,    // internal: topology has no quads
 };
 
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)
@@ -104,10 +103,12 @@ struct ShootIO {
     unsigned long long* prof;  // developer profiling kernel: 17 x u64 phase statistics (else null)
     int64_t n;
     uint32_t flags;
-    int32_t steps_per_round;   // persistent kernel: DDA steps per scheduling round
-    int32_t refill_min_idle;   // persistent kernel: refill when this many lanes are idle
-    int32_t ray_chunk;         // persistent kernel: rays drawn per ticket
-    int32_t exact_min_parked;  // persistent kernel: run the FP64 phase when this many lanes hold a survivor
+    // scheduling knobs: read only by the developer profiling build (hare_voxel_persist_prof); the
+    // production kernels use the tuned values as compile-time constants
+    int32_t steps_per_round;   // DDA steps per scheduling round
+    int32_t refill_min_idle;   // refill when this many lanes are idle
+    int32_t ray_chunk;         // rays drawn per ticket
+    int32_t exact_min_parked;  // run the FP64 phase when this many lanes hold a survivor
     int32_t audit_polys;       // hare_cull_audit: polygon count
 };
 

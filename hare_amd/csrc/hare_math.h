@@ -246,26 +246,6 @@ HARE_HD bool aabb_clip_move(const double* bmin, const double* bmax, V3& o, const
 HARE_HD double voxel_lo(int i, double vd, double omin) { return (i * vd - 0.001) + omin; }
 HARE_HD double voxel_hi(int i, double vd, double omin) { return ((i + 1) * vd + 0.001) + omin; }
 
-// Index range [imin, imax] of the voxels (along one axis) whose padded box contains coordinate h under
-// AABB.IsPointInBox's own comparisons (AABB_Main.cs:75-84: reject if h < Min or h > Max), evaluated
-// with the exact padded-box arithmetic above.  voxel_lo / voxel_hi are monotone non-decreasing in i
-// (each is a chain of correctly rounded monotone operations), so {i : lo(i) <= h} is a prefix and
-// {i : hi(i) >= h} a suffix of 0..ct-1; their intersection is what this returns (imin > imax: empty).
-// NaN h passes every comparison, like the reference: the range is 0..ct-1.
-HARE_HD void voxel_accept_range(double h, double vd, double omin, int ct, int& imin, int& imax)
-{
-    double gf = floor((h - omin) / vd);
-    int g = (gf >= 0.0) ? ((gf < (double)ct) ? (int)gf : ct - 1) : 0;   // NaN -> 0
-    int hi_i = g;
-    while (hi_i + 1 < ct && !(h < voxel_lo(hi_i + 1, vd, omin))) ++hi_i;
-    while (hi_i >= 0 && (h < voxel_lo(hi_i, vd, omin))) --hi_i;
-    int lo_i = g;
-    while (lo_i - 1 >= 0 && !(h > voxel_hi(lo_i - 1, vd, omin))) --lo_i;
-    while (lo_i < ct && (h > voxel_hi(lo_i, vd, omin))) ++lo_i;
-    imin = lo_i;
-    imax = hi_i;
-}
-
 // ---- AABB.PolyBoxOverlap: AABB_Tri_Int.cs:165-260 (Akenine-Moller SAT as Hare translated it) ----
 // One fan triangle against a box given by centre c and half-width h (AABB ctor, AABB_Main.cs:64-67).
 HARE_HD bool tri_box_sat(const double* c, const double* h, const double* A, const double* B, const double* C)

@@ -4,12 +4,24 @@
 // (contraction OFF is a correctness requirement: the reference is .NET FP64, which never fuses
 //  a*b+c; X_Event parity on near-ties depends on it -- SURVEY.md F5.)
 //
-// One ray per lane.  The traversal arithmetic is a restatement of
+// Kernels (one ray per lane everywhere):
+//   hare_voxel_persist_*   K1p  production Voxel_Grid.Shoot: persistent waves, per-lane state machine,
+//                               LDS occupancy bitmap, FP32 pre-cull + exact FP64 test
+//   hare_voxel_shoot_*     K1   the reference loop structure as is (work counters, A/B baseline)
+//   hare_octree_persist    K2p  production Octree.Shoot; hare_octree_shoot* K2 simple/counting form
+//   hare_kdtree_shoot*          KDTree.Shoot (visits every leaf, like the reference)
+//   hare_reflect           K3   specular bounce between casts (harness-defined)
+//   hare_cull_audit             tests only: FP32 cull vs exact test on every ray x polygon pair
+//   hare_vb_*, hare_scan_*      Voxel_Grid construction (build_kernels.hip, included at the end)
+//
+// The arithmetic is a restatement of
 //   Voxel_Grid.Shoot           Voxel_Grid.cs:561-761 (+ :351-552, the poly_origin overload)
 //   AABB.Intersect/IsPointInBox AABB_Main.cs:173-260, :75-84
-//   Triangle/Quadrilateral.Intersect + RayXtri  Hare_Geometry_Polygons.cs:449-510, :637-660, :784-823
-// in hare_math.h.  There is no mailbox on the GPU: re-testing a polygon can never change the
-// result because the accept is the strict `t < tmin`.
+//   Triangle/Quadrilateral.Intersect + RayXtri  Hare_Geometry_Polygons.cs:385-510, :637-688, :731-823
+//   Octree.Shoot "Octree - alt.cs":159-306, KDTree.Shoot KDTree.cs:204-361
+// kept in hare_math.h.  There is no Poly_Ray_ID mailbox on the GPU: re-testing a polygon can never
+// change the result because the accept is the strict `t < tmin`; the production kernels
+// only remember the last few polygons a ray tested, in registers.
 #include <hip/hip_runtime.h>
 #include "hare_device.h"
 
