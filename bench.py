@@ -112,24 +112,42 @@ def main() -> None:
 
     d_rays0 = d_rays.clone() if args.bounces > 1 else None
     d_excl = torch.full((n,), -1, dtype=torch.int32, device="cuda") if args.bounces > 1 else None
+    # the per-batch hit-count reduce runs on RCCL's stream, overlapped with the NEXT batch's kernel:
+    # two counter blocks alternate, a block is reused only after its all-reduce has been waited for
+    ctrs = [d_ctr, torch.zeros_like(d_ctr)]
+    pending = [None, None]
+    state = {"k": 0}
 
     def step():
-        d_ctr.zero_()
+        k = state["k"]
+        state["k"] = k + 1
+        c = ctrs[k & 1]
+        if pending[k & 1] is not None:
+            pending[k & 1].wait()
+            pending[k & 1] = None
+        c.zero_()
         if args.bounces > 1:     # config 5: shoot -> reflect -> shoot with poly_origin1 = the polygon just hit
             d_rays.copy_(d_rays0)
             d_excl.fill_(-1)
             for b in range(args.bounces):
                 part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl1=d_excl.data_ptr(),
-                                  d_counters=d_ctr.data_ptr(), stream=stream.cuda_stream)
+                                  d_counters=c.data_ptr(), stream=stream.cuda_stream)
                 if b + 1 < args.bounces:
                     part.reflect_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl.data_ptr(), stream=stream.cuda_stream)
         else:
-            part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(),
+            part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=c.data_ptr(),
                               stream=stream.cuda_stream)
         if dist is not None:
-            dist.all_reduce(d_ctr)   # RCCL: the final hit-count reduce (64 B, latency-bound)
+            pending[k & 1] = dist.all_reduce(c, async_op=True)   # RCCL: the final hit-count reduce (64 B)
+
+    def drain():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     def fence():
+        drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -152,8 +170,9 @@ def main() -> None:
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(t[0]), float(t[1])
-    hits_total = int(d_ctr[1])
-    rays_total = int(d_ctr[0])
+    last = ctrs[(state["k"] - 1) & 1]
+    hits_total = int(last[1])
+    rays_total = int(last[0])
 
     # kernel-only duration: K launches back to back on the launch stream, HIP events around them
     kern_ms = None
