@@ -21,11 +21,16 @@ namespace Hare
     {
         public abstract class Gpu_Spatial_Partition : Spatial_Partition, IDisposable
         {
+            /// <summary>HIP device ordinal new partitions are created on (the constructors keep the reference's
+            /// exact signatures, so the device is not a constructor argument).</summary>
+            public static int Device = 0;
+
             protected IntPtr scene = IntPtr.Zero;
             protected abstract int Kind { get; }
 
-            protected Gpu_Spatial_Partition(Topology[] Model_in, int device)
+            protected Gpu_Spatial_Partition(Topology[] Model_in)
             {
+                int device = Device;
                 Model = Model_in;
                 var descs = new hare_topology_desc[Model.Length];
                 var pins = new GCHandle[Model.Length * 3];
@@ -138,13 +143,15 @@ namespace Hare
             protected override int Kind { get { return HareHip.HARE_KIND_VOXEL; } }
             hare_voxel_info info;
 
-            public Gpu_Voxel_Grid(Topology[] Model_in, int Domain, int device = 0) : base(Model_in, device)
+            /// <summary>Voxel_Grid(Topology[] Model_in, int Domain) -- Voxel_Grid.cs:48</summary>
+            public Gpu_Voxel_Grid(Topology[] Model_in, int Domain) : base(Model_in)
             {
                 HareHip.Check(HareHip.hare_voxel_build(scene, Domain));
                 Refresh();
             }
 
-            public Gpu_Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys, int device) : base(Model_in, device)
+            /// <summary>Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys) -- Voxel_Grid.cs:128</summary>
+            public Gpu_Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys) : base(Model_in)
             {
                 HareHip.Check(HareHip.hare_voxel_build_adaptive(scene, MaxDomain, Avg_polys));
                 Refresh();
@@ -175,7 +182,7 @@ namespace Hare
         public class Gpu_Octree : Gpu_Spatial_Partition
         {
             protected override int Kind { get { return HareHip.HARE_KIND_OCTREE; } }
-            public Gpu_Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode, int device = 0) : base(Model_In, device)
+            public Gpu_Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) : base(Model_In)
             {
                 HareHip.Check(HareHip.hare_octree_build(scene, maxDepth, maxPolygonsPerNode));
             }
@@ -185,7 +192,7 @@ namespace Hare
         public class Gpu_KDTree : Gpu_Spatial_Partition
         {
             protected override int Kind { get { return HareHip.HARE_KIND_KDTREE; } }
-            public Gpu_KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode, int device = 0) : base(Model_In, device)
+            public Gpu_KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) : base(Model_In)
             {
                 HareHip.Check(HareHip.hare_kdtree_build(scene, maxDepth, maxPolygonsPerNode));
             }
