@@ -296,6 +296,19 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (e > 0 && e <= 64) io.exact_min_parked = e;
         }
     }
+    {
+        // staggered retirement: tier 3 stops drawing at f_base*n, tiers 2 and 1 each f_step*n later
+        double f_base = 1.0, f_step = 0.0;
+        if (getenv("HARE_RETIRE")) sscanf(getenv("HARE_RETIRE"), "%lf,%lf", &f_base, &f_step);   // developer sweeps
+        if (f_base >= 1.0 || f_base < 0.0 || f_step < 0.0 || f_base + 2.0 * f_step > 1.0) {
+            io.retire_base = 0xFFFFFFFFu;     // off
+            io.retire_step = 0;
+        } else {
+            io.retire_base = (uint32_t)(f_base * (double)n);
+            io.retire_step = (uint32_t)(f_step * (double)n);
+        }
+        io.retire_q = 1;                      // set with the persistent grid below
+    }
     const bool quads = s.topos[top].has_quads;
     const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0;
     const DeviceModule& M = *s.module;
@@ -350,6 +363,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         unsigned pgrid = (unsigned)std::max(1, M.cu_count) * std::max(1u, per_cu);
         pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
         if (pgrid == 0) pgrid = 1;
+        io.retire_q = std::max(1u, pgrid / 4u);
         const unsigned slot = s.work_slot.fetch_add(1) % 64u;
         io.work = (unsigned int*)s.d_work + slot;
         HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));

@@ -110,6 +110,12 @@ struct ShootIO {
     int32_t ray_chunk;         // rays drawn per ticket
     int32_t exact_min_parked;  // run the FP64 phase when this many lanes hold a survivor
     int32_t audit_polys;       // hare_cull_audit: polygon count
+    // Staggered retirement (persistent voxel kernel): workgroups of residency tier k = blockIdx / retire_q
+    // (the dispatcher places workgroup b on CU b mod #CU, so k is "the k-th workgroup resident on its CU")
+    // stop drawing tickets once the ticket counter has reached retire_base + (3-k)*retire_step, k = 1..3.
+    // Tier 0 never retires early and consumes the rest.  (Arithmetic, not a table: a dynamically indexed
+    // kernarg member would move the struct to scratch.)
+    uint32_t retire_q, retire_base, retire_step;
 };
 
 }  // namespace hare

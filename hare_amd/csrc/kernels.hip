@@ -274,9 +274,16 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     const int RAY_CHUNK = PROF ? io.ray_chunk : 128;
     const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : 8;
 
-    // wave-uniform work chunk [cn, ce)
-    unsigned int cn = 0, ce = 0;                  // 32-bit: the host routes n >= 2^31 to the simple kernel
-    const unsigned int n32 = (unsigned int)io.n;
+    // wave-uniform work chunk [cn, ce).  The first chunk of every wave is static (wave w owns rays
+    // [w*RAY_CHUNK, (w+1)*RAY_CHUNK)); tickets hand out the rays after those.  Same-address atomics
+    // serialise chip-wide (~30 ns each), so a start-up draw by every wave would cost ~100 us of ramp.
+    const unsigned int n32 = (unsigned int)io.n;   // 32-bit: the host routes n >= 2^31 to the simple kernel
+    const unsigned int waves_per_block = blockDim.x >> 6;
+    const unsigned int n_static = gridDim.x * waves_per_block * (unsigned int)RAY_CHUNK;
+    unsigned int cn = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * (unsigned int)RAY_CHUNK;
+    unsigned int ce = cn + (unsigned int)RAY_CHUNK;
+    if (cn > n32) cn = n32;
+    if (ce > n32) ce = n32;
     bool drained = false;
 
     // ---- per-lane ray state
@@ -355,7 +362,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     unsigned int base = 0;
                     if (lane == 0) base = atomicAdd(io.work, (unsigned int)RAY_CHUNK);
                     base = __shfl(base, 0, 64);
-                    cn = base;
+                    cn = base + n_static;
                     if (cn >= n32) { drained = true; break; }
                     ce = (n32 - cn > (unsigned int)RAY_CHUNK) ? cn + (unsigned int)RAY_CHUNK : n32;
                 }
