@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhare_hip.so")
+LIB_PATH = os.environ.get("HARE_LIB") or os.path.join(_HERE, "libhare_hip.so")   # HARE_LIB: developer A/B builds
 
 HARE_OK = 0
 HARE_E_INVALID, HARE_E_NOMEM, HARE_E_HIP, HARE_E_NODEVICE, HARE_E_STATE, HARE_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6

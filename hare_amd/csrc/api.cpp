@@ -85,6 +85,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
+        {"hare_ctr_reduce", &m->ctr_reduce},
         {"hare_cull_audit", &m->cull_audit},
         {"hare_voxel_persist_prof", &m->voxel_persist_prof},
         {"hare_vb_count", &m->vb_count},
@@ -157,6 +158,7 @@ int ensure_device(Scene& s, const HipApi*& H)
         HIP_TRY(H->Malloc(&s.d_work, 256));
         HIP_TRY(H->MemsetAsync(s.d_work, 0, 256, nullptr));
     }
+    if (!s.d_part) HIP_TRY(H->Malloc(&s.d_part, (size_t)kPartSlots * kPartWaves * 16));
     return HARE_OK;
 }
 
@@ -253,6 +255,31 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
     return HARE_OK;
 }
 
+// Batch counters of a persistent launch: the waves store {rays, hits} partials (io.part), one small
+// kernel adds them to the caller's counters afterwards.
+int prepare_partials(Scene& s, const DeviceModule& M, ShootIO& io, unsigned& pgrid)
+{
+    io.part = nullptr;
+    if (!io.ctr) return HARE_OK;
+    if (!M.ctr_reduce || !s.d_part) {
+        set_error("hare_shoot: counter-reduce kernel missing from code object");
+        return HARE_E_STATE;
+    }
+    pgrid = std::min(pgrid, kPartWaves / 4u);
+    const unsigned slot = s.work_slot.load() % kPartSlots;
+    io.part = (unsigned long long*)s.d_part + (size_t)slot * kPartWaves * 2;
+    return HARE_OK;
+}
+
+int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, unsigned waves, hipStream_t st)
+{
+    const unsigned long long* part = io.part;
+    int nw = (int)waves;
+    unsigned long long* ctr = io.ctr;
+    void* args[] = {&part, &nw, &ctr};
+    return launch(H, M.ctr_reduce, 1, 256, 0, st, args);
+}
+
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
                       const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st)
 {
@@ -295,19 +322,6 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             tune_blocks_per_cu = d > 0 ? (unsigned)d : 0u;
             if (e > 0 && e <= 64) io.exact_min_parked = e;
         }
-    }
-    {
-        // staggered retirement: tier 3 stops drawing at f_base*n, tiers 2 and 1 each f_step*n later
-        double f_base = 1.0, f_step = 0.0;
-        if (getenv("HARE_RETIRE")) sscanf(getenv("HARE_RETIRE"), "%lf,%lf", &f_base, &f_step);   // developer sweeps
-        if (f_base >= 1.0 || f_base < 0.0 || f_step < 0.0 || f_base + 2.0 * f_step > 1.0) {
-            io.retire_base = 0xFFFFFFFFu;     // off
-            io.retire_step = 0;
-        } else {
-            io.retire_base = (uint32_t)(f_base * (double)n);
-            io.retire_step = (uint32_t)(f_step * (double)n);
-        }
-        io.retire_q = 1;                      // set with the persistent grid below
     }
     const bool quads = s.topos[top].has_quads;
     const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0;
@@ -363,19 +377,26 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         unsigned pgrid = (unsigned)std::max(1, M.cu_count) * std::max(1u, per_cu);
         pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
         if (pgrid == 0) pgrid = 1;
-        io.retire_q = std::max(1u, pgrid / 4u);
+        if (int rc = prepare_partials(s, M, io, pgrid)) return rc;
+        // ticket size: measured optimum on MI355X (tools/sweep_ticket.py) -- 32 rays up to ~1.5M rays, where the
+        // end of the batch dominates, growing to 128 where the ~11 ns/ticket atomic rate would start to bind
+        io.ticket_rays = n < 1572864 ? 32 : (n < 6291456 ? 64 : (n < 12582912 ? 96 : 128));
+        if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
         const unsigned slot = s.work_slot.fetch_add(1) % 64u;
         io.work = (unsigned int*)s.d_work + slot;
         HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
         void* args[] = {&g, &io};
         hipFunction_t pf = g.occ_in_lds ? (quads ? M.voxel_persist_quad : M.voxel_persist_tri)
                                         : (quads ? M.voxel_persist_quad_g : M.voxel_persist_tri_g);
+        if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
         if ((flags & 0x4000u) && M.voxel_persist_prof && g.occ_in_lds && !quads && d_ctr) {
             // developer profiling: phase statistics land in the 17 u64 words FOLLOWING the counters block
             io.prof = (unsigned long long*)d_ctr + CTR_WORDS;
             pf = M.voxel_persist_prof;
         }
-        return launch(H, pf, pgrid, block, lds, st, args);
+        int rc = launch(H, pf, pgrid, block, lds, st, args);
+        if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * 4u, st);
+        return rc;
     }
     if (kind == HARE_KIND_OCTREE) {
         if (!s.oct.built || !s.d_oct_nodes) {
@@ -403,11 +424,16 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
+            if (int rc = prepare_partials(s, M, io, pgrid)) return rc;
+            io.ticket_rays = 32;                  // an octree ray costs ~10x a voxel ray: ticket atomics never bind
+            if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
             const unsigned slot = s.work_slot.fetch_add(1) % 64u;
             io.work = (unsigned int*)s.d_work + slot;
             HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
             void* pargs[] = {&g, &io};
-            return launch(H, M.octree_persist, pgrid, 256, plds, st, pargs);
+            int rc = launch(H, M.octree_persist, pgrid, 256, plds, st, pargs);
+            if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * 4u, st);
+            return rc;
         }
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
         const unsigned levels = (unsigned)std::max(1, g.max_depth);
@@ -556,7 +582,7 @@ void hare_scene_destroy(hare_scene* s)
         if (s->stream) (void)H->StreamSynchronize(s->stream);
         for (auto* v : {&s->d_polys, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
-        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_rays,
+        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_part, &s->d_rays,
                          &s->d_e1, &s->d_e2, &s->d_out, &s->d_ctr})
             dev_free(H, *p);
         if (s->stream) (void)H->StreamDestroy(s->stream);

@@ -100,6 +100,8 @@ struct ShootIO {
     XEventRec* out;            // n
     unsigned long long* ctr;   // nullable: CTR_WORDS counters, atomically accumulated
     unsigned int* work;        // persistent kernels: next-ray ticket (zeroed before launch)
+    unsigned long long* part;  // persistent kernels with ctr: {rays, hits} per wave, plain stores; hare_ctr_reduce adds
+                               // them to ctr afterwards (8192 end-of-kernel atomics on two addresses cost ~45 us)
     unsigned long long* prof;  // developer profiling kernel: 17 x u64 phase statistics (else null)
     int64_t n;
     uint32_t flags;
@@ -110,12 +112,9 @@ struct ShootIO {
     int32_t ray_chunk;         // rays drawn per ticket
     int32_t exact_min_parked;  // run the FP64 phase when this many lanes hold a survivor
     int32_t audit_polys;       // hare_cull_audit: polygon count
-    // Staggered retirement (persistent voxel kernel): workgroups of residency tier k = blockIdx / retire_q
-    // (the dispatcher places workgroup b on CU b mod #CU, so k is "the k-th workgroup resident on its CU")
-    // stop drawing tickets once the ticket counter has reached retire_base + (3-k)*retire_step, k = 1..3.
-    // Tier 0 never retires early and consumes the rest.  (Arithmetic, not a table: a dynamically indexed
-    // kernarg member would move the struct to scratch.)
-    uint32_t retire_q, retire_base, retire_step;
+    // persistent voxel kernel: rays per ticket after each wave's static first chunk.  Small tickets even
+    // out the end of a small batch; large ones keep the (chip-wide serialised) ticket atomics rare.
+    int32_t ticket_rays;
 };
 
 }  // namespace hare

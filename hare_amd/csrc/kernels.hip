@@ -267,6 +267,14 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     const double fct = (double)ct;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // developer timeline (flag 0x2000, tools/timeline_prof.py): per wave {start, last refill, end} on the
+    // 100 MHz wall clock, stored straight to memory so that nothing stays live across the loop
+    auto timeline = [&](int slot) {
+        if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
+            if (lane == 0) io.prof[32 + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6)) + slot] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    timeline(0);
     // scheduling knobs: compile-time in the production kernels (fewer live SGPRs), run-time in the
     // developer profiling build so that sweeps need no rebuild
     const int STEPS_PER_ROUND = PROF ? io.steps_per_round : 3;
@@ -278,9 +286,8 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     // [w*RAY_CHUNK, (w+1)*RAY_CHUNK)); tickets hand out the rays after those.  Same-address atomics
     // serialise chip-wide (~30 ns each), so a start-up draw by every wave would cost ~100 us of ramp.
     const unsigned int n32 = (unsigned int)io.n;   // 32-bit: the host routes n >= 2^31 to the simple kernel
-    const unsigned int waves_per_block = blockDim.x >> 6;
-    const unsigned int n_static = gridDim.x * waves_per_block * (unsigned int)RAY_CHUNK;
-    unsigned int cn = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) * (unsigned int)RAY_CHUNK;
+    const unsigned int n_static = gridDim.x * 4u * (unsigned int)RAY_CHUNK;     // the host launches 4 waves per workgroup
+    unsigned int cn = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned int)RAY_CHUNK;
     unsigned int ce = cn + (unsigned int)RAY_CHUNK;
     if (cn > n32) cn = n32;
     if (ce > n32) ce = n32;
@@ -360,16 +367,18 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                 if (wm == 0) break;
                 if (cn >= ce) {   // draw a new chunk: one atomic per RAY_CHUNK rays per wave
                     unsigned int base = 0;
-                    if (lane == 0) base = atomicAdd(io.work, (unsigned int)RAY_CHUNK);
+                    const unsigned int dyn = (unsigned int)io.ticket_rays;     // run-time: the host sizes tickets to the batch
+                    if (lane == 0) base = atomicAdd(io.work, dyn);
                     base = __shfl(base, 0, 64);
                     cn = base + n_static;
                     if (cn >= n32) { drained = true; break; }
-                    ce = (n32 - cn > (unsigned int)RAY_CHUNK) ? cn + (unsigned int)RAY_CHUNK : n32;
+                    ce = (n32 - cn > dyn) ? cn + dyn : n32;
                 }
                 const unsigned int rank = (unsigned int)__popcll(wm & lane_lt);
                 const unsigned int mine = cn + rank;
                 const bool got = want && mine < ce;
                 cn += (unsigned int)__popcll(__ballot(got));
+                timeline(1);
                 if (got) {
                     want = false;
                     ray = (unsigned int)mine;
@@ -556,15 +565,18 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 #pragma unroll
             for (int k = 0; k < 16; ++k) atomicAdd(&io.prof[k], pf[k]);
             atomicAdd(&io.prof[16], 1ull);
+
         }
     }
 
+    timeline(2);
     // batch counters: one atomic pair per wave
     if (io.ctr) {
         const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
         if (lane == 0) {
-            atomicAdd(&io.ctr[CTR_RAYS], r);
-            atomicAdd(&io.ctr[CTR_HITS], h);
+            unsigned long long* slot = io.part + 2ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+            slot[0] = r;
+            slot[1] = h;
         }
     }
 }
@@ -805,7 +817,12 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     // tuned on C3 (tools/sweep_oct.py): parking survivors does not pay here, several culls per round do
     const int STEPS = 4, CULLS = 8, REFILL_MIN_IDLE = 8, RAY_CHUNK = 128, EXACT_MIN_PARKED = 1;
     const unsigned int n32 = (unsigned int)io.n;
-    unsigned int cn = 0, ce = 0;
+    // static first chunk per wave, tickets of io.ticket_rays after those (as in the voxel kernel)
+    const unsigned int n_static = gridDim.x * 4u * (unsigned int)RAY_CHUNK;
+    unsigned int cn = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (unsigned int)RAY_CHUNK;
+    unsigned int ce = cn + (unsigned int)RAY_CHUNK;
+    if (cn > n32) cn = n32;
+    if (ce > n32) ce = n32;
     bool drained = false;
 
     bool alive = false, parked = false, hit = false;
@@ -886,11 +903,12 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 if (wm == 0) break;
                 if (cn >= ce) {
                     unsigned int base = 0;
-                    if (lane == 0) base = atomicAdd(io.work, (unsigned int)RAY_CHUNK);
+                    const unsigned int dyn = (unsigned int)io.ticket_rays;
+                    if (lane == 0) base = atomicAdd(io.work, dyn);
                     base = __shfl(base, 0, 64);
-                    cn = base;
+                    cn = base + n_static;
                     if (cn >= n32) { drained = true; break; }
-                    ce = (n32 - cn > (unsigned int)RAY_CHUNK) ? cn + (unsigned int)RAY_CHUNK : n32;
+                    ce = (n32 - cn > dyn) ? cn + dyn : n32;
                 }
                 const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
                 const bool got = want && mine < ce;
@@ -1017,8 +1035,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     if (io.ctr) {
         const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
         if (lane == 0) {
-            atomicAdd(&io.ctr[CTR_RAYS], r);
-            atomicAdd(&io.ctr[CTR_HITS], h);
+            unsigned long long* slot = io.part + 2ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+            slot[0] = r;
+            slot[1] = h;
         }
     }
 }
@@ -1166,6 +1185,29 @@ __global__ __launch_bounds__(256) void hare_octree_persist(OctreeArgs g, ShootIO
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }
 __global__ void hare_kdtree_shoot_count(KdArgs g, ShootIO io) { kdtree_shoot_body<true>(g, io); }
+
+// Batch counters of the persistent kernels: sum the per-wave {rays, hits} partials into ctr (one launch
+// of one workgroup after the shoot kernel, same stream).
+__global__ __launch_bounds__(256) void hare_ctr_reduce(const unsigned long long* part, int waves, unsigned long long* ctr)
+{
+    __shared__ unsigned long long sr[4], sh[4];
+    unsigned long long r = 0, h = 0;
+    for (int k = threadIdx.x; k < waves; k += blockDim.x) {
+        r += part[2 * k];
+        h += part[2 * k + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_down(r, off, 64);
+        h += __shfl_down(h, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { sr[threadIdx.x >> 6] = r; sh[threadIdx.x >> 6] = h; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&ctr[CTR_RAYS], sr[0] + sr[1] + sr[2] + sr[3]);
+        atomicAdd(&ctr[CTR_HITS], sh[0] + sh[1] + sh[2] + sh[3]);
+    }
+}
 
 // K3: specular bounce (harness-defined): o' = X_Point, d' = d - (2*(d.n))*n,
 // next exclusion = the polygon just hit; rays that missed are marked dead (-2).

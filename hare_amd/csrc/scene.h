@@ -12,6 +12,9 @@
 
 namespace hare {
 
+constexpr unsigned kPartSlots = 8;        // ring of launches whose counter partials may be in flight
+constexpr unsigned kPartWaves = 8192;     // >= waves of one persistent launch (CUs x 4 workgroups x 4 waves)
+
 struct Topo {
     int32_t P = 0;
     std::vector<double> verts;    // P x 12
@@ -53,7 +56,7 @@ struct DeviceModule {
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
-    hipFunction_t reflect = nullptr;
+    hipFunction_t reflect = nullptr, ctr_reduce = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
     hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
@@ -80,6 +83,7 @@ struct Scene {
     void* d_kd_items = nullptr;
     void* d_work = nullptr;                      // ticket counters for persistent kernels (64 x u32)
     std::atomic<unsigned> work_slot{0};
+    void* d_part = nullptr;                      // per-wave {rays, hits} partials: kPartSlots launches x kPartWaves waves
 
     // staging for hare_shoot_batch (guarded by mu)
     std::mutex mu;

@@ -1,4 +1,5 @@
-"""Developer sweep of the staggered-retirement cutoffs (HARE_RETIRE=f1,f2,f3) on the bench workload."""
+"""Developer sweep of the staggered-retirement draw budgets (HARE_BUDGET=f1,f2,f3: fractions of the fair share of ticket chunks) on the bench workload.
+The first configuration should be "tickets" (reference output); every other output is compared with it."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,8 +20,10 @@ def run(K=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / K
 res = []
-for cfg in sys.argv[1:] or ["1,1,1"]:
-    os.environ["HARE_RETIRE"] = cfg
+for cfg in sys.argv[1:] or ["tickets"]:
+    if cfg == "tickets": os.environ.pop("HARE_BUDGET", None)
+    else: os.environ["HARE_BUDGET"] = cfg
+    out.zero_()
     ms = run()
     o = out.cpu().numpy().copy()
     if ref is None: ref = o

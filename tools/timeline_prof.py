@@ -1,0 +1,33 @@
+"""Developer tool: per-wave timeline of the production persistent voxel kernel (flag 0x2000): when each wave
+started, took its last rays, and ended, grouped by residency tier (blockIdx // (grid/4))."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import hare_amd as H
+N = int(os.environ.get("RAYS", 1 << 20)); D = 64
+mesh = H.scenes.hall(); g = H.Voxel_Grid([H.Topology(mesh.verts, mesh.nverts)], D)
+rays = H.scenes.burst_rays(N, mesh.size)
+dr = torch.from_numpy(rays).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
+W = 4096
+buf = torch.zeros(8 + 32 + 4 * W, dtype=torch.int64, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+for cfg in sys.argv[1:] or ["tickets"]:
+    if cfg == "tickets": os.environ.pop("HARE_BUDGET", None)
+    else: os.environ["HARE_BUDGET"] = cfg
+    for rep in range(2):
+        buf.zero_()
+        g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x2000)
+        torch.cuda.synchronize()
+    tl = buf.cpu().numpy()[8 + 32:].reshape(W, 4).astype(np.float64)
+    live = tl[:, 0] > 0
+    t0 = tl[live, 0].min()
+    start = (tl[:, 0] - t0) / 100.0; last = (tl[:, 1] - t0) / 100.0; end = (tl[:, 2] - t0) / 100.0   # microseconds
+    print("== %s: kernel span %.0f us, waves live %d" % (cfg, end[live].max(), live.sum()))
+    tier = (np.arange(W) // 4) // 256
+    for k in range(4):
+        m = live & (tier == k)
+        print("  tier %d: start %.0f..%.0f  last-refill p10/50/90 %.0f/%.0f/%.0f  end p10/50/90/max %.0f/%.0f/%.0f/%.0f  tail(end-last) mean %.0f"
+              % (k, start[m].min(), start[m].max(), *np.percentile(last[m], [10, 50, 90]), *np.percentile(end[m], [10, 50, 90]), end[m].max(),
+                 (end[m] - last[m]).mean()))
+    e = np.sort(end[live]); tot = e.max()
+    print("  waves still running at 50/60/70/80/90/95%% of span: %s" % [int((e > tot * f).sum()) for f in (0.5, 0.6, 0.7, 0.8, 0.9, 0.95)])
