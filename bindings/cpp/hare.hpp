@@ -61,6 +61,23 @@ public:
         check(hare_polygon_normals(verts.data(), nverts.data(), P, normals.data()));
         check(hare_topology_bounds(verts.data(), nverts.data(), P, Min, Max));
     }
+    // Topology(Point[][]) + Finish_Topology(): raw polygon soup through the reference's ingest (Round(15) and the
+    // 1 mm Hash2 corner merge) first.  Vertices_List and the per-corner vertex index are returned on request.
+    static Topology from_polygons(const double* soup, const int32_t* nv, int32_t P, std::vector<double>* vertices = nullptr,
+                                  std::vector<int32_t>* corner_vertex = nullptr)
+    {
+        std::vector<double> merged((size_t)P * 12), vlist;
+        std::vector<int32_t> cv((size_t)P * 4);
+        size_t corners = 0;
+        for (int32_t p = 0; p < P; ++p) corners += (size_t)(nv[p] > 0 ? nv[p] : 0);
+        vlist.resize(corners * 3 + 3);
+        int32_t n_vertices = 0;
+        check(hare_topology_ingest(soup, nv, P, merged.data(), cv.data(), vlist.data(), &n_vertices));
+        vlist.resize((size_t)n_vertices * 3);
+        if (vertices) *vertices = std::move(vlist);
+        if (corner_vertex) *corner_vertex = std::move(cv);
+        return Topology(merged.data(), nv, P);
+    }
     int Polygon_Count() const { return (int)nverts.size(); }
     std::array<double, 3> Normal(int Poly_ID) const { return {{normals[3 * Poly_ID], normals[3 * Poly_ID + 1], normals[3 * Poly_ID + 2]}}; }
     std::array<double, 3> operator()(int Poly_ID, int Corner_ID) const

@@ -44,6 +44,23 @@ int main()
     Topology topo(verts.data(), nverts.data(), (int32_t)nverts.size());
     int failures = 0;
     try {
+        {   // ingest: a copy of polygon 0 whose corners are 0.2 mm off merges back onto polygon 0's vertices
+            std::vector<double> soup(verts.begin(), verts.begin() + 12);
+            soup.insert(soup.end(), verts.begin(), verts.begin() + 12);
+            for (int c = 0; c < nverts[0]; ++c) soup[12 + 3 * c] += 0.0002;
+            const int32_t nv2[2] = {nverts[0], nverts[0]};
+            std::vector<double> vlist;
+            std::vector<int32_t> cv;
+            Topology merged = Topology::from_polygons(soup.data(), nv2, 2, &vlist, &cv);
+            bool same = true;
+            for (int k = 0; k < 3 * nverts[0]; ++k) same = same && merged.verts[12 + k] == merged.verts[k];
+            if (!same || (int)vlist.size() != 3 * nverts[0] || cv[4] != cv[0]) {
+                std::printf("selftest: ingest did not merge near-duplicate corners\n");
+                ++failures;
+            }
+            const int32_t bad[1] = {5};
+            if (hare_topology_ingest(soup.data(), bad, 1, soup.data(), nullptr, nullptr, nullptr) != HARE_E_UNSUPPORTED) ++failures;
+        }
         Voxel_Grid fixed({&topo}, 9);
         Voxel_Grid adaptive({&topo}, 5, 6, 0);
         Octree oct({&topo}, 5, 6);

@@ -115,6 +115,26 @@ namespace Hare
                 return (int)ctr.hits;
             }
 
+#if NET7_0_OR_GREATER
+            /// <summary>Span flavour (net7.0 target): rays/events may live in any contiguous memory -- a slice of a larger
+            /// array, native memory, a stackalloc -- and are pinned only for the duration of the call.</summary>
+            public unsafe int Shoot(Span<hare_ray> rays, int top_index, Span<hare_xevent> results,
+                                    ReadOnlySpan<int> poly_origin1 = default, ReadOnlySpan<int> poly_origin2 = default, bool moveOrigins = false)
+            {
+                if (results.Length < rays.Length) throw new ArgumentException("results is shorter than rays");
+                if (!poly_origin1.IsEmpty && poly_origin1.Length < rays.Length) throw new ArgumentException("poly_origin1 is shorter than rays");
+                if (!poly_origin2.IsEmpty && poly_origin2.Length < rays.Length) throw new ArgumentException("poly_origin2 is shorter than rays");
+                hare_counters ctr;
+                fixed (hare_ray* r = rays)
+                fixed (hare_xevent* e = results)
+                fixed (int* e1 = poly_origin1)      // an empty span pins to null == "no exclusions"
+                fixed (int* e2 = poly_origin2)
+                    HareHip.Check(HareHip.hare_shoot_batch(scene, Kind, top_index, rays.Length, r, e1, e2,
+                                                           moveOrigins ? HareHip.HARE_SHOOT_WRITEBACK_ORIGIN : 0u, e, &ctr));
+                return (int)ctr.hits;
+            }
+#endif
+
             public override bool Shoot(Ray R, int top_index, out X_Event Ret_event)
             {
                 return Shoot(R, top_index, out Ret_event, -1, -1);

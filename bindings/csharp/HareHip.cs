@@ -78,6 +78,13 @@ namespace Hare
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_shoot_batch(IntPtr scene, int kind, int top_index, long n, [In, Out] hare_ray[] rays,
                                                       int[] excl1, int[] excl2, uint flags, [Out] hare_xevent[] ev, out hare_counters ctr);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern unsafe int hare_shoot_batch(IntPtr scene, int kind, int top_index, long n, hare_ray* rays,
+                                                             int* excl1, int* excl2, uint flags, hare_xevent* ev, hare_counters* ctr);
+            /// <summary>Topology(Point[][]) ingest for hosts holding a raw polygon soup (include/hare_hip.h).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_topology_ingest([In] double[] soup, [In] int[] nverts, int P, [Out] double[] verts_out,
+                                                          [Out] int[] corner_vertex, [Out] double[] vertices_out, out int n_vertices);
 
             public static void Check(int rc)
             {

@@ -65,6 +65,7 @@ SYMBOLS = {
     "hare_hip_runtime_path": (C.c_char_p, []),
     "hare_polygon_normals": (C.c_int, [_vp, _vp, _i32, _vp]),
     "hare_topology_bounds": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "hare_topology_ingest": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "hare_scene_create": (C.c_int, [_vp, _i32, _i32, _vp]),
     "hare_scene_destroy": (None, [_vp]),
     "hare_voxel_build": (C.c_int, [_vp, _i32]),

@@ -522,6 +522,34 @@ int hare_topology_bounds(const double* verts, const int32_t* nverts, int32_t P, 
     return HARE_OK;
 }
 
+int hare_topology_ingest(const double* soup, const int32_t* nverts, int32_t P, double* verts_out, int32_t* corner_vertex,
+                         double* vertices_out, int32_t* n_vertices_out)
+{
+    if (n_vertices_out) *n_vertices_out = 0;
+    if (P < 0 || (P > 0 && (!soup || !nverts || !verts_out))) {
+        set_error("hare_topology_ingest: bad arguments");
+        return HARE_E_INVALID;
+    }
+    for (int32_t p = 0; p < P; ++p)
+        if (nverts[p] != 3 && nverts[p] != 4) {
+            set_error("hare_topology_ingest: Hare does not support polygons of other than 3 or 4 sides");
+            return HARE_E_UNSUPPORTED;
+        }
+    try {
+        std::vector<double> vertices;
+        const int nv = topology_ingest(soup, nverts, P, verts_out, corner_vertex, vertices);
+        if (vertices_out && nv > 0) memcpy(vertices_out, vertices.data(), (size_t)nv * 3 * sizeof(double));
+        if (n_vertices_out) *n_vertices_out = nv;
+    } catch (const std::bad_alloc&) {
+        set_error("hare_topology_ingest: out of memory");
+        return HARE_E_NOMEM;
+    } catch (...) {
+        set_error("hare_topology_ingest: unexpected exception");
+        return HARE_E_INVALID;
+    }
+    return HARE_OK;
+}
+
 int hare_scene_create(const hare_topology_desc* topos, int32_t n_topos, int32_t device, hare_scene** out)
 {
     if (!out) {

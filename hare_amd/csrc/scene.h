@@ -128,5 +128,7 @@ int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys);
 // host helpers
 void polygon_normals(const double* verts, const int32_t* nverts, int32_t P, double* out);
 void topology_bounds(const double* verts, const int32_t* nverts, int32_t P, double mn[3], double mx[3]);
+int topology_ingest(const double* soup, const int32_t* nverts, int32_t P, double* verts_out, int32_t* corner_vertex,
+                    std::vector<double>& vertices);   // ingest.cpp
 
 }  // namespace hare

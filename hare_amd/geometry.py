@@ -87,6 +87,43 @@ class Topology:
         self.Min = np.ascontiguousarray(Min, np.float64)
         self.Max = np.ascontiguousarray(Max, np.float64)
 
+    @classmethod
+    def from_polygons(cls, T, nverts=None):
+        """Topology(Point[][] T) (Hare_Geometry_Topology.cs:120-142) followed by Finish_Topology(): the raw
+        corners go through the reference's ingest (Math.Round(x, 15), corners in the same 1 mm Hash2 cell
+        merged onto the first one) before normals and bounds are taken.  `T` is [P,3,3], [P,4,3] or a
+        sequence of 3- or 4-corner polygons; `nverts` overrides the corner count per polygon.
+        The result also carries Vertices_List (`.vertices`) and the per-corner vertex index (`.corner_vertex`)."""
+        if not isinstance(T, np.ndarray):
+            polys = [np.asarray(p, np.float64).reshape(-1, 3) for p in T]
+            soup = np.zeros((len(polys), 4, 3), np.float64)
+            nverts = np.zeros(len(polys), np.int32)
+            for i, p in enumerate(polys):
+                if p.shape[0] not in (3, 4):
+                    raise NotImplementedError("Hare Does not yet support polygons of more than 4 sides.")
+                soup[i, :p.shape[0]] = p
+                nverts[i] = p.shape[0]
+        else:
+            v = np.ascontiguousarray(T, np.float64)
+            soup = np.zeros((v.shape[0], 4, 3), np.float64)
+            soup[:, :v.shape[1]] = v
+            if nverts is None:
+                nverts = np.full(v.shape[0], v.shape[1], np.int32)
+        nverts = np.ascontiguousarray(nverts, np.int32)
+        P = soup.shape[0]
+        verts = np.zeros((P, 4, 3), np.float64)
+        corner_vertex = np.full((P, 4), -1, np.int32)
+        vertices = np.zeros((max(int(nverts.sum()), 1), 3), np.float64)
+        nv = C.c_int32(0)
+        rc = lib.hare_topology_ingest(ptr(soup), ptr(nverts), P, ptr(verts), ptr(corner_vertex), ptr(vertices), C.addressof(nv))
+        if rc == capi.HARE_E_UNSUPPORTED:
+            raise NotImplementedError(capi.last_error())
+        check(rc)
+        top = cls(verts, nverts)
+        top.vertices = vertices[:nv.value].copy()
+        top.corner_vertex = corner_vertex
+        return top
+
     @property
     def Polygon_Count(self) -> int:
         return int(self.verts.shape[0])

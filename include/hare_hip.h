@@ -111,6 +111,21 @@ HARE_API const char *hare_hip_runtime_path(void);
 HARE_API int hare_polygon_normals(const double *verts, const int32_t *nverts, int32_t P, double *normals_out);
 HARE_API int hare_topology_bounds(const double *verts, const int32_t *nverts, int32_t P, double min_out[3], double max_out[3]);
 
+/* Topology(Point[][]) ingest, for hosts that start from a raw polygon soup (Hare_Geometry_Topology.cs:120-142
+ * ctor, :258-311 Build_Topology, :342-377 AddGetIndex; Point.Round / Point.Hash2
+ * Hare_Geometry_Primitives.cs:230-250; MS_AABB Hare_Geometry_Topology.cs:677-697).  Every corner is rounded
+ * with Math.Round(x, 15) and corners that fall into the same 1 mm Hash2 cell are merged onto the FIRST such
+ * corner, in polygon order, exactly as the managed Topology does.
+ *   soup           P x 4 x 3 corner coordinates (slot 3 ignored for triangles)
+ *   verts_out      P x 4 x 3: the merged corner coordinates (unused slots zero) -- what hare_scene_create,
+ *                  hare_polygon_normals and hare_topology_bounds expect
+ *   corner_vertex  nullable, P x 4: index of each corner in Vertices_List order (-1 in unused slots)
+ *   vertices_out   nullable, capacity sum(nverts) x 3: Vertices_List
+ *   n_vertices_out nullable: length of Vertices_List
+ * A polygon with nverts other than 3 or 4 is HARE_E_UNSUPPORTED (the reference throws NotImplementedException). */
+HARE_API int hare_topology_ingest(const double *soup, const int32_t *nverts, int32_t P, double *verts_out,
+                                  int32_t *corner_vertex, double *vertices_out, int32_t *n_vertices_out);
+
 /* ---- scene = Spatial_Partition.Model (Spatial_Partition.cs:29) ----
  * Copies the topologies; `device` is the HIP device ordinal that will hold the scene. */
 HARE_API int hare_scene_create(const hare_topology_desc *topos, int32_t n_topos, int32_t device, hare_scene **out);
