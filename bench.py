@@ -100,6 +100,7 @@ def main() -> None:
         part = H.KDTree([topo], 12, 16, device=device)
         kdesc = "KDTree maxDepth=12 maxPolys=16"
     build_s = time.time() - t0
+    kernel_name = {"voxel": "hare_voxel_persist_tri", "octree": "hare_octree_persist", "kdtree": "hare_kdtree_shoot"}[args.kind]
 
     n = args.rays
     n_total = n * world
@@ -230,7 +231,7 @@ def main() -> None:
         wkey = f"{args.scene}-{args.kind}-D{args.domain}-n{n}"
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(wkey),
-                    "kernel": "hare_voxel_shoot", "kernel_ms": round(kern_ms, 4),
+                    "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
                     "algorithmic_bytes_per_launch": bytes_launch,
                     "bytes_per_ray": round(bytes_launch / n, 1),
                     "per_ray": {"C_cells": round(ctr["cells"] / n, 2), "L_entries": round(ctr["entries"] / n, 2),
