@@ -277,10 +277,11 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     timeline(0);
     // scheduling knobs: compile-time in the production kernels (fewer live SGPRs), run-time in the
     // developer profiling build so that sweeps need no rebuild
+    // tuned on MI355X at 1M and 16M rays (tools/ab_libs.py): steps 3 / refill 16 / exact 12
     const int STEPS_PER_ROUND = PROF ? io.steps_per_round : 3;
-    const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : 8;
+    const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : 16;
     const int RAY_CHUNK = PROF ? io.ray_chunk : 128;
-    const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : 8;
+    const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : 12;
 
     // wave-uniform work chunk [cn, ce).  The first chunk of every wave is static (wave w owns rays
     // [w*RAY_CHUNK, (w+1)*RAY_CHUNK)); tickets hand out the rays after those.  Same-address atomics
