@@ -26,5 +26,9 @@ print("%%.4f ms  %%.0f Mrays/s  crc %%08x" %% (best, N / best / 1e3, zlib.crc32(
 for lib in sys.argv[1:]:
     env = dict(os.environ)
     if lib != "default": env["HARE_LIB"] = os.path.abspath(lib)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=float(os.environ.get("AB_TIMEOUT", 90)))
+    except subprocess.TimeoutExpired:
+        print("%-40s TIMEOUT (hung kernel?) -- stopping" % os.path.basename(lib), flush=True)
+        sys.exit(3)      # never start another GPU run after a hang
     print("%-40s %s" % (os.path.basename(lib), (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1]), flush=True)
