@@ -52,7 +52,7 @@ class VoxelInfo(C.Structure):
 
 
 class TreeInfo(C.Structure):
-    _fields_ = [("n_nodes", C.c_int32), ("max_depth", C.c_int32), ("max_polys", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_nodes", C.c_int32), ("max_depth", C.c_int32), ("max_polys", C.c_int32), ("built_on_device", C.c_int32),
                 ("total_items", C.c_uint64)]
 
 

@@ -99,6 +99,8 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_vb_finalize", &m->vb_finalize},
         {"hare_vb_find_big", &m->vb_find_big},
         {"hare_vb_fill_big", &m->vb_fill_big},
+        {"hare_ob_count", &m->ob_count},
+        {"hare_ob_fill", &m->ob_fill},
     };
     for (auto& t : table) {
         hipError_t e = H->ModuleGetFunction(t.fn, m->mod, t.name);
@@ -723,8 +725,27 @@ int hare_octree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
-    int rc = build_octree(*s, max_depth, max_polys);
+    int rc = octree_check_args(*s, max_depth, max_polys);
     if (rc) return rc;
+    bool on_gpu = false;
+    {   // SAT binning on the GPU when there is one (HARE_BUILD=host forces the host builder; identical output)
+        const char* mode = getenv("HARE_BUILD");
+        std::string e;
+        const HipApi* H = (mode && strcmp(mode, "host") == 0) ? nullptr : hip_api(&e);
+        int n = 0;
+        if (H && H->GetDeviceCount(&n) == hipSuccess && n > 0) {
+            rc = ensure_device(*s, H);
+            if (rc) return rc;
+            rc = upload_polys(*s, H);
+            if (rc) return rc;
+            rc = gpu_build_octree(*s, H, max_depth, max_polys, &on_gpu);
+            if (rc) return rc;
+        }
+    }
+    if (!on_gpu) {
+        rc = build_octree(*s, max_depth, max_polys);
+        if (rc) return rc;
+    }
     return sync_partition_to_device(s, HARE_KIND_OCTREE);
     GUARD_END
 }
@@ -797,6 +818,7 @@ int hare_octree_get_info(const hare_scene* s, hare_tree_info* out)
     out->n_nodes = (int32_t)s->oct.nodes.size();
     out->max_depth = s->oct.max_depth;
     out->max_polys = s->oct.max_polys;
+    out->built_on_device = s->oct.built_on_device ? 1 : 0;
     out->total_items = s->oct.items.size();
     return HARE_OK;
 }

@@ -326,4 +326,202 @@ int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int3
     return HARE_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Octree.BuildOctree on the GPU ("Octree - alt.cs":91-138).  Level by level: the host decides which nodes
+// of the level split (depth < maxDepth and more than maxPolygonsPerNode polygons, :93) and writes the
+// children's boxes; the GPU runs every PolyBoxOverlap of the level (hare_ob_count -> host prefix ->
+// hare_ob_fill, ordered, so a child's list keeps its parent's ascending order exactly like the
+// reference's foreach).  Nodes are numbered afterwards in the host builder's (depth-first) order, so both
+// builders return identical arrays.
+int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_polys, bool* used)
+{
+    *used = false;
+    const DeviceModule& M = *s.module;
+    if (!M.ob_count || !M.ob_fill) return HARE_OK;
+    const Topo& T = s.topos[0];
+    DevMem mem(H);
+    BuildArgs b;
+    memset(&b, 0, sizeof b);
+    b.polys = (const PolyRec*)s.d_polys[0];
+    b.quads = (const QuadRec*)s.d_quads[0];
+    b.P = T.P;
+
+    struct BNode {                 // breadth-first working node
+        double bmin[3], bmax[3];
+        int32_t first_child;       // BFS index, -1 leaf
+        int32_t level;             // which level array holds its list
+        uint32_t start, count;     // list = level_items[level][start .. start + count)
+    };
+    std::vector<BNode> nodes;
+    std::vector<std::vector<int32_t>> level_items;     // host mirrors of the per-level item arrays
+    {
+        BNode r;
+        memset(&r, 0, sizeof r);
+        octree_root_box(T, r.bmin, r.bmax);
+        r.first_child = -1;
+        r.level = 0;
+        r.start = 0;
+        r.count = (uint32_t)T.P;
+        nodes.push_back(r);
+        level_items.emplace_back((size_t)T.P);
+        for (int32_t i = 0; i < T.P; ++i) level_items[0][i] = i;
+    }
+    void* d_cur = nullptr;         // device copy of the current level's item array
+    int rc = mem.alloc(&d_cur, (size_t)T.P * 4, false);
+    if (rc) return rc;
+    if (T.P > 0) HIP_TRY(H->Memcpy(d_cur, level_items[0].data(), (size_t)T.P * 4, hipMemcpyHostToDevice));
+
+    constexpr uint32_t kSeg = 8192;                    // parent-list entries per task
+    size_t level_begin = 0;                            // nodes of the current level: [level_begin, nodes.size())
+    for (int depth = 0; depth < max_depth; ++depth) {
+        const size_t level_end = nodes.size();
+        std::vector<OctTask> tasks;
+        std::vector<uint32_t> task_child;              // BFS index of the child a task belongs to
+        for (size_t n = level_begin; n < level_end; ++n) {
+            if ((int64_t)nodes[n].count <= (int64_t)max_polys) continue;          // :93
+            if (nodes.size() + 8 > 0x7FFFFFF0ull) {
+                set_error("hare_octree_build: more than 2^31 nodes");
+                return HARE_E_UNSUPPORTED;
+            }
+            nodes[n].first_child = (int32_t)nodes.size();
+            const BNode parent = nodes[n];
+            for (int i = 0; i < 8; ++i) {
+                BNode c;
+                memset(&c, 0, sizeof c);
+                octree_child_box(parent.bmin, parent.bmax, i, c.bmin, c.bmax);
+                c.first_child = -1;
+                c.level = depth + 1;
+                const uint32_t child = (uint32_t)nodes.size();
+                nodes.push_back(c);
+                for (uint32_t q = 0; q < parent.count; q += kSeg) {
+                    OctTask t;
+                    memset(&t, 0, sizeof t);
+                    for (int a = 0; a < 3; ++a) {
+                        t.bmin[a] = c.bmin[a];
+                        t.bmax[a] = c.bmax[a];
+                    }
+                    t.pstart = parent.start + q;
+                    t.pcount = std::min(kSeg, parent.count - q);
+                    tasks.push_back(t);
+                    task_child.push_back(child);
+                }
+            }
+        }
+        if (tasks.empty()) break;
+        if (tasks.size() > 0x7FFFFFFFull) {
+            set_error("hare_octree_build: level too large for one launch");
+            return HARE_E_UNSUPPORTED;
+        }
+        void* d_tasks = nullptr;
+        void* d_counts = nullptr;
+        rc = mem.alloc(&d_tasks, tasks.size() * sizeof(OctTask), false);
+        if (rc) return rc;
+        rc = mem.alloc(&d_counts, tasks.size() * 4, false);
+        if (rc) return rc;
+        HIP_TRY(H->Memcpy(d_tasks, tasks.data(), tasks.size() * sizeof(OctTask), hipMemcpyHostToDevice));
+        {
+            void* args[] = {&b, &d_tasks, &d_cur, &d_counts};
+            rc = launch(H, M.ob_count, (unsigned)tasks.size(), 256, 0, nullptr, args);
+            if (rc) return rc;
+        }
+        std::vector<uint32_t> counts(tasks.size());
+        HIP_TRY(H->Memcpy(counts.data(), d_counts, tasks.size() * 4, hipMemcpyDeviceToHost));
+        // prefix over tasks (tasks of one child are consecutive and in list order) = the next level's item array
+        uint64_t total = 0;
+        for (size_t k = 0; k < tasks.size(); ++k) {
+            BNode& c = nodes[task_child[k]];
+            if (k == 0 || task_child[k] != task_child[k - 1]) c.start = (uint32_t)total;
+            tasks[k].ostart = (uint32_t)total;
+            c.count += counts[k];
+            total += counts[k];
+            if (total > 0x7FFFFFF0ull) {
+                set_error("hare_octree_build: more than 2^31 list entries on one level");
+                return HARE_E_UNSUPPORTED;
+            }
+        }
+        void* d_next = nullptr;
+        rc = mem.alloc(&d_next, (size_t)total * 4, false);
+        if (rc) return rc;
+        HIP_TRY(H->Memcpy(d_tasks, tasks.data(), tasks.size() * sizeof(OctTask), hipMemcpyHostToDevice));
+        {
+            void* args[] = {&b, &d_tasks, &d_cur, &d_next};
+            rc = launch(H, M.ob_fill, (unsigned)tasks.size(), 256, 0, nullptr, args);
+            if (rc) return rc;
+        }
+        level_items.emplace_back((size_t)total);
+        if (total) HIP_TRY(H->Memcpy(level_items.back().data(), d_next, (size_t)total * 4, hipMemcpyDeviceToHost));
+        // the parent level's device array and this level's scratch are no longer needed
+        for (void* p : {d_cur, d_tasks, d_counts}) {
+            mem.release(p);
+            (void)H->Free(p);
+        }
+        d_cur = d_next;
+        level_begin = level_end;
+    }
+
+    // depth-first renumbering = the order in which the recursive reference / host builder allocates nodes:
+    // a node's eight children get consecutive numbers when the node is processed, then each subtree in turn
+    std::vector<int32_t> order;                 // order[new] = BFS index
+    order.reserve(nodes.size());
+    std::vector<int32_t> renum(nodes.size(), -1);
+    {
+        order.push_back(0);
+        renum[0] = 0;
+        std::vector<std::pair<int32_t, int>> stack;      // (BFS node, next child to descend into)
+        auto open = [&](int32_t n) {
+            if (nodes[n].first_child >= 0) {
+                for (int i = 0; i < 8; ++i) {
+                    renum[nodes[n].first_child + i] = (int32_t)order.size();
+                    order.push_back(nodes[n].first_child + i);
+                }
+                stack.emplace_back(n, 0);
+            }
+        };
+        open(0);
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            if (top.second == 8) {
+                stack.pop_back();
+                continue;
+            }
+            const int32_t child = nodes[top.first].first_child + top.second++;
+            open(child);
+        }
+    }
+    OctreeHost o;
+    o.max_depth = max_depth;
+    o.max_polys = max_polys;
+    o.nodes.resize(nodes.size());
+    size_t tot = 0;
+    for (const BNode& n : nodes)
+        if (n.first_child < 0) tot += n.count;
+    if (tot > 0x7FFFFFF0ull) {
+        set_error("hare_octree_build: more than 2^31 leaf entries");
+        return HARE_E_UNSUPPORTED;
+    }
+    o.items.reserve(tot);
+    for (size_t k = 0; k < order.size(); ++k) {
+        const BNode& n = nodes[order[k]];
+        OctNode r;
+        memset(&r, 0, sizeof r);
+        for (int a = 0; a < 3; ++a) {
+            r.bmin[a] = n.bmin[a];
+            r.bmax[a] = n.bmax[a];
+        }
+        r.first_child = n.first_child >= 0 ? renum[n.first_child] : -1;
+        r.item_start = (int32_t)o.items.size();
+        if (n.first_child < 0) {                 // a node that split has handed its list on (node.Polygons.Clear(), :132)
+            r.item_count = (int32_t)n.count;
+            const int32_t* src = level_items[n.level].data() + n.start;
+            o.items.insert(o.items.end(), src, src + n.count);
+        }
+        o.nodes[k] = r;
+    }
+    o.built = true;
+    o.built_on_device = true;
+    s.oct = std::move(o);
+    *used = true;
+    return HARE_OK;
+}
+
 }  // namespace hare

@@ -295,21 +295,16 @@ struct OBuild {
 void oct_split(OBuild& b, int32_t ni, int depth)
 {
     if (depth >= b.max_depth || (int)b.lists[ni].size() <= b.max_polys) return;   // :93
-    double nmin[3], nmax[3], center[3];
+    double nmin[3], nmax[3];
     for (int a = 0; a < 3; ++a) {
         nmin[a] = b.nodes[ni].bmin[a];
         nmax[a] = b.nodes[ni].bmax[a];
-        center[a] = (nmax[a] + nmin[a]) / 2;     // AABB.Center, AABB_Main.cs:64
     }
     const int32_t first = (int32_t)b.nodes.size();
-    for (int i = 0; i < 8; ++i) {                // :99-114, bit 4 -> x, 2 -> y, 1 -> z
+    for (int i = 0; i < 8; ++i) {
         OctNode c;
         memset(&c, 0, sizeof c);
-        const int bit[3] = {4, 2, 1};
-        for (int a = 0; a < 3; ++a) {
-            c.bmin[a] = ((i & bit[a]) == 0 ? nmin[a] : center[a]) - 0.1;
-            c.bmax[a] = ((i & bit[a]) == 0 ? center[a] : nmax[a]) + 0.1;
-        }
+        octree_child_box(nmin, nmax, i, c.bmin, c.bmax);
         c.first_child = -1;
         b.nodes.push_back(c);
         b.lists.emplace_back();
@@ -328,7 +323,37 @@ void oct_split(OBuild& b, int32_t ni, int depth)
 
 }  // namespace
 
-int build_octree(Scene& s, int32_t max_depth, int32_t max_polys)
+// the eight loose children of a node: bit 4 -> x, 2 -> y, 1 -> z ("Octree - alt.cs":96-114)
+void octree_child_box(const double nmin[3], const double nmax[3], int i, double cmin[3], double cmax[3])
+{
+    const int bit[3] = {4, 2, 1};
+    for (int a = 0; a < 3; ++a) {
+        const double center = (nmax[a] + nmin[a]) / 2;     // AABB.Center, AABB_Main.cs:64
+        cmin[a] = ((i & bit[a]) == 0 ? nmin[a] : center) - 0.1;
+        cmax[a] = ((i & bit[a]) == 0 ? center : nmax[a]) + 0.1;
+    }
+}
+
+// root cube ("Octree - alt.cs":63-88)
+void octree_root_box(const Topo& T, double bmin[3], double bmax[3])
+{
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int32_t p = 0; p < T.P; ++p)
+        for (int c = 0; c < T.nverts[p]; ++c)
+            for (int a = 0; a < 3; ++a) {
+                const double v = T.verts[(size_t)p * 12 + 3 * c + a];
+                if (v < mn[a]) mn[a] = v;
+                if (v > mx[a]) mx[a] = v;
+            }
+    const double maxdim = net_max(mx[0] - mn[0], net_max(mx[1] - mn[1], mx[2] - mn[2]));   // :78
+    for (int a = 0; a < 3; ++a) {
+        const double center = mx[a] + mn[a] / 2;   // `max + min / 2` as written (:79, SURVEY.md F8)
+        bmin[a] = center - maxdim - 1e-1;
+        bmax[a] = center + maxdim + 1e-1;
+    }
+}
+
+int octree_check_args(const Scene& s, int32_t max_depth, int32_t max_polys)
 {
     if (max_depth < 0 || max_depth > 24 || max_polys < 0) {
         set_error("hare_octree_build: max_depth must be in [0, 24], max_polys >= 0");
@@ -340,27 +365,20 @@ int build_octree(Scene& s, int32_t max_depth, int32_t max_polys)
         set_error("hare_octree_build: exactly one topology is supported (reference uses Model[0] for membership)");
         return HARE_E_UNSUPPORTED;
     }
+    return HARE_OK;
+}
+
+int build_octree(Scene& s, int32_t max_depth, int32_t max_polys)
+{
+    if (int rc = octree_check_args(s, max_depth, max_polys)) return rc;
     const Topo& T = s.topos[0];
-    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int32_t p = 0; p < T.P; ++p)
-        for (int c = 0; c < T.nverts[p]; ++c)
-            for (int a = 0; a < 3; ++a) {
-                const double v = T.verts[(size_t)p * 12 + 3 * c + a];
-                if (v < mn[a]) mn[a] = v;
-                if (v > mx[a]) mx[a] = v;
-            }
-    const double maxdim = net_max(mx[0] - mn[0], net_max(mx[1] - mn[1], mx[2] - mn[2]));   // :78
     OBuild b;
     b.T0 = &T;
     b.max_depth = max_depth;
     b.max_polys = max_polys;
     OctNode root;
     memset(&root, 0, sizeof root);
-    for (int a = 0; a < 3; ++a) {
-        const double center = mx[a] + mn[a] / 2;   // `max + min / 2` as written (:79, SURVEY.md F8)
-        root.bmin[a] = center - maxdim - 1e-1;
-        root.bmax[a] = center + maxdim + 1e-1;
-    }
+    octree_root_box(T, root.bmin, root.bmax);
     root.first_child = -1;
     b.nodes.push_back(root);
     b.lists.emplace_back();

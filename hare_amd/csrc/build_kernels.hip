@@ -119,6 +119,46 @@ __device__ __forceinline__ void voxel_major(const BuildArgs& b, const uint32_t* 
     if (!FILL) count[c] = n;
 }
 
+// ---- Octree.BuildOctree ("Octree - alt.cs":91-138) -------------------------------------------------
+// A splitting node hands each polygon of its list to every child whose loose box it overlaps, in list
+// order.  One workgroup per task (child box x <= 8192-entry segment of the parent's list): 256 entries
+// at a time, exact PolyBoxOverlap, survivors appended in order with a block-wide prefix sum.
+template <bool FILL>
+__device__ __forceinline__ void octree_task(const BuildArgs& b, const OctTask* tasks, const int32_t* pitems, uint32_t* counts,
+                                            int32_t* oitems)
+{
+    __shared__ uint32_t wcount[4];
+    __shared__ uint32_t base_s;
+    const OctTask t = tasks[blockIdx.x];
+    const double bmin[3] = {t.bmin[0], t.bmin[1], t.bmin[2]}, bmax[3] = {t.bmax[0], t.bmax[1], t.bmax[2]};
+    if (threadIdx.x == 0) base_s = FILL ? t.ostart : 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (uint32_t q0 = 0; q0 < t.pcount; q0 += 256) {
+        const uint32_t q = q0 + threadIdx.x;
+        bool in = false;
+        int p = -1;
+        if (q < t.pcount) {
+            p = pitems[t.pstart + q];
+            double V[12];
+            const int nv = load_corners(b, p, V);
+            in = poly_box_overlap(bmin, bmax, V, nv);
+        }
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) wcount[wid] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (FILL) {
+            uint32_t off = base_s;
+            for (int w = 0; w < wid; ++w) off += wcount[w];
+            if (in) oitems[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+    }
+    if (!FILL && threadIdx.x == 0) counts[blockIdx.x] = base_s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -277,6 +317,15 @@ __global__ __launch_bounds__(256) void hare_vb_fill_big(BuildArgs b, const uint3
         if (threadIdx.x == 0) base_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void hare_ob_count(BuildArgs b, const OctTask* tasks, const int32_t* pitems, uint32_t* counts)
+{
+    octree_task<false>(b, tasks, pitems, counts, nullptr);
+}
+__global__ __launch_bounds__(256) void hare_ob_fill(BuildArgs b, const OctTask* tasks, const int32_t* pitems, int32_t* oitems)
+{
+    octree_task<true>(b, tasks, pitems, nullptr, oitems);
 }
 
 // cell records (start, count, first two entries inlined) + occupancy bitmap (zeroed beforehand)

@@ -93,6 +93,16 @@ struct BuildArgs {             // Voxel_Grid construction kernels (build_kernels
     double vd[3];              // VoxelDims
 };
 
+// Octree construction on the GPU (build_kernels.hip: hare_ob_count / hare_ob_fill): one workgroup per
+// task = one child box x one segment of its parent's polygon list.
+struct OctTask {               // 64 bytes
+    double bmin[3], bmax[3];   // the child's loose box ("Octree - alt.cs":99-114)
+    uint32_t pstart, pcount;   // segment of the parent level's item array
+    uint32_t ostart;           // where this task's survivors go in the child level's item array (fill pass)
+    uint32_t pad;
+};
+static_assert(sizeof(OctTask) == 64, "octree task size");
+
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN
     const int32_t* excl1;      // nullable: poly_origin1 per ray

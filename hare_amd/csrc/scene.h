@@ -36,6 +36,7 @@ struct VoxelHost {
 
 struct OctreeHost {
     bool built = false;
+    bool built_on_device = false;
     int32_t max_depth = 0, max_polys = 0;
     std::vector<OctNode> nodes;
     std::vector<int32_t> items;
@@ -62,6 +63,7 @@ struct DeviceModule {
     hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
     hipFunction_t scan_block = nullptr, scan_add = nullptr, vb_sort_small = nullptr, vb_sort_block = nullptr, vb_finalize = nullptr;
     hipFunction_t vb_find_big = nullptr, vb_fill_big = nullptr;
+    hipFunction_t ob_count = nullptr, ob_fill = nullptr;
     int cu_count = 0;
 };
 
@@ -118,11 +120,15 @@ void voxel_grid_set_ct(VoxelHost& g, int32_t ct);
 // GPU builders (build_gpu.cpp); *used = false means "not applicable, use the host builder"
 int gpu_build_voxel_fixed(Scene& s, const HipApi* H, int32_t domain, bool* used);
 int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int32_t avg_polys, bool* used);
+int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_polys, bool* used);
 
 // builders (host); return HARE_* codes
 int build_voxel_fixed(Scene& s, int32_t domain);
 int build_voxel_adaptive(Scene& s, int32_t max_domain, int32_t avg_polys);
 int build_octree(Scene& s, int32_t max_depth, int32_t max_polys);
+int octree_check_args(const Scene& s, int32_t max_depth, int32_t max_polys);
+void octree_root_box(const Topo& T, double bmin[3], double bmax[3]);                      // "Octree - alt.cs":63-88
+void octree_child_box(const double nmin[3], const double nmax[3], int i, double cmin[3], double cmax[3]);   // :96-114
 int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys);
 
 // host helpers

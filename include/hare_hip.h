@@ -166,7 +166,7 @@ typedef struct hare_tree_info {
     int32_t n_nodes;
     int32_t max_depth;
     int32_t max_polys;
-    int32_t reserved;
+    int32_t built_on_device;    /* 1: the membership tests ran on the GPU (octree); same arrays either way */
     uint64_t total_items;
 } hare_tree_info;
 HARE_API int hare_octree_get_info(const hare_scene *s, hare_tree_info *out);

@@ -261,6 +261,28 @@ def test_fp32_cull_never_rejects_a_hit():
         assert culled > 0.5 * cands          # and it is actually doing something
 
 
+def test_gpu_octree_builder_equals_host_builder(monkeypatch):
+    """Octree.BuildOctree with the PolyBoxOverlap tests on the GPU (build_gpu.cpp: gpu_build_octree) returns
+    the very arrays the host builder does (which tests/test_host_builders.py pins to the oracle): boxes,
+    child links in depth-first creation order, leaf lists in parent order."""
+    v, nv, _ = soup()
+    hall = H.scenes.hall(edge=1.0)
+    full = H.scenes.hall()
+    cases = [("soup", v, nv, 6, 8), ("soup-deep", v, nv, 9, 2), ("soup-flat", v, nv, 0, 4), ("soup-leafy", v, nv, 5, 10 ** 6),
+             ("hall-coarse", hall.verts, hall.nverts, 7, 12), ("hall", full.verts, full.nverts, 8, 16)]
+    for name, verts, nverts, depth, polys in cases:
+        top = H.Topology(verts, nverts)
+        monkeypatch.delenv("HARE_BUILD", raising=False)
+        g = H.Octree([top], depth, polys)
+        assert g.info().built_on_device == 1, name
+        monkeypatch.setenv("HARE_BUILD", "host")
+        h = H.Octree([top], depth, polys)
+        assert h.info().built_on_device == 0, name
+        for a, b, what in zip(g.nodes(), h.nodes(), ("boxes", "first_child", "item_start", "item_count", "items")):
+            assert np.array_equal(a, b), (name, what)
+    monkeypatch.delenv("HARE_BUILD", raising=False)
+
+
 @pytest.fixture(scope="module")
 def cathedral():
     m = H.scenes.cathedral()
