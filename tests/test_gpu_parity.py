@@ -261,6 +261,72 @@ def test_fp32_cull_never_rejects_a_hit():
         assert culled > 0.5 * cands          # and it is actually doing something
 
 
+def degenerate_rays(size, ct, seed=17):
+    """Rays a traversal kernel could trip over: zero / axis-parallel / denormal / huge / inf / NaN direction
+    components, origins on voxel faces, edges and corners, on the model corner, far outside, inf and NaN."""
+    rng = np.random.default_rng(seed)
+    L = np.asarray(size, np.float64)
+    nan, inf = np.nan, np.inf
+    base = [
+        [1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 0, 0], [1, 1, 1, 0, -1, 0], [1, 1, 1, 0, 0, 1], [1, 1, 1, 0, 0, 1e-320],
+        [1, 1, 1, nan, 0, 1], [1, 1, 1, nan, nan, nan], [nan, 1, 1, 1, 0, 0], [inf, 1, 1, -1, 0, 0], [1, 1, 1, inf, 0, 0],
+        [1, 1, 1, 1, -inf, 0.5], [-50, 1, 1, 1, 0, 0], [-50, 1, 1, -1, 0, 0], [0, 0, 0, 1, 1, 1], [0, 0, 0, -1, -1, -1],
+        [1e300, 1, 1, -1, 0, 0], [1, 1, 1, 1e-300, 1e-300, 1], [1, 1, 1, 1e300, 1e300, 1e300], [1, 1, 1, -0.0, 0.0, -1],
+        [L[0], L[1], L[2], -1, -1, -1], [L[0] / 2, L[1] / 2, -1e-7, 0, 0, 1], [L[0] / 2, L[1] / 2, L[2] + 1e-7, 0, 0, -1],
+    ]
+    rows = [np.asarray(b, np.float64) for b in base]
+    vd = L / ct
+    for _ in range(400):          # origins on voxel faces / edges / corners with assorted directions
+        idx = rng.integers(0, ct + 1, 3).astype(np.float64)
+        frac = np.where(rng.random(3) < 0.6, 0.0, rng.random(3))
+        o = np.minimum((idx + frac) * vd, L)
+        d = rng.normal(size=3)
+        d[rng.random(3) < 0.3] = 0.0
+        rows.append(np.concatenate([o, d]))
+    special = np.array([0.0, -0.0, 1.0, -1.0, 1e-310, -1e-310, 1e200, nan, inf, -inf, 0.5])
+    for _ in range(400):          # random mixtures of special values
+        o = rng.uniform(-1, 1, 3) * (L + 2)
+        d = rng.normal(size=3)
+        k = rng.random(3) < 0.5
+        d[k] = rng.choice(special, int(k.sum()))
+        if rng.random() < 0.15:
+            o[rng.integers(0, 3)] = rng.choice(special[5:])
+        rows.append(np.concatenate([o, d]))
+    return np.ascontiguousarray(np.stack(rows))
+
+
+def bits_equal(a, b, what):
+    for f in ("hit", "poly_id", "t", "u", "v", "x", "y", "z"):
+        x, y = np.ascontiguousarray(a[f]), np.ascontiguousarray(b[f])
+        if x.dtype.kind == "f":
+            x, y = x.view(np.int64), y.view(np.int64)
+        bad = np.nonzero(x != y)[0]
+        assert bad.size == 0, f"{what}: X_Event.{f} differs on rays {bad[:8]}"
+
+
+@pytest.mark.parametrize("domain", [1, 8, 33])
+def test_degenerate_rays_match_the_oracle_bit_for_bit(domain):
+    """Zero, axis-parallel, denormal, huge, inf and NaN ray components; origins on voxel faces/edges/corners and
+    far outside: every kernel returns exactly what the restated reference does (and terminates)."""
+    m = H.scenes.shoebox()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    rays = degenerate_rays(m.size, domain)
+    ref, rc = po.VoxelGrid([To], domain=domain).shoot(rays.copy())
+    g = H.Voxel_Grid([T], domain)
+    for kw in ({}, {"simple_kernel": True}, {"count_work": True}):
+        ev, c = g.Shoot_batch(rays.copy(), **kw)
+        bits_equal(ev, ref, f"voxel D={domain} {kw}")
+        assert c["hits"] == rc["hits"]
+    if domain == 8:
+        oref, _ = po.Octree([To], 5, 8).shoot(rays.copy())
+        for kw in ({}, {"simple_kernel": True}):
+            ev, _ = H.Octree([T], 5, 8).Shoot_batch(rays.copy(), **kw)
+            bits_equal(ev, oref, f"octree {kw}")
+        kref, _ = po.KDTree([To], 6, 8).shoot(rays.copy())
+        ev, _ = H.KDTree([T], 6, 8).Shoot_batch(rays.copy())
+        bits_equal(ev, kref, "kdtree")
+
+
 def test_gpu_octree_builder_equals_host_builder(monkeypatch):
     """Octree.BuildOctree with the PolyBoxOverlap tests on the GPU (build_gpu.cpp: gpu_build_octree) returns
     the very arrays the host builder does (which tests/test_host_builders.py pins to the oracle): boxes,
