@@ -230,7 +230,7 @@ int upload_voxel(Scene& s, const HipApi* H)
         v->assign(M, nullptr);
     }
     const size_t ncell = (size_t)g.ct * g.ct * g.ct;
-    s.occ_words = (int32_t)((ncell + 31) / 32);
+    occ_layout(g.ct, s.occ_shift, s.occ_cd, s.occ_words);
     for (size_t m = 0; m < M; ++m) {
         std::vector<CellRec> cells(ncell);
         std::vector<uint32_t> occ((size_t)((s.occ_words + 3) / 4) * 4, 0u);   // padded to 16 bytes for uint4 staging
@@ -239,7 +239,11 @@ int upload_voxel(Scene& s, const HipApi* H)
             cells[c].count = g.start[m][c + 1] - g.start[m][c];
             cells[c].i0 = cells[c].count > 0 ? g.items[m][cells[c].start] : -1;
             cells[c].i1 = cells[c].count > 1 ? g.items[m][cells[c].start + 1] : -1;
-            if (cells[c].count) occ[c >> 5] |= 1u << (c & 31);
+            if (cells[c].count) {
+                const size_t z = c % g.ct, y = (c / g.ct) % g.ct, x = c / ((size_t)g.ct * g.ct);
+                const size_t b = (((x >> s.occ_shift) * s.occ_cd) + (y >> s.occ_shift)) * s.occ_cd + (z >> s.occ_shift);
+                occ[b >> 5] |= 1u << (b & 31);
+            }
         }
         int rc = upload(H, &s.d_cells[m], cells.data(), cells.size() * sizeof(CellRec));
         if (rc) return rc;
@@ -345,6 +349,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.occ = (const uint32_t*)s.d_occ[top];
         g.ct = s.vox.ct;
         g.occ_words = s.occ_words;
+        g.occ_shift = s.occ_shift;
+        g.occ_cd = s.occ_cd;
         for (int a = 0; a < 3; ++a) {
             g.omin[a] = s.vox.omin[a];
             g.omax[a] = s.vox.omax[a];
@@ -370,9 +376,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return launch(H, f, grid, block, 0, st, args);
         }
         // persistent kernel: a grid that just fills the chip; waves draw ray chunks from a ticket
-        const size_t occ_bytes = (size_t)((s.occ_words + 3) / 4) * 16;
-        g.occ_in_lds = occ_bytes <= 64 * 1024 ? 1 : 0;
-        const unsigned lds = g.occ_in_lds ? (unsigned)occ_bytes : 0u;
+        const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;     // the occupancy bitmap, <= 64 KB (occ_layout)
+        const bool coarse = s.occ_shift > 0;
         unsigned per_cu = 4;
         if (tune_blocks_per_cu) per_cu = tune_blocks_per_cu;
         if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(160 * 1024 / lds));
@@ -388,10 +393,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         io.work = (unsigned int*)s.d_work + slot;
         HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
         void* args[] = {&g, &io};
-        hipFunction_t pf = g.occ_in_lds ? (quads ? M.voxel_persist_quad : M.voxel_persist_tri)
-                                        : (quads ? M.voxel_persist_quad_g : M.voxel_persist_tri_g);
+        hipFunction_t pf = !coarse ? (quads ? M.voxel_persist_quad : M.voxel_persist_tri)
+                                   : (quads ? M.voxel_persist_quad_g : M.voxel_persist_tri_g);
         if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
-        if ((flags & 0x4000u) && M.voxel_persist_prof && g.occ_in_lds && !quads && d_ctr) {
+        if ((flags & 0x4000u) && M.voxel_persist_prof && !coarse && !quads && d_ctr) {
             // developer profiling: phase statistics land in the 17 u64 words FOLLOWING the counters block
             io.prof = (unsigned long long*)d_ctr + CTR_WORDS;
             pf = M.voxel_persist_prof;

@@ -84,10 +84,11 @@ void fill_args(BuildArgs& b, const Scene& s, size_t m, const VoxelHost& g)
 }
 
 // cells + occupancy from (start, items); takes ownership of nothing, allocates d_cells / d_occ
-int finalize_level(const HipApi* H, const DeviceModule& M, DevMem& mem, const void* d_start, const void* d_items, long long ncell,
-                   void** d_cells, void** d_occ, int32_t* occ_words, unsigned long long stats_out[2])
+int finalize_level(const HipApi* H, const DeviceModule& M, DevMem& mem, const void* d_start, const void* d_items, int ct,
+                   void** d_cells, void** d_occ, int32_t* occ_words, int32_t* occ_shift, int32_t* occ_cd, unsigned long long stats_out[2])
 {
-    *occ_words = (int32_t)((ncell + 31) / 32);
+    long long ncell = (long long)ct * ct * ct;
+    occ_layout(ct, *occ_shift, *occ_cd, *occ_words);
     const size_t occ_bytes = (size_t)((*occ_words + 3) / 4) * 16;
     int rc = mem.alloc(d_cells, (size_t)ncell * sizeof(CellRec), false);
     if (rc) return rc;
@@ -96,7 +97,7 @@ int finalize_level(const HipApi* H, const DeviceModule& M, DevMem& mem, const vo
     void* d_stats = nullptr;
     rc = mem.alloc(&d_stats, 16, true);
     if (rc) return rc;
-    void* args[] = {(void*)&d_start, (void*)&d_items, d_cells, d_occ, &ncell, &d_stats};
+    void* args[] = {(void*)&d_start, (void*)&d_items, d_cells, d_occ, &ncell, &d_stats, &ct, occ_shift, occ_cd};
     rc = launch(H, M.vb_finalize, (unsigned)((ncell + 255) / 256), 256, 0, nullptr, args);
     if (rc) return rc;
     HIP_TRY(H->Memcpy(stats_out, d_stats, 16, hipMemcpyDeviceToHost));
@@ -125,7 +126,7 @@ int gpu_build_voxel_fixed(Scene& s, const HipApi* H, int32_t domain, bool* used)
     g.items.resize(NT);
     std::vector<void*> cells(NT, nullptr), items(NT, nullptr), occ(NT, nullptr);
     DevMem mem(H);
-    int32_t occ_words = 0;
+    int32_t occ_words = 0, occ_shift = 0, occ_cd = 0;
     for (size_t m = 0; m < NT; ++m) {
         BuildArgs b;
         fill_args(b, s, m, g);
@@ -191,7 +192,7 @@ int gpu_build_voxel_fixed(Scene& s, const HipApi* H, int32_t domain, bool* used)
             if (big[1] > 0) return HARE_OK;   // a voxel with > 8192 polygons: leave it to the host builder
         }
         unsigned long long stats[2];
-        rc = finalize_level(H, M, mem, d_start, d_items, ncell, &cells[m], &occ[m], &occ_words, stats);
+        rc = finalize_level(H, M, mem, d_start, d_items, g.ct, &cells[m], &occ[m], &occ_words, &occ_shift, &occ_cd, stats);
         if (rc) return rc;
         items[m] = d_items;
         // mirror the lists on the host (introspection / parity tests)
@@ -213,6 +214,8 @@ int gpu_build_voxel_fixed(Scene& s, const HipApi* H, int32_t domain, bool* used)
         replace_buffer(H, s.d_occ, m, occ[m]);
     }
     s.occ_words = occ_words;
+    s.occ_shift = occ_shift;
+    s.occ_cd = occ_cd;
     g.built = true;
     g.on_device = true;
     s.vox = std::move(g);
@@ -243,7 +246,7 @@ int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int3
         HIP_TRY(H->Memcpy(pstart[m], st, 8, hipMemcpyHostToDevice));
         HIP_TRY(H->Memcpy(pitems[m], iota.data(), iota.size() * 4, hipMemcpyHostToDevice));
     }
-    int32_t ct = 1, occ_words = 0;
+    int32_t ct = 1, occ_words = 0, occ_shift = 0, occ_cd = 0;
     std::vector<uint32_t> totals(NT, 0);
     for (int32_t k = 0; k < max_domain; ++k) {
         const int32_t nct = 2 * ct;
@@ -278,7 +281,7 @@ int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int3
             }
             unsigned long long stats[2];
             void *d_cells, *d_occ;
-            rc = finalize_level(H, M, mem, d_start, d_items, ncell, &d_cells, &d_occ, &occ_words, stats);
+            rc = finalize_level(H, M, mem, d_start, d_items, nct, &d_cells, &d_occ, &occ_words, &occ_shift, &occ_cd, stats);
             if (rc) return rc;
             sum += (double)stats[0];
             cnt += (long long)stats[1];
@@ -319,6 +322,8 @@ int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int3
         replace_buffer(H, s.d_occ, m, occ[m]);
     }
     s.occ_words = occ_words;
+    s.occ_shift = occ_shift;
+    s.occ_cd = occ_cd;
     g.built = true;
     g.on_device = true;
     s.vox = std::move(g);

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256) void hare_ob_fill(BuildArgs b, const OctTask* 
 
 // cell records (start, count, first two entries inlined) + occupancy bitmap (zeroed beforehand)
 __global__ __launch_bounds__(256) void hare_vb_finalize(const uint32_t* start, const int32_t* items, CellRec* cells,
-                                                        uint32_t* occ, long long ncell, unsigned long long* stats)
+                                                        uint32_t* occ, long long ncell, unsigned long long* stats,
+                                                        int ct, int occ_shift, int occ_cd)
 {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n = 0;
@@ -343,7 +344,11 @@ __global__ __launch_bounds__(256) void hare_vb_finalize(const uint32_t* start, c
         r.i0 = n > 0 ? items[s] : -1;
         r.i1 = n > 1 ? items[s + 1] : -1;
         cells[c] = r;
-        if (n) atomicOr(&occ[c >> 5], 1u << (c & 31));
+        if (n) {   // one bit per block of (2^occ_shift)^3 voxels (scene.h: occ_layout)
+            const int z = (int)(c % ct), y = (int)((c / ct) % ct), x = (int)(c / ((long long)ct * ct));
+            const uint32_t b = (uint32_t)(((x >> occ_shift) * occ_cd + (y >> occ_shift)) * occ_cd + (z >> occ_shift));
+            atomicOr(&occ[b >> 5], 1u << (b & 31));
+        }
     }
     // stats[0] += sum of counts over non-empty voxels, stats[1] += number of non-empty voxels (Voxel_Grid.cs:249-252)
     const unsigned long long ne = __ballot(n > 0);

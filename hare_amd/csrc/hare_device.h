@@ -39,11 +39,12 @@ struct VoxelArgs {
     const QuadRec* quads;      // null when the topology is all triangles
     const CellRec* cells;      // ct^3, cell = (x*ct + y)*ct + z
     const int32_t* items;
-    const uint32_t* occ;       // ct^3 bits: cell non-empty
+    const uint32_t* occ;       // occupancy bitmap, staged in LDS by the persistent kernel (<= 64 KB): one bit per
+                               // block of (2^occ_shift)^3 voxels, occ_cd blocks per axis; shift 0 = one bit per voxel
     int32_t ct;
     int32_t occ_words;
-    int32_t occ_in_lds;        // persistent kernel: stage `occ` in LDS (it fits)
-    int32_t pad;
+    int32_t occ_shift;
+    int32_t occ_cd;
     double omin[3], omax[3];   // OBox
     double vd[3];              // VoxelDims
 };

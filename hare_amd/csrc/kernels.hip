@@ -233,13 +233,13 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 //       FP64 test -- the reference's RayXtri, the only thing that decides a hit.
 // Lanes that finish are refilled from a chunk of rays the wave drew with one atomic ticket
 // (ballot + popcount compaction of the idle lanes), so waves stay full until the batch drains.
-// The cell-occupancy bitmap (1 bit per voxel) is staged in LDS once per workgroup, so the ~90 % of
+// The cell-occupancy bitmap (1 bit per voxel; per 2x2x2 .. 16x16x16 block above ~80^3) is staged in LDS once per workgroup, so the ~90 % of
 // DDA steps that cross empty voxels never leave the CU.  Each polygon is one 128-byte line; the
 // cull reads its first 64 bytes, the exact test the rest, both requested one phase before use.
 //
 // Per ray, the sequence of EXACT tests is the reference's candidate sequence with some certain
 // misses removed; accepted hits, their order and their arithmetic are unchanged (Voxel_Grid.cs:561-761).
-template <bool QUADS, bool OCC_LDS, bool PROF = false>
+template <bool QUADS, bool COARSE, bool PROF = false>
 __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
 {
     // PROF: developer build with s_memtime stamps per phase (never the timed kernel)
@@ -255,7 +255,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     if (PROF) tstamp = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);   // address space known: ds_read, not flat
-    if (OCC_LDS) {
+    {
         const int nw4 = (g.occ_words + 3) >> 2;           // the device buffer is padded to 16 bytes
         const uint4* src = reinterpret_cast<const uint4*>(g.occ);
         uint4* dst = reinterpret_cast<uint4*>(locc);
@@ -338,8 +338,11 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     };
     // the voxel just entered: occupancy bit from LDS; only a non-empty voxel touches memory
     auto enter_cell = [&]() {
-        const uint32_t word = OCC_LDS ? locc[cell >> 5] : g.occ[cell >> 5];
-        if ((word >> (cell & 31)) & 1u) {
+        // COARSE (grids above ~80^3): the bit covers a block of voxels; the cell record says whether THIS one is empty
+        const uint32_t bit = COARSE ? (uint32_t)(((X >> g.occ_shift) * g.occ_cd + (Y >> g.occ_shift)) * g.occ_cd + (Z >> g.occ_shift))
+                                    : (uint32_t)cell;
+        const uint32_t word = locc[bit >> 5];
+        if ((word >> (bit & 31)) & 1u) {
             const CellRec c = g.cells[cell];
             q = c.start;
             qe = c.start + c.count;
@@ -1163,15 +1166,15 @@ __global__ __launch_bounds__(256) void hare_voxel_shoot_count(VoxelArgs g, Shoot
     voxel_shoot_body<true, true>(g, io);
 }
 
-// K1p: persistent Voxel_Grid.Shoot (default voxel kernel); dynamic LDS = occupancy bitmap when it fits
-__global__ __launch_bounds__(256) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
-// same with the occupancy bitmap left in global memory (grids whose bitmap exceeds 64 KB of LDS)
-__global__ __launch_bounds__(256) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false>(g, io); }
+// K1p: persistent Voxel_Grid.Shoot (default voxel kernel); dynamic LDS = the occupancy bitmap, one bit per voxel
+__global__ __launch_bounds__(256) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false>(g, io); }
+// same for grids above ~80^3, whose bitmap has one bit per block of 2^k voxels per axis so that it still fits 64 KB of LDS
+__global__ __launch_bounds__(256) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
 
 // developer profiling build of the persistent kernel (phase stamps into ShootIO::prof)
-__global__ __launch_bounds__(256) void hare_voxel_persist_prof(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true, true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_persist_prof(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false, true>(g, io); }
 
 // tests only: FP32-cull audit against the exact test, all polygons x all rays
 __global__ __launch_bounds__(256) void hare_cull_audit(VoxelArgs g, ShootIO io) { audit_body(g, io); }

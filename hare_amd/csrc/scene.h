@@ -12,6 +12,19 @@
 
 namespace hare {
 
+// Occupancy bitmap layout for a grid of ct^3 voxels: the finest power-of-two block size whose bitmap fits the
+// 64 KB the persistent kernel stages in LDS.  shift 0 = one bit per voxel (ct <= 80); a coarser bit means "some
+// voxel of this block is non-empty" and the kernel then reads the voxel's cell record to find out which.
+inline void occ_layout(int ct, int32_t& shift, int32_t& cd, int32_t& words)
+{
+    for (shift = 0;; ++shift) {
+        cd = (ct + (1 << shift) - 1) >> shift;
+        const long long bits = (long long)cd * cd * cd;
+        words = (int32_t)((bits + 31) / 32);
+        if ((long long)((words + 3) / 4) * 16 <= 64 * 1024) return;
+    }
+}
+
 constexpr unsigned kPartSlots = 8;        // ring of launches whose counter partials may be in flight
 constexpr unsigned kPartWaves = 8192;     // >= waves of one persistent launch (CUs x 4 workgroups x 4 waves)
 
@@ -78,7 +91,8 @@ struct Scene {
     std::vector<void*> d_polys;                  // per topo: PolyRec[P]
     std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
-    int32_t occ_words = 0;
+    int32_t occ_words = 0;                       // words of the occupancy bitmap the persistent kernel stages in LDS
+    int32_t occ_shift = 0, occ_cd = 0;           // bitmap resolution: one bit per (2^occ_shift)^3 voxels, occ_cd blocks per axis
     void* d_oct_nodes = nullptr;
     void* d_oct_items = nullptr;
     void* d_kd_nodes = nullptr;

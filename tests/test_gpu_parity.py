@@ -45,7 +45,7 @@ def test_voxel_full_size_c2_1M_rays_100k_tris(hall):
     assert not ev["u"].any() and not ev["v"].any()
 
 
-@pytest.mark.parametrize("domain", [1, 7, 32, 128])
+@pytest.mark.parametrize("domain", [1, 7, 32, 80, 81, 128, 200])   # <= 80: one occupancy bit per voxel; 81..160: per 2^3 block; 200: per 4^3
 def test_voxel_domains(hall, domain):
     m, T, To = hall
     rays = H.scenes.burst_rays(200_000, m.size)
