@@ -25,12 +25,24 @@ namespace Hare
             /// exact signatures, so the device is not a constructor argument).</summary>
             public static int Device = 0;
 
-            protected IntPtr scene = IntPtr.Zero;
+            /// <summary>Optional: several device ordinals of one node.  A partition constructed while this is set keeps a
+            /// replica on each of them and the batch Shoot overloads split their rays over the replicas in contiguous
+            /// shards (hare_shoot_batch_sharded): the in-process way to use all GPUs of a node.</summary>
+            public static int[] Devices = null;
+
+            protected IntPtr scene = IntPtr.Zero;                 // replica 0 (== scenes[0])
+            protected IntPtr[] scenes = new IntPtr[0];            // all replicas, in shard order
             protected abstract int Kind { get; }
+
+            /// <summary>Run a build call on every replica.</summary>
+            protected void BuildAll(Func<IntPtr, int> build)
+            {
+                foreach (IntPtr s in scenes) HareHip.Check(build(s));
+            }
 
             protected Gpu_Spatial_Partition(Topology[] Model_in)
             {
-                int device = Device;
+                int[] devices = (Devices != null && Devices.Length > 0) ? (int[])Devices.Clone() : new int[] { Device };
                 Model = Model_in;
                 var descs = new hare_topology_desc[Model.Length];
                 var pins = new GCHandle[Model.Length * 3];
@@ -69,7 +81,10 @@ namespace Hare
                         descs[m].min0 = T.Min.x; descs[m].min1 = T.Min.y; descs[m].min2 = T.Min.z;
                         descs[m].max0 = T.Max.x; descs[m].max1 = T.Max.y; descs[m].max2 = T.Max.z;
                     }
-                    HareHip.Check(HareHip.hare_scene_create(descs, descs.Length, device, out scene));   // copies everything
+                    scenes = new IntPtr[devices.Length];
+                    for (int k = 0; k < devices.Length; k++)
+                        HareHip.Check(HareHip.hare_scene_create(descs, descs.Length, devices[k], out scenes[k]));   // copies everything
+                    scene = scenes[0];
                 }
                 finally
                 {
@@ -94,8 +109,8 @@ namespace Hare
                 }
                 var ev = new hare_xevent[n];
                 hare_counters ctr;
-                HareHip.Check(HareHip.hare_shoot_batch(scene, Kind, top_index, n, r, poly_origin1, poly_origin2,
-                                                       HareHip.HARE_SHOOT_WRITEBACK_ORIGIN, ev, out ctr));
+                HareHip.Check(HareHip.hare_shoot_batch_sharded(scenes, scenes.Length, Kind, top_index, n, r, poly_origin1, poly_origin2,
+                                                               HareHip.HARE_SHOOT_WRITEBACK_ORIGIN, ev, out ctr));
                 for (int i = 0; i < n; i++)
                 {
                     rays[i].x = r[i].x; rays[i].y = r[i].y; rays[i].z = r[i].z;       // F11: the reference mutates R
@@ -110,8 +125,8 @@ namespace Hare
             public int Shoot(hare_ray[] rays, int top_index, hare_xevent[] results, int[] poly_origin1 = null, int[] poly_origin2 = null, bool moveOrigins = false)
             {
                 hare_counters ctr;
-                HareHip.Check(HareHip.hare_shoot_batch(scene, Kind, top_index, rays.Length, rays, poly_origin1, poly_origin2,
-                                                       moveOrigins ? HareHip.HARE_SHOOT_WRITEBACK_ORIGIN : 0u, results, out ctr));
+                HareHip.Check(HareHip.hare_shoot_batch_sharded(scenes, scenes.Length, Kind, top_index, rays.Length, rays, poly_origin1, poly_origin2,
+                                                               moveOrigins ? HareHip.HARE_SHOOT_WRITEBACK_ORIGIN : 0u, results, out ctr));
                 return (int)ctr.hits;
             }
 
@@ -129,8 +144,8 @@ namespace Hare
                 fixed (hare_xevent* e = results)
                 fixed (int* e1 = poly_origin1)      // an empty span pins to null == "no exclusions"
                 fixed (int* e2 = poly_origin2)
-                    HareHip.Check(HareHip.hare_shoot_batch(scene, Kind, top_index, rays.Length, r, e1, e2,
-                                                           moveOrigins ? HareHip.HARE_SHOOT_WRITEBACK_ORIGIN : 0u, e, &ctr));
+                    HareHip.Check(HareHip.hare_shoot_batch_sharded(scenes, scenes.Length, Kind, top_index, rays.Length, r, e1, e2,
+                                                                   moveOrigins ? HareHip.HARE_SHOOT_WRITEBACK_ORIGIN : 0u, e, &ctr));
                 return (int)ctr.hits;
             }
 #endif
@@ -148,13 +163,20 @@ namespace Hare
                 return Ret_event.Hit;
             }
 
+            void Release()
+            {
+                for (int k = 0; k < scenes.Length; k++)
+                    if (scenes[k] != IntPtr.Zero) { HareHip.hare_scene_destroy(scenes[k]); scenes[k] = IntPtr.Zero; }
+                scene = IntPtr.Zero;
+            }
+
             public void Dispose()
             {
-                if (scene != IntPtr.Zero) { HareHip.hare_scene_destroy(scene); scene = IntPtr.Zero; }
+                Release();
                 GC.SuppressFinalize(this);
             }
 
-            ~Gpu_Spatial_Partition() { if (scene != IntPtr.Zero) HareHip.hare_scene_destroy(scene); }
+            ~Gpu_Spatial_Partition() { Release(); }
         }
 
         /// <summary>Voxel_Grid on the GPU (Voxel_Grid.cs).</summary>
@@ -166,14 +188,14 @@ namespace Hare
             /// <summary>Voxel_Grid(Topology[] Model_in, int Domain) -- Voxel_Grid.cs:48</summary>
             public Gpu_Voxel_Grid(Topology[] Model_in, int Domain) : base(Model_in)
             {
-                HareHip.Check(HareHip.hare_voxel_build(scene, Domain));
+                BuildAll(sc => HareHip.hare_voxel_build(sc, Domain));
                 Refresh();
             }
 
             /// <summary>Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys) -- Voxel_Grid.cs:128</summary>
             public Gpu_Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys) : base(Model_in)
             {
-                HareHip.Check(HareHip.hare_voxel_build_adaptive(scene, MaxDomain, Avg_polys));
+                BuildAll(sc => HareHip.hare_voxel_build_adaptive(sc, MaxDomain, Avg_polys));
                 Refresh();
             }
 
@@ -204,7 +226,7 @@ namespace Hare
             protected override int Kind { get { return HareHip.HARE_KIND_OCTREE; } }
             public Gpu_Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) : base(Model_In)
             {
-                HareHip.Check(HareHip.hare_octree_build(scene, maxDepth, maxPolygonsPerNode));
+                BuildAll(sc => HareHip.hare_octree_build(sc, maxDepth, maxPolygonsPerNode));
             }
         }
 
@@ -214,7 +236,7 @@ namespace Hare
             protected override int Kind { get { return HareHip.HARE_KIND_KDTREE; } }
             public Gpu_KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) : base(Model_In)
             {
-                HareHip.Check(HareHip.hare_kdtree_build(scene, maxDepth, maxPolygonsPerNode));
+                BuildAll(sc => HareHip.hare_kdtree_build(sc, maxDepth, maxPolygonsPerNode));
             }
         }
     }

@@ -81,6 +81,15 @@ namespace Hare
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern unsafe int hare_shoot_batch(IntPtr scene, int kind, int top_index, long n, hare_ray* rays,
                                                              int* excl1, int* excl2, uint flags, hare_xevent* ev, hare_counters* ctr);
+            /// <summary>One batch over several scenes (one per device), contiguous shards (include/hare_hip.h).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_shoot_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
+                                                              [In, Out] hare_ray[] rays, int[] excl1, int[] excl2, uint flags,
+                                                              [Out] hare_xevent[] ev, out hare_counters ctr);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern unsafe int hare_shoot_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
+                                                                     hare_ray* rays, int* excl1, int* excl2, uint flags,
+                                                                     hare_xevent* ev, hare_counters* ctr);
             /// <summary>Topology(Point[][]) ingest for hosts holding a raw polygon soup (include/hare_hip.h).</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_topology_ingest([In] double[] soup, [In] int[] nverts, int P, [Out] double[] verts_out,

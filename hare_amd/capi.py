@@ -79,6 +79,7 @@ SYMBOLS = {
     "hare_kdtree_get_info": (C.c_int, [_vp, _vp]),
     "hare_kdtree_get_nodes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hare_shoot_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "hare_shoot_batch_sharded": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
     "hare_shoot_device": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "hare_reflect_device": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
 }

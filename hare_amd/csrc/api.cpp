@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hare_hip.h"
@@ -961,6 +962,57 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
         HIP_TRY(H->MemcpyAsync(rays, s->d_rays, (size_t)n * sizeof(hare_ray), hipMemcpyDeviceToHost, st));
     if (ctr) HIP_TRY(H->MemcpyAsync(ctr, s->d_ctr, sizeof(hare_counters), hipMemcpyDeviceToHost, st));
     HIP_TRY(H->StreamSynchronize(st));
+    return HARE_OK;
+    GUARD_END
+}
+
+int hare_shoot_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n,
+                             hare_ray* rays, const int32_t* excl1, const int32_t* excl2, uint32_t flags, hare_xevent* out,
+                             hare_counters* ctr)
+{
+    if (!scenes || n_scenes < 1 || n_scenes > 64) {
+        set_error("hare_shoot_batch_sharded: need 1..64 scenes");
+        return HARE_E_INVALID;
+    }
+    for (int32_t k = 0; k < n_scenes; ++k)
+        if (!scenes[k]) {
+            set_error("hare_shoot_batch_sharded: null scene");
+            return HARE_E_INVALID;
+        }
+    if (n < 0 || (n > 0 && (!rays || !out))) {
+        set_error("hare_shoot_batch_sharded: bad arguments");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    if (ctr) memset(ctr, 0, sizeof *ctr);
+    const int G = n_scenes;
+    std::vector<int> rcs((size_t)G, HARE_OK);
+    std::vector<std::string> errs((size_t)G);
+    std::vector<hare_counters> parts((size_t)G);
+    auto shard = [&](int k) {
+        const int64_t lo = (int64_t)((__int128)n * k / G), hi = (int64_t)((__int128)n * (k + 1) / G);
+        memset(&parts[k], 0, sizeof parts[k]);
+        rcs[k] = hare_shoot_batch(scenes[k], kind, top_index, hi - lo, rays ? rays + lo : nullptr, excl1 ? excl1 + lo : nullptr,
+                                  excl2 ? excl2 + lo : nullptr, flags, out ? out + lo : nullptr, &parts[k]);
+        if (rcs[k] != HARE_OK) errs[k] = hare_last_error();     // thread-local: carry it to the caller's thread
+    };
+    std::vector<std::thread> workers;
+    for (int k = 1; k < G; ++k) workers.emplace_back(shard, k);
+    shard(0);
+    for (auto& w : workers) w.join();
+    for (int k = 0; k < G; ++k)
+        if (rcs[k] != HARE_OK) {
+            set_error("shard " + std::to_string(k) + ": " + errs[k]);
+            return rcs[k];
+        }
+    if (ctr)
+        for (int k = 0; k < G; ++k) {
+            ctr->rays += parts[k].rays;
+            ctr->hits += parts[k].hits;
+            ctr->cells += parts[k].cells;
+            ctr->entries += parts[k].entries;
+            ctr->tests += parts[k].tests;
+        }
     return HARE_OK;
     GUARD_END
 }

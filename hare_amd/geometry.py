@@ -205,6 +205,31 @@ class Spatial_Partition:
                                    ptr(out), C.addressof(ctr)))
         return out, ctr.as_dict()
 
+    @staticmethod
+    def Shoot_batch_sharded(partitions, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
+                            writeback_origin: bool = False):
+        """One batch over several devices from one process: `partitions` are equal partitions built on different
+        devices (e.g. [Voxel_Grid(model, 64, device=k) for k in range(G)]); rays are split into contiguous shards in
+        that order (hare_shoot_batch_sharded).  Returns (events, summed counters), byte-identical to Shoot_batch."""
+        parts = list(partitions)
+        if not parts or any(p._kind != parts[0]._kind for p in parts):
+            raise ValueError("need one or more partitions of the same kind")
+        if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
+            rays = np.array(rays, np.float64, order="C")
+        rays = rays.reshape(-1, 6)
+        n = rays.shape[0]
+        out = np.zeros(n, XEVENT_DTYPE)
+        e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
+        e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
+        for e in (e1, e2):
+            if e is not None and e.shape != (n,):
+                raise ValueError("poly_origin arrays must have one entry per ray")
+        handles = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        ctr = capi.Counters()
+        check(lib.hare_shoot_batch_sharded(handles, len(parts), parts[0]._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2),
+                                           capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0, ptr(out), C.addressof(ctr)))
+        return out, ctr.as_dict()
+
     def shoot_device(self, n: int, d_rays: int, d_out: int, top_index: int = 0, d_excl1: int = 0, d_excl2: int = 0,
                      d_counters: int = 0, stream: int = 0, flags: int = 0):
         """Device-resident shoot: raw device addresses (e.g. torch.Tensor.data_ptr()) + a hipStream_t."""

@@ -188,6 +188,16 @@ HARE_API int hare_shoot_batch(hare_scene *s, int32_t kind, int32_t top_index, in
                      const int32_t *excl1, const int32_t *excl2, uint32_t flags, hare_xevent *out,
                      hare_counters *ctr /* nullable */);
 
+/* The same call over several devices of one node from ONE process (hosts without torch.distributed, e.g. the
+ * .NET shim): scenes[k] is the scene on device k's ordinal of choice -- same topologies, same partition, built by
+ * the caller with hare_scene_create(..., device_k, ...) + hare_*_build -- and rays [n*k/G, n*(k+1)/G) go to it
+ * (the contiguous split of SURVEY.md 8(e); scene replicated, no exchange between devices).  One host thread per
+ * scene drives its copies and kernel; outputs land in the same slices of `out`, so the result is byte-identical
+ * to the one-device call; `ctr` is the sum over devices.  The first failing shard's code and message are returned. */
+HARE_API int hare_shoot_batch_sharded(hare_scene *const *scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n,
+                                      hare_ray *rays, const int32_t *excl1, const int32_t *excl2, uint32_t flags,
+                                      hare_xevent *out, hare_counters *ctr);
+
 /* Same with DEVICE pointers on the scene's device and a caller stream (hipStream_t as void*,
  * NULL = default stream); stream-ordered, does not synchronise.  d_counters (nullable) points to
  * a device hare_counters that the kernel ACCUMULATES into. */

@@ -327,6 +327,38 @@ def test_degenerate_rays_match_the_oracle_bit_for_bit(domain):
         bits_equal(ev, kref, "kdtree")
 
 
+def test_in_process_sharding_over_scenes_is_byte_identical(hall):
+    """hare_shoot_batch_sharded: one process, one scene per device, contiguous ray shards, one host thread each.
+    (This box has one GPU, so the scenes share device 0; the slicing, threading, error and counter paths are the
+    same.)  Output must equal the one-scene call byte for byte, for ragged splits and exclusions too."""
+    import ctypes as C
+    from hare_amd import capi
+    m, T, To = hall
+    n = 300_007                                    # not divisible by 3 or 4
+    rays = H.scenes.burst_rays(n, m.size)
+    grids = [H.Voxel_Grid([T], 32) for _ in range(4)]
+    ref, rc = grids[0].Shoot_batch(rays)
+    excl = ref["poly_id"].astype(np.int32)
+    ref2, rc2 = grids[0].Shoot_batch(rays, poly_origin1=excl)
+    for G in (1, 3, 4):
+        ev, c = H.Spatial_Partition.Shoot_batch_sharded(grids[:G], rays)
+        assert ev.tobytes() == ref.tobytes(), G
+        assert c["hits"] == rc["hits"] and c["rays"] == n
+        ev2, c2 = H.Spatial_Partition.Shoot_batch_sharded(grids[:G], rays, poly_origin1=excl)
+        assert ev2.tobytes() == ref2.tobytes() and c2["hits"] == rc2["hits"], G
+    # fewer rays than scenes, and none at all
+    ev, c = H.Spatial_Partition.Shoot_batch_sharded(grids, rays[:2])
+    assert ev.tobytes() == ref[:2].tobytes() and c["rays"] == 2
+    ev, c = H.Spatial_Partition.Shoot_batch_sharded(grids, rays[:0])
+    assert len(ev) == 0 and c["rays"] == 0
+    # a failing shard reports its index: an octree that was never built on one of the handles
+    bad = (C.c_void_p * 2)(grids[0]._h, grids[1]._h)
+    out = np.zeros(4, capi.XEVENT_DTYPE)
+    r4 = np.ascontiguousarray(rays[:4])
+    assert capi.lib.hare_shoot_batch_sharded(bad, 2, capi.KIND_OCTREE, 0, 4, r4.ctypes.data, None, None, 0, out.ctypes.data, None) == capi.HARE_E_STATE
+    assert capi.last_error().startswith("shard 0:")
+
+
 def test_gpu_octree_builder_equals_host_builder(monkeypatch):
     """Octree.BuildOctree with the PolyBoxOverlap tests on the GPU (build_gpu.cpp: gpu_build_octree) returns
     the very arrays the host builder does (which tests/test_host_builders.py pins to the oracle): boxes,
