@@ -25,7 +25,7 @@ inline void occ_layout(int ct, int32_t& shift, int32_t& cd, int32_t& words)
     }
 }
 
-constexpr unsigned kPartSlots = 8;        // ring of launches whose counter partials may be in flight
+constexpr unsigned kPartSlots = 64;       // ring of launches whose counter partials may be in flight (same depth as the ticket ring)
 constexpr unsigned kPartWaves = 8192;     // >= waves of one persistent launch (CUs x 4 workgroups x 4 waves)
 
 struct Topo {

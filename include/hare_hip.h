@@ -200,7 +200,9 @@ HARE_API int hare_shoot_batch_sharded(hare_scene *const *scenes, int32_t n_scene
 
 /* Same with DEVICE pointers on the scene's device and a caller stream (hipStream_t as void*,
  * NULL = default stream); stream-ordered, does not synchronise.  d_counters (nullable) points to
- * a device hare_counters that the kernel ACCUMULATES into. */
+ * a device hare_counters that the kernel ACCUMULATES into.  Calls may be issued from several host
+ * threads and on several streams; the scene keeps per-launch scratch (work tickets, counter partials) in a
+ * ring of 64 launches, so at most 64 launches of one scene may be in flight at a time. */
 HARE_API int hare_shoot_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
                       const void *d_excl1, const void *d_excl2, uint32_t flags, void *d_out,
                       void *d_counters, void *stream);
