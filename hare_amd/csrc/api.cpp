@@ -264,7 +264,7 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
 
 // Batch counters of a persistent launch: the waves store {rays, hits} partials (io.part), one small
 // kernel adds them to the caller's counters afterwards.
-int prepare_partials(Scene& s, const DeviceModule& M, ShootIO& io, unsigned& pgrid)
+int prepare_partials(Scene& s, const DeviceModule& M, ShootIO& io, unsigned& pgrid, unsigned slot)
 {
     io.part = nullptr;
     if (!io.ctr) return HARE_OK;
@@ -273,8 +273,7 @@ int prepare_partials(Scene& s, const DeviceModule& M, ShootIO& io, unsigned& pgr
         return HARE_E_STATE;
     }
     pgrid = std::min(pgrid, kPartWaves / 4u);
-    const unsigned slot = s.work_slot.load() % kPartSlots;
-    io.part = (unsigned long long*)s.d_part + (size_t)slot * kPartWaves * 2;
+    io.part = (unsigned long long*)s.d_part + (size_t)(slot % kPartSlots) * kPartWaves * 2;
     return HARE_OK;
 }
 
@@ -385,12 +384,12 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         unsigned pgrid = (unsigned)std::max(1, M.cu_count) * std::max(1u, per_cu);
         pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
         if (pgrid == 0) pgrid = 1;
-        if (int rc = prepare_partials(s, M, io, pgrid)) return rc;
+        const unsigned slot = s.work_slot.fetch_add(1) % 64u;       // this launch's scratch: ticket word + counter partials
+        if (int rc = prepare_partials(s, M, io, pgrid, slot)) return rc;
         // ticket size: measured optimum on MI355X (tools/sweep_ticket.py) -- 32 rays up to ~1.5M rays, where the
         // end of the batch dominates, growing to 128 where the ~11 ns/ticket atomic rate would start to bind
         io.ticket_rays = n < 1572864 ? 32 : (n < 6291456 ? 64 : (n < 12582912 ? 96 : 128));
         if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
-        const unsigned slot = s.work_slot.fetch_add(1) % 64u;
         io.work = (unsigned int*)s.d_work + slot;
         HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
         void* args[] = {&g, &io};
@@ -432,10 +431,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
-            if (int rc = prepare_partials(s, M, io, pgrid)) return rc;
+            const unsigned slot = s.work_slot.fetch_add(1) % 64u;
+            if (int rc = prepare_partials(s, M, io, pgrid, slot)) return rc;
             io.ticket_rays = 32;                  // an octree ray costs ~10x a voxel ray: ticket atomics never bind
             if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
-            const unsigned slot = s.work_slot.fetch_add(1) % 64u;
             io.work = (unsigned int*)s.d_work + slot;
             HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
             void* pargs[] = {&g, &io};
