@@ -187,19 +187,22 @@ HARE_HD bool poly_full(const PolyRec& p, const double* v3, const V3& o, const V3
 HARE_HD bool cull_fp32(float tvx, float tvy, float tvz, float dx, float dy, float dz, float dm /*|d|_1*/,
                        const float* e1, const float* e2, float ee, float emax)
 {
+    // Explicit fused multiply-adds (the build contracts nothing by itself): this is the filter, not the
+    // reference arithmetic -- a fused term has one rounding instead of two, so the bound above still holds.
     const float G = 3.814697265625e-06f;   // 2^-18
-    const float px = dy * e2[2] - dz * e2[1];
-    const float py = dz * e2[0] - dx * e2[2];
-    const float pz = dx * e2[1] - dy * e2[0];
-    const float det = e1[0] * px + e1[1] * py + e1[2] * pz;
-    const float u = tvx * px + tvy * py + tvz * pz;
-    const float qx = tvy * e1[2] - tvz * e1[1];
-    const float qy = tvz * e1[0] - tvx * e1[2];
-    const float qz = tvx * e1[1] - tvy * e1[0];
-    const float v = dx * qx + dy * qy + dz * qz;
+    const float px = __builtin_fmaf(dy, e2[2], -(dz * e2[1]));
+    const float py = __builtin_fmaf(dz, e2[0], -(dx * e2[2]));
+    const float pz = __builtin_fmaf(dx, e2[1], -(dy * e2[0]));
+    const float det = __builtin_fmaf(e1[0], px, __builtin_fmaf(e1[1], py, e1[2] * pz));
+    const float u = __builtin_fmaf(tvx, px, __builtin_fmaf(tvy, py, tvz * pz));
+    const float qx = __builtin_fmaf(tvy, e1[2], -(tvz * e1[1]));
+    const float qy = __builtin_fmaf(tvz, e1[0], -(tvx * e1[2]));
+    const float qz = __builtin_fmaf(tvx, e1[1], -(tvy * e1[0]));
+    const float v = __builtin_fmaf(dx, qx, __builtin_fmaf(dy, qy, dz * qz));
     const float tvm = fabsf(tvx) + fabsf(tvy) + fabsf(tvz);
-    const float muv = G * tvm * dm * emax + 1e-30f;
-    const float md = G * dm * ee + 1e-30f;
+    const float gd = G * dm;
+    const float muv = __builtin_fmaf(gd * tvm, emax, 1e-30f);
+    const float md = __builtin_fmaf(gd, ee, 1e-30f);
     const float adet = fabsf(det);
     const float su = det < 0.0f ? -u : u;
     const float sv = det < 0.0f ? -v : v;
