@@ -2,7 +2,8 @@
 //
 // Built with: hipcc --offload-arch=gfx950 --genco -O3 -ffp-contract=off
 // (contraction OFF is a correctness requirement: the reference is .NET FP64, which never fuses
-//  a*b+c; X_Event parity on near-ties depends on it -- SURVEY.md F5.)
+//  a*b+c; X_Event parity on near-ties depends on it -- SURVEY.md F5.  The one place that fuses, explicitly,
+//  is the conservative FP32 pre-cull, which is a filter and not reference arithmetic.)
 //
 // Kernels (one ray per lane everywhere):
 //   hare_voxel_persist_*   K1p  production Voxel_Grid.Shoot: persistent waves, per-lane state machine,
@@ -11,8 +12,9 @@
 //   hare_octree_persist    K2p  production Octree.Shoot; hare_octree_shoot* K2 simple/counting form
 //   hare_kdtree_shoot*          KDTree.Shoot (visits every leaf, like the reference)
 //   hare_reflect           K3   specular bounce between casts (harness-defined)
+//   hare_ctr_reduce             sums the persistent kernels' per-wave {rays, hits} partials into the batch counters
 //   hare_cull_audit             tests only: FP32 cull vs exact test on every ray x polygon pair
-//   hare_vb_*, hare_scan_*      Voxel_Grid construction (build_kernels.hip, included at the end)
+//   hare_vb_*, hare_scan_*, hare_ob_*  Voxel_Grid / Octree construction (build_kernels.hip, included at the end)
 //
 // The arithmetic is a restatement of
 //   Voxel_Grid.Shoot           Voxel_Grid.cs:561-761 (+ :351-552, the poly_origin overload)
@@ -574,7 +576,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     }
 
     timeline(2);
-    // batch counters: one atomic pair per wave
+    // batch counters: per-wave partials, summed by hare_ctr_reduce
     if (io.ctr) {
         const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
         if (lane == 0) {
