@@ -45,6 +45,18 @@ def test_voxel_full_size_c2_1M_rays_100k_tris(hall):
     assert not ev["u"].any() and not ev["v"].any()
 
 
+@pytest.mark.parametrize("n", [7_000_003, 1 << 24])
+def test_voxel_large_batches_7M_and_16M_rays(hall, n):
+    """One launch of 7M / 16.7M rays (BASELINE's largest single-GPU batch): the 96- and 128-ray ticket sizes the host
+    picks for big batches, the static first chunks and the 32-bit ray indexing, every X_Event against the oracle."""
+    m, T, To = hall
+    rays = H.scenes.burst_rays(n, m.size)
+    ev, c = H.Voxel_Grid([T], 64).Shoot_batch(rays)
+    ref, rc = po.VoxelGrid([To], domain=64).shoot(rays, nthreads=16)
+    assert_events_equal(ev, ref, what=f"voxel D=64, {n} rays in one launch")
+    assert c["rays"] == n and c["hits"] == rc["hits"] == n
+
+
 @pytest.mark.parametrize("domain", [1, 7, 32, 80, 81, 128, 200])   # <= 80: one occupancy bit per voxel; 81..160: per 2^3 block; 200: per 4^3
 def test_voxel_domains(hall, domain):
     m, T, To = hall
