@@ -11,9 +11,9 @@ dr = torch.from_numpy(rays).cuda(); out = torch.empty(N * 56, dtype=torch.uint8,
 W = 4096
 buf = torch.zeros(8 + 32 + 4 * W, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for cfg in sys.argv[1:] or ["tickets"]:
-    if cfg == "tickets": os.environ.pop("HARE_BUDGET", None)
-    else: os.environ["HARE_BUDGET"] = cfg
+for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET values to compare
+    if cfg == "default": os.environ.pop("HARE_TICKET", None)
+    else: os.environ["HARE_TICKET"] = cfg
     for rep in range(2):
         buf.zero_()
         g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x2000)
