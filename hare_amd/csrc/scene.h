@@ -104,6 +104,7 @@ struct Scene {
     // staging for hare_shoot_batch (guarded by mu)
     std::mutex mu;
     hipStream_t stream = nullptr;
+    hipStream_t extra_streams[2] = {nullptr, nullptr};   // hare_shoot_batch pipelines a large batch as up to 3 chunks
     void* d_rays = nullptr;
     void* d_e1 = nullptr;
     void* d_e2 = nullptr;
