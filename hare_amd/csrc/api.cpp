@@ -312,10 +312,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.work = (unsigned int*)s.d_work;
     io.n = n;
     io.flags = flags & 0x3FFFu;
-    io.steps_per_round = 3;
+    io.steps_per_round = 10;
     io.refill_min_idle = 16;
     io.ray_chunk = 128;
-    io.exact_min_parked = 12;
+    io.exact_min_parked = 8;
     io.audit_polys = s.topos[top].P;
     unsigned tune_blocks_per_cu = 0;
     if (getenv("HARE_TUNE")) {   // developer sweeps (tools/sweep.py, tools/phase_prof.py): steps,refill,chunk,blocks_per_cu,exact;

@@ -241,7 +241,11 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 //
 // Per ray, the sequence of EXACT tests is the reference's candidate sequence with some certain
 // misses removed; accepted hits, their order and their arithmetic are unchanged (Voxel_Grid.cs:561-761).
-template <bool QUADS, bool COARSE, bool PROF = false>
+#ifndef HARE_K1P_STEPS
+#define HARE_K1P_STEPS 10
+#define HARE_K1P_CULLS 4
+#endif
+template <bool QUADS, bool COARSE, bool PROF = false, int STEPS = HARE_K1P_STEPS, int CULLS = HARE_K1P_CULLS>
 __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
 {
     // PROF: developer build with s_memtime stamps per phase (never the timed kernel)
@@ -279,11 +283,16 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     timeline(0);
     // scheduling knobs: compile-time in the production kernels (fewer live SGPRs), run-time in the
     // developer profiling build so that sweeps need no rebuild
-    // tuned on MI355X at 1M and 16M rays (tools/ab_libs.py): steps 3 / refill 16 / exact 12
-    const int STEPS_PER_ROUND = PROF ? io.steps_per_round : 3;
-    const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : 16;
+    // tuned on MI355X at 1M and 16M rays (tools/ab_libs.py).  Steps and culls per round must grow TOGETHER: (8..12, 4) beat
+    // (3, 1) by 6 % at 1M rays, while (8, 1), (3, 4), (8, 8) or (16, 8) all lose to it; the refill / exact thresholds are flat.
+#ifndef HARE_K1P_REFILL
+#define HARE_K1P_REFILL 16
+#define HARE_K1P_EXACT 8
+#endif
+    const int STEPS_PER_ROUND = PROF ? io.steps_per_round : STEPS;
+    const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : HARE_K1P_REFILL;
     const int RAY_CHUNK = PROF ? io.ray_chunk : 128;
-    const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : 12;
+    const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : HARE_K1P_EXACT;
 
     // wave-uniform work chunk [cn, ce).  The first chunk of every wave is static (wave w owns rays
     // [w*RAY_CHUNK, (w+1)*RAY_CHUNK)); tickets hand out the rays after those.  Same-address atomics
@@ -498,7 +507,10 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
         stamp(2);
         // ------------------------------------------------------------------ phase B1: FP32 cull
         if (PROF) { const unsigned long long m = __ballot(alive && !parked && q < qe); if (m) { pf[8]++; pf[9] += __popcll(m); } }
-        if (alive && !parked && q < qe) {
+#pragma unroll 1
+        for (int kc = 0; kc < CULLS; ++kc) {
+          if (CULLS > 1 && kc > 0 && __ballot(alive && !parked && q < qe) == 0) break;
+          if (alive && !parked && q < qe) {
             if (skip(idx)) {                                                // Voxel_Grid.cs:477 (+ mailbox)
                 next_candidate();
             } else {
@@ -519,6 +531,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     parked = true;
                 }
             }
+          }
         }
 
         stamp(3);
