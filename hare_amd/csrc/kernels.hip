@@ -834,7 +834,13 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     const int lane = tid & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     // tuned on C3 (tools/sweep_oct.py): parking survivors does not pay here, several culls per round do
-    const int STEPS = 4, CULLS = 8, REFILL_MIN_IDLE = 8, RAY_CHUNK = 128, EXACT_MIN_PARKED = 1;
+#ifndef HARE_K2P_STEPS
+#define HARE_K2P_STEPS 4
+#define HARE_K2P_CULLS 8
+#define HARE_K2P_REFILL 8
+#define HARE_K2P_EXACT 1
+#endif
+    const int STEPS = HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS, REFILL_MIN_IDLE = HARE_K2P_REFILL, RAY_CHUNK = 128, EXACT_MIN_PARKED = HARE_K2P_EXACT;
     const unsigned int n32 = (unsigned int)io.n;
     // static first chunk per wave, tickets of io.ticket_rays after those (as in the voxel kernel)
     const unsigned int n_static = gridDim.x * 4u * (unsigned int)RAY_CHUNK;
