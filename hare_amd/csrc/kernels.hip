@@ -291,7 +291,10 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 #endif
     const int STEPS_PER_ROUND = PROF ? io.steps_per_round : STEPS;
     const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : HARE_K1P_REFILL;
-    const int RAY_CHUNK = PROF ? io.ray_chunk : 128;
+#ifndef HARE_K1P_STATIC
+#define HARE_K1P_STATIC 128
+#endif
+    const int RAY_CHUNK = PROF ? io.ray_chunk : HARE_K1P_STATIC;
     const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : HARE_K1P_EXACT;
 
     // wave-uniform work chunk [cn, ce).  The first chunk of every wave is static (wave w owns rays
