@@ -46,6 +46,20 @@ __device__ __forceinline__ void set_miss(XEventRec& e)
     e.hit = 0;
 }
 
+// Events are written exactly once per launch (59 MB per 1M rays) while the scene is re-read all the time: stream
+// them past the caches (non-temporal) so that they do not evict it (+1.3 %; the same for the ray loads measured worse).
+__device__ __forceinline__ void store_event_streaming(XEventRec* dst, const XEventRec& e)
+{
+    double* q = reinterpret_cast<double*>(dst);      // 56-byte records: 8-byte aligned only
+    __builtin_nontemporal_store(e.t, q + 0);
+    __builtin_nontemporal_store(e.u, q + 1);
+    __builtin_nontemporal_store(e.v, q + 2);
+    __builtin_nontemporal_store(e.x, q + 3);
+    __builtin_nontemporal_store(e.y, q + 4);
+    __builtin_nontemporal_store(e.z, q + 5);
+    __builtin_nontemporal_store(__hiloint2double(e.hit, e.poly_id), q + 6);
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v)
 {
     unsigned long long s = v;
@@ -354,7 +368,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
         } else {
             set_miss(ev);
         }
-        io.out[ray] = ev;
+        store_event_streaming(&io.out[ray], ev);
         alive = false;
     };
     // the voxel just entered: occupancy bit from LDS; only a non-empty voxel touches memory
@@ -890,7 +904,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         } else {
             set_miss(ev);
         }
-        io.out[ray] = ev;
+        store_event_streaming(&io.out[ray], ev);
         alive = false;
     };
     // child planes of a node box and their ray parameters ("Octree - alt.cs":96-111, :253-263)
