@@ -401,7 +401,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             io.prof = (unsigned long long*)d_ctr + CTR_WORDS;
             pf = M.voxel_persist_prof;
         }
-        int rc = launch(H, pf, pgrid, block, lds, st, args);
+        const unsigned lds_total = lds + (pf == M.voxel_persist_prof ? 4u * 18u * 8u : 0u);   // + the profiling build's per-wave statistics
+        int rc = launch(H, pf, pgrid, block, lds_total, st, args);
         if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * 4u, st);
         return rc;
     }

@@ -262,19 +262,32 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 template <bool QUADS, bool COARSE, bool PROF = false, int STEPS = HARE_K1P_STEPS, int CULLS = HARE_K1P_CULLS>
 __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
 {
-    // PROF: developer build with s_memtime stamps per phase (never the timed kernel)
-    unsigned long long pf[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tstamp = 0;
-    auto stamp = [&](int slot) {
-        if (PROF) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            pf[slot] += now - tstamp;
-            tstamp = now;
-        }
-    };
-    if (PROF) tstamp = __builtin_readcyclecounter();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);   // address space known: ds_read, not flat
+    // PROF: developer build with cycle stamps per phase (never the timed kernel).  Its statistics live in LDS behind the
+    // bitmap (17 u64 per wave; the host adds the space), not in registers: the build must keep the production kernel's
+    // register footprint, or it runs at a different occupancy and measures something else.
+    unsigned long long* const pf = reinterpret_cast<unsigned long long*>(lds_raw + ((size_t)((g.occ_words + 3) >> 2) << 4)) + (threadIdx.x >> 6) * 18;
+    unsigned long long* const pn = pf;              // slots 5..15: event / lane counts; slot 17: last stamp
+    auto bump = [&](int slot, unsigned long long v) {
+        if (PROF) { if ((threadIdx.x & 63) == 0) pf[slot] += v; }
+    };
+    auto stamp = [&](int slot) {
+        if (PROF) {
+            if ((threadIdx.x & 63) == 0) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                pf[slot] += now - pf[17];
+                pf[17] = now;
+            }
+        }
+    };
+    if (PROF) {
+        if ((threadIdx.x & 63) == 0) {
+            for (int k = 0; k < 17; ++k) pf[k] = 0;
+            pf[17] = __builtin_readcyclecounter();
+        }
+    }
+    (void)pn;
     {
         const int nw4 = (g.occ_words + 3) >> 2;           // the device buffer is padded to 16 bytes
         const uint4* src = reinterpret_cast<const uint4*>(g.occ);
@@ -303,13 +316,13 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 #define HARE_K1P_REFILL 16
 #define HARE_K1P_EXACT 8
 #endif
-    const int STEPS_PER_ROUND = PROF ? io.steps_per_round : STEPS;
-    const int REFILL_MIN_IDLE = PROF ? io.refill_min_idle : HARE_K1P_REFILL;
+    const int STEPS_PER_ROUND = STEPS;
+    const int REFILL_MIN_IDLE = HARE_K1P_REFILL;
 #ifndef HARE_K1P_STATIC
 #define HARE_K1P_STATIC 128
 #endif
-    const int RAY_CHUNK = PROF ? io.ray_chunk : HARE_K1P_STATIC;
-    const int EXACT_MIN_PARKED = PROF ? io.exact_min_parked : HARE_K1P_EXACT;
+    const int RAY_CHUNK = HARE_K1P_STATIC;
+    const int EXACT_MIN_PARKED = HARE_K1P_EXACT;
 
     // wave-uniform work chunk [cn, ce).  The first chunk of every wave is static (wave w owns rays
     // [w*RAY_CHUNK, (w+1)*RAY_CHUNK)); tickets hand out the rays after those.  Same-address atomics
@@ -395,12 +408,12 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 
     stamp(0);
     for (;;) {
-        if (PROF) pf[5]++;
+        bump(5, 1);
         // ------------------------------------------------------------------ refill idle lanes
         const unsigned long long idle = __ballot(!alive);
         if (__builtin_expect(!drained && (__popcll(idle) >= REFILL_MIN_IDLE || idle == ~0ull), 0)) {
             bool want = !alive;
-            if (PROF) { pf[12]++; pf[13] += __popcll(idle); }
+            if (PROF) { bump(12, 1); bump(13, __popcll(idle)); }
             while (true) {
                 const unsigned long long wm = __ballot(want);
                 if (wm == 0) break;
@@ -484,14 +497,14 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             if (drained) break;
             continue;
         }
-        if (PROF) pf[14] += __popcll(__ballot(alive));
+        if (PROF) bump(14, __popcll(__ballot(alive)));
 
         // ------------------------------------------------------------------ phase A: DDA steps
 #pragma unroll 1
         for (int k = 0; k < STEPS_PER_ROUND; ++k) {
             const bool walk = alive && q == qe;
             if (__ballot(walk) == 0) break;
-            if (PROF) { pf[6]++; pf[7] += __popcll(__ballot(walk)); }
+            if (PROF) { bump(6, 1); bump(7, __popcll(__ballot(walk))); }
             if (walk) {
                 // Voxel_Grid.cs:705: pending hit inside the CURRENT padded voxel?
                 bool done = false;
@@ -530,7 +543,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 
         stamp(2);
         // ------------------------------------------------------------------ phase B1: FP32 cull
-        if (PROF) { const unsigned long long m = __ballot(alive && !parked && q < qe); if (m) { pf[8]++; pf[9] += __popcll(m); } }
+        if (PROF) { const unsigned long long m = __ballot(alive && !parked && q < qe); if (m) { bump(8, 1); bump(9, __popcll(m)); } }
 #pragma unroll 1
         for (int kc = 0; kc < CULLS; ++kc) {
           if (CULLS > 1 && kc > 0 && __ballot(alive && !parked && q < qe) == 0) break;
@@ -564,7 +577,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             const unsigned long long pm = __ballot(alive && parked);
             const unsigned long long busy = __ballot(alive && !parked);   // lanes that can still walk or cull
             if (pm != 0 && (__popcll(pm) >= EXACT_MIN_PARKED || busy == 0)) {
-                if (PROF) { pf[10]++; pf[11] += __popcll(pm); }
+                if (PROF) { bump(10, 1); bump(11, __popcll(pm)); }
                 if (alive && parked) {
                     const int i = idx;
                     const PolyRec& p = g.polys[i];

@@ -1,4 +1,5 @@
-"""Developer tool: per-phase cycle shares and lane occupancy of the persistent voxel kernel."""
+"""Developer tool: per-phase cycle shares and lane occupancy of the persistent voxel kernel (profiling build: the
+production kernel + cycle stamps kept in LDS, same register footprint and occupancy)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,8 +11,7 @@ rays = H.scenes.burst_rays(N, mesh.size)
 dr = torch.from_numpy(rays).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
 buf = torch.zeros(8 + 17, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
-for tune in sys.argv[2:] or ["3,8,128,4,8"]:
-    os.environ["HARE_TUNE"] = tune
+for tune in ["production constants"]:      # the profiling build uses the production kernel's compile-time knobs
     buf.zero_()
     g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x4000)
     torch.cuda.synchronize()
