@@ -1055,22 +1055,55 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         }
 
         // ------------------------------------------------------------------ phase B1: FP32 cull (leaf candidates)
+        // Two candidates per iteration: both list entries, then both polygon records, are requested together and the culls
+        // run back to back -- two culls per pair of dependent loads instead of one.  (This kernel is held to three workgroups
+        // per CU by its LDS frames, so the second record in flight costs no occupancy; the voxel kernel has no such room.)
+        struct CullRec { double2 c0; uint4 r1; float4 fb; float2 fc; };
+        auto load_rec = [&](int i) {
+            const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + i);
+            CullRec r;
+            r.c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
+            r.r1 = *reinterpret_cast<const uint4*>(rec + 16);       // v0.z | e1f.x e1f.y
+            r.fb = *reinterpret_cast<const float4*>(rec + 32);      // e1f.z e2f.x e2f.y e2f.z
+            r.fc = *reinterpret_cast<const float2*>(rec + 48);      // ee emax
+            return r;
+        };
+        auto culled = [&](const CullRec& r) {
+            const double c1x = __hiloint2double((int)r.r1.y, (int)r.r1.x);
+            const float e1f[3] = {__uint_as_float(r.r1.z), __uint_as_float(r.r1.w), r.fb.x}, e2f[3] = {r.fb.y, r.fb.z, r.fb.w};
+            return cull_fp32((float)(o.x - r.c0.x), (float)(o.y - r.c0.y), (float)(o.z - c1x), dfx, dfy, dfz, dm, e1f, e2f, r.fc.x, r.fc.y);
+        };
+        auto recently = [&](int i) { return i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3; };   // :218 (+ mailbox)
 #pragma unroll 1
-        for (int kc = 0; kc < CULLS; ++kc) {
+        for (int kc = 0; kc < CULLS / 2; ++kc) {
             const bool culling = alive && !parked && q < qe;
             if (__ballot(culling) == 0) break;
             if (culling) {
-                const int i = g.items[q];
-                if (i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3) {        // :218 (+ mailbox)
-                    ++q;
+                const bool has1 = q + 1 < qe;
+                const int i0 = g.items[q];
+                int i1 = -1;
+                if (has1) i1 = g.items[q + 1];
+                const bool sk0 = recently(i0);
+                const bool sk1 = !has1 || recently(i1) || i1 == i0;
+                CullRec ra, rb;
+                if (!sk0) ra = load_rec(i0);
+                if (!sk1) rb = load_rec(i1);
+                bool consumed0 = true;
+                if (!sk0) {
+                    m3 = m2; m2 = m1; m1 = m0; m0 = i0;
+                    if (culled(ra)) ++q;
+                    else { parked = true; consumed0 = false; }           // phase B2 tests items[q]
                 } else {
-                    const PolyRec& p = g.polys[i];
-                    m3 = m2; m2 = m1; m1 = m0; m0 = i;
-                    if (cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
-                                  p.e1f, p.e2f, p.ee, p.emax))
+                    ++q;
+                }
+                if (consumed0 && has1) {
+                    if (sk1) {
                         ++q;
-                    else
-                        parked = true;
+                    } else {
+                        m3 = m2; m2 = m1; m1 = m0; m0 = i1;
+                        if (culled(rb)) ++q;
+                        else parked = true;
+                    }
                 }
             }
         }
