@@ -997,7 +997,14 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     };
     {
         std::vector<std::thread> workers;
-        for (int k = 1; k < K; ++k) workers.emplace_back(guarded, k);
+        workers.reserve((size_t)K);
+        for (int k = 1; k < K; ++k) {
+            try {
+                workers.emplace_back(guarded, k);
+            } catch (...) {
+                guarded(k);          // no thread to be had: run the chunk here (a started thread must never be left unjoined)
+            }
+        }
         guarded(0);
         for (auto& w : workers) w.join();
     }
@@ -1048,7 +1055,14 @@ int hare_shoot_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_
         if (rcs[k] != HARE_OK) errs[k] = hare_last_error();     // thread-local: carry it to the caller's thread
     };
     std::vector<std::thread> workers;
-    for (int k = 1; k < G; ++k) workers.emplace_back(shard, k);
+    workers.reserve((size_t)G);
+    for (int k = 1; k < G; ++k) {
+        try {
+            workers.emplace_back(shard, k);
+        } catch (...) {
+            shard(k);                // no thread to be had: run the shard here
+        }
+    }
     shard(0);
     for (auto& w : workers) w.join();
     for (int k = 0; k < G; ++k)
