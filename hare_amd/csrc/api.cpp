@@ -20,8 +20,6 @@
 extern "C" const unsigned char hare_kernels_co[];
 extern "C" const unsigned char hare_kernels_co_end[];
 
-struct hare_scene : hare::Scene {};
-
 static_assert(sizeof(hare_ray) == sizeof(hare::RayRec), "hare_ray layout");
 static_assert(sizeof(hare_xevent) == sizeof(hare::XEventRec), "hare_xevent layout");
 static_assert(sizeof(hare_xevent) == 56 && sizeof(hare_ray) == 48, "wire sizes");
@@ -87,6 +85,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
         {"hare_ctr_reduce", &m->ctr_reduce},
+        {"hare_occlusion", &m->occlusion},
         {"hare_cull_audit", &m->cull_audit},
         {"hare_voxel_persist_prof", &m->voxel_persist_prof},
         {"hare_vb_count", &m->vb_count},
@@ -173,6 +172,44 @@ float up(double x)
     return f;
 }
 
+// The device (and host-mirror) polygon records of one topology: PolyRec per polygon, QuadRec side array only when
+// the topology has quadrilaterals.
+void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<QuadRec>& quads)
+{
+    rec.assign((size_t)std::max(T.P, 1), PolyRec());
+    memset(rec.data(), 0, rec.size() * sizeof(PolyRec));
+    quads.clear();
+    if (T.has_quads) {
+        quads.resize((size_t)T.P);
+        memset(quads.data(), 0, quads.size() * sizeof(QuadRec));
+    }
+    for (int32_t p = 0; p < T.P; ++p) {
+        const double* V = &T.verts[(size_t)p * 12];
+        PolyRec& r = rec[p];
+        double e1[3], e2[3], n1 = 0, emax = 0;
+        for (int a = 0; a < 3; ++a) {
+            r.v0[a] = V[a];
+            r.v1[a] = V[3 + a];
+            r.v2[a] = V[6 + a];
+            r.n[a] = T.normals[(size_t)p * 3 + a];
+            e1[a] = V[3 + a] - V[a];            // edge1 / edge2 of RayXtri (Polygons.cs:452-457)
+            e2[a] = V[6 + a] - V[a];
+            r.e1f[a] = (float)e1[a];
+            r.e2f[a] = (float)e2[a];
+            n1 += fabs(e1[a]);
+            emax = std::max(emax, std::max(fabs(e1[a]), fabs(e2[a])));
+        }
+        r.emax = up(emax);
+        r.ee = up(n1 * (double)r.emax);
+        if (T.nverts[p] == 4) {
+            r.emax = INFINITY;                  // quadrilaterals are never pre-culled
+            r.ee = INFINITY;
+            for (int a = 0; a < 3; ++a) quads[p].v3[a] = V[9 + a];
+        }
+        if (T.has_quads) quads[p].nverts = T.nverts[p];
+    }
+}
+
 int upload_polys(Scene& s, const HipApi* H)
 {
     if (s.d_polys.size() == s.topos.size()) return HARE_OK;
@@ -180,38 +217,9 @@ int upload_polys(Scene& s, const HipApi* H)
     s.d_quads.assign(s.topos.size(), nullptr);
     for (size_t m = 0; m < s.topos.size(); ++m) {
         const Topo& T = s.topos[m];
-        std::vector<PolyRec> rec((size_t)std::max(T.P, 1));
-        memset(rec.data(), 0, rec.size() * sizeof(PolyRec));
+        std::vector<PolyRec> rec;
         std::vector<QuadRec> quads;
-        if (T.has_quads) {
-            quads.resize((size_t)T.P);
-            memset(quads.data(), 0, quads.size() * sizeof(QuadRec));
-        }
-        for (int32_t p = 0; p < T.P; ++p) {
-            const double* V = &T.verts[(size_t)p * 12];
-            PolyRec& r = rec[p];
-            double e1[3], e2[3], n1 = 0, emax = 0;
-            for (int a = 0; a < 3; ++a) {
-                r.v0[a] = V[a];
-                r.v1[a] = V[3 + a];
-                r.v2[a] = V[6 + a];
-                r.n[a] = T.normals[(size_t)p * 3 + a];
-                e1[a] = V[3 + a] - V[a];            // edge1 / edge2 of RayXtri (Polygons.cs:452-457)
-                e2[a] = V[6 + a] - V[a];
-                r.e1f[a] = (float)e1[a];
-                r.e2f[a] = (float)e2[a];
-                n1 += fabs(e1[a]);
-                emax = std::max(emax, std::max(fabs(e1[a]), fabs(e2[a])));
-            }
-            r.emax = up(emax);
-            r.ee = up(n1 * (double)r.emax);
-            if (T.nverts[p] == 4) {
-                r.emax = INFINITY;                  // quadrilaterals are never pre-culled
-                r.ee = INFINITY;
-                for (int a = 0; a < 3; ++a) quads[p].v3[a] = V[9 + a];
-            }
-            if (T.has_quads) quads[p].nverts = T.nverts[p];
-        }
+        make_poly_records(T, rec, quads);
         int rc = upload(H, &s.d_polys[m], rec.data(), rec.size() * sizeof(PolyRec));
         if (rc) return rc;
         if (T.has_quads) {
@@ -286,9 +294,39 @@ int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, u
     return launch(H, M.ctr_reduce, 1, 256, 0, st, args);
 }
 
+// Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
+// counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass when the process
+// opted in with HARE_DEV=1 (tools/, the cull-audit test), so a stray bit from a caller can never reach a kernel.
+constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS;
+uint32_t sanitize_flags(uint32_t flags)
+{
+    const char* e = getenv("HARE_DEV");
+    const bool dev = e && *e && *e != '0';
+    return flags & (kPublicFlags | (dev ? 0xE000u : 0u));
+}
+
+// Frames the octree kernels keep per lane: one per interior level the tree really has.
+int32_t octree_levels(const OctreeHost& o)
+{
+    if (o.nodes.empty()) return 1;
+    int32_t best = 0;
+    std::vector<std::pair<int32_t, int32_t>> st;   // node, depth
+    st.emplace_back(0, 0);
+    while (!st.empty()) {
+        const auto [ni, d] = st.back();
+        st.pop_back();
+        const OctNode& nd = o.nodes[(size_t)ni];
+        if (nd.first_child < 0) continue;
+        best = std::max(best, d + 1);
+        for (int c = 0; c < 8; ++c) st.emplace_back(nd.first_child + c, d + 1);
+    }
+    return std::max(best, 1);
+}
+
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
                       const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st)
 {
+    flags = sanitize_flags(flags);
     if (n < 0 || top < 0 || top >= (int32_t)s.topos.size()) {
         set_error("hare_shoot: bad n or top_index");
         return HARE_E_INVALID;
@@ -311,7 +349,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.ctr = (unsigned long long*)d_ctr;
     io.work = (unsigned int*)s.d_work;
     io.n = n;
-    io.flags = flags & 0x3FFFu;
+    io.flags = flags;
     io.steps_per_round = 10;
     io.refill_min_idle = 16;
     io.ray_chunk = 128;
@@ -418,17 +456,21 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.nodes = (const OctNode*)s.d_oct_nodes;
         g.items = (const int32_t*)s.d_oct_items;
         g.n_nodes = (int32_t)s.oct.nodes.size();
-        g.max_depth = s.oct.max_depth;
+        g.max_depth = std::max(1, s.oct_levels);   // frames per lane = interior levels the tree really has (<= maxDepth)
         hipFunction_t f = count ? M.octree_count : M.octree;
         if (!f) {
             set_error("hare_shoot: octree kernel missing from code object");
             return HARE_E_STATE;
         }
-        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && g.max_depth <= 16) {
-            // persistent kernel: frames = 24 bytes x levels x 256 lanes of LDS per workgroup
-            const unsigned plevels = (unsigned)std::max(1, g.max_depth);
-            const unsigned plds = plevels * 256u * 24u;
-            unsigned per_cu = std::min(4u, std::max(1u, (unsigned)(160 * 1024 / plds)));
+        constexpr unsigned kLdsMax = 160u * 1024u;
+        if ((size_t)g.max_depth * 64u * 24u > kLdsMax) {   // cannot happen while hare_octree_build caps maxDepth at 24
+            set_error("hare_shoot: octree is deeper than the per-lane frames the kernels keep in LDS (" +
+                      std::to_string(g.max_depth) + " levels)");
+            return HARE_E_UNSUPPORTED;
+        }
+        const unsigned plds = (unsigned)g.max_depth * 256u * 24u;   // persistent kernel: 24 bytes x levels x 256 lanes per workgroup
+        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && plds <= kLdsMax) {
+            unsigned per_cu = std::min(4u, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
@@ -444,9 +486,9 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return rc;
         }
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
-        const unsigned levels = (unsigned)std::max(1, g.max_depth);
+        const unsigned levels = (unsigned)g.max_depth;
         unsigned ob = 256;
-        while (ob > 64 && (size_t)levels * ob * 24 > 64 * 1024) ob >>= 1;
+        while (ob > 64 && (size_t)levels * ob * 24 > 64 * 1024) ob >>= 1;   // ob = 64: up to 106 levels fit 160 KB
         const unsigned lds = levels * ob * 24;
         void* args[] = {&g, &io};
         return launch(H, f, (unsigned)((n + ob - 1) / ob), ob, lds, st, args);
@@ -613,8 +655,9 @@ void hare_scene_destroy(hare_scene* s)
     if (!s) return;
     std::string e;
     const HipApi* H = hip_api(&e);
+    free_host_mirror(*s);
     if (H && (s->module || s->stream)) {
-        (void)H->SetDevice(s->device);
+        DeviceGuard dev_guard(H, s->device);   // act on the scene's device, leave the caller's current device as it was
         if (s->stream) (void)H->StreamSynchronize(s->stream);
         for (auto* v : {&s->d_polys, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
@@ -691,11 +734,13 @@ int hare_voxel_build(hare_scene* s, int32_t domain)
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    DeviceGuard dev_guard(hip_api(nullptr), s->device);
     if (domain < 1 || domain > 1024) {
         set_error("hare_voxel_build: domain must be in [1, 1024]");
         return HARE_E_INVALID;
     }
     bool on_gpu = false;
+    free_host_mirror(*s);
     int rc = try_gpu_voxel_build(s, domain, 0, 0, &on_gpu);
     if (rc) return rc;
     if (on_gpu) return HARE_OK;
@@ -712,11 +757,13 @@ int hare_voxel_build_adaptive(hare_scene* s, int32_t max_domain, int32_t avg_pol
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    DeviceGuard dev_guard(hip_api(nullptr), s->device);
     if (max_domain < 1 || max_domain > 10) {
         set_error("hare_voxel_build_adaptive: max_domain must be in [1, 10]");
         return HARE_E_INVALID;
     }
     bool on_gpu = false;
+    free_host_mirror(*s);
     int rc = try_gpu_voxel_build(s, 0, max_domain, avg_polys, &on_gpu);
     if (rc) return rc;
     if (on_gpu) return HARE_OK;
@@ -733,6 +780,7 @@ int hare_octree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    DeviceGuard dev_guard(hip_api(nullptr), s->device);
     int rc = octree_check_args(*s, max_depth, max_polys);
     if (rc) return rc;
     bool on_gpu = false;
@@ -754,6 +802,8 @@ int hare_octree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
         rc = build_octree(*s, max_depth, max_polys);
         if (rc) return rc;
     }
+    s->oct_levels = octree_levels(s->oct);
+    free_host_mirror(*s);
     return sync_partition_to_device(s, HARE_KIND_OCTREE);
     GUARD_END
 }
@@ -765,6 +815,8 @@ int hare_kdtree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    DeviceGuard dev_guard(hip_api(nullptr), s->device);
+    free_host_mirror(*s);
     int rc = build_kdtree(*s, max_depth, max_polys);
     if (rc) return rc;
     return sync_partition_to_device(s, HARE_KIND_KDTREE);
@@ -910,13 +962,14 @@ int hare_shoot_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
-    const HipApi* H = nullptr;
+    const HipApi* H = api_or_err();
+    if (!H) return HARE_E_NODEVICE;
+    // the launch and the ticket memset must be issued with the scene's device current, whatever the calling thread had
+    // selected (a torch device guard, another scene); the guard puts the caller's device back afterwards
+    DeviceGuard dev_guard(H, s->device);
     if (!s->module) {
         int rc = ensure_device(*s, H);
         if (rc) return rc;
-    } else {
-        H = api_or_err();
-        if (!H) return HARE_E_NODEVICE;
     }
     return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_out, d_counters,
                              (hipStream_t)stream);
@@ -935,7 +988,12 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    // host-buffer callers get the reference's meaning of poly_origin: an index that matches no polygon (any negative
+    // value) excludes nothing.  Only the device-resident bounce loop (hare_reflect_device + hare_shoot_device) may
+    // retire rays, so the retire flag never passes here, nor do developer bits.
+    flags = sanitize_flags(flags) & ~HARE_SHOOT_RETIRED_RAYS;
     std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard dev_guard(hip_api(nullptr), s->device);
     const HipApi* H = nullptr;
     int rc = ensure_device(*s, H);
     if (rc) return rc;
@@ -963,11 +1021,9 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     memset(parts, 0, sizeof parts);
     int rcs[kMaxChunks] = {HARE_OK, HARE_OK, HARE_OK};
     std::string errs[kMaxChunks];
-    auto chunk = [&](int k) -> int {
+    auto chunk_body = [&](int k, hipStream_t st) -> int {
         const int64_t lo = (int64_t)((__int128)n * k / K), m = (int64_t)((__int128)n * (k + 1) / K) - lo;
         if (m == 0) return HARE_OK;
-        HIP_TRY(H->SetDevice(s->device));                       // the current device is per host thread
-        hipStream_t st = k == 0 ? s->stream : s->extra_streams[k - 1];
         hare_ray* dr = (hare_ray*)s->d_rays + lo;
         int32_t* de1 = (int32_t*)s->d_e1 + lo;
         int32_t* de2 = (int32_t*)s->d_e2 + lo;
@@ -985,6 +1041,15 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
         HIP_TRY(H->MemcpyAsync(&parts[k], dctr, sizeof(hare_counters), hipMemcpyDeviceToHost, st));
         HIP_TRY(H->StreamSynchronize(st));
         return HARE_OK;
+    };
+    auto chunk = [&](int k) -> int {
+        DeviceGuard g(H, s->device);                            // the current device is per host thread
+        hipStream_t st = k == 0 ? s->stream : s->extra_streams[k - 1];
+        const int r = chunk_body(k, st);
+        // a failed step leaves earlier async copies into the caller's buffers in flight: drain them before the
+        // error reaches a caller who may free those buffers
+        if (r != HARE_OK) (void)H->StreamSynchronize(st);
+        return r;
     };
     auto guarded = [&](int k) {
         try {
@@ -1042,6 +1107,7 @@ int hare_shoot_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    flags = sanitize_flags(flags) & ~HARE_SHOOT_RETIRED_RAYS;
     if (ctr) memset(ctr, 0, sizeof *ctr);
     const int G = n_scenes;
     std::vector<int> rcs((size_t)G, HARE_OK);
@@ -1094,6 +1160,7 @@ int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_ray
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
+    DeviceGuard dev_guard(hip_api(nullptr), s->device);
     const HipApi* H = nullptr;
     int rc = ensure_device(*s, H);
     if (rc) return rc;
@@ -1108,6 +1175,65 @@ int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_ray
     void* args[] = {&polys, &d_rays, &d_events, &d_excl_out, &n};
     const unsigned block = 256;
     return launch(H, s->module->reflect, (unsigned)((n + block - 1) / block), block, 0, (hipStream_t)stream, args);
+    GUARD_END
+}
+
+int hare_occluded_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, void* d_rays, const void* d_excl1,
+                         const void* d_excl2, const void* d_tmax, uint32_t flags, void* d_events, void* d_occluded,
+                         void* d_counters, void* stream)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    if (n < 0 || (n > 0 && (!d_events || !d_occluded))) {
+        set_error("hare_occluded_device: bad arguments");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    const HipApi* H = api_or_err();
+    if (!H) return HARE_E_NODEVICE;
+    DeviceGuard dev_guard(H, s->device);
+    if (!s->module) {
+        int rc = ensure_device(*s, H);
+        if (rc) return rc;
+    }
+    int rc = shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_events, d_counters, (hipStream_t)stream);
+    if (rc || n == 0) return rc;
+    if (!s->module->occlusion) {
+        set_error("hare_occluded_device: kernel missing from code object");
+        return HARE_E_STATE;
+    }
+    const void* ev = d_events;
+    void* args[] = {&ev, &d_tmax, &d_occluded, &n};
+    const unsigned block = 256;
+    return launch(H, s->module->occlusion, (unsigned)((n + block - 1) / block), block, 0, (hipStream_t)stream, args);
+    GUARD_END
+}
+
+int hare_occluded_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays, const int32_t* excl1,
+                        const int32_t* excl2, const double* tmax, uint32_t flags, int32_t* occluded, hare_xevent* events,
+                        hare_counters* ctr)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    if (n < 0 || (n > 0 && (!rays || !occluded))) {
+        set_error("hare_occluded_batch: bad arguments");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    std::vector<hare_xevent> tmp;
+    if (!events && n > 0) {
+        tmp.resize((size_t)n);
+        events = tmp.data();
+    }
+    const int rc = hare_shoot_batch(s, kind, top_index, n, rays, excl1, excl2, flags, events, ctr);   // the GPU does the casting
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i)     // the predicate itself: closest hit before t_max
+        occluded[i] = (events[i].hit != 0 && (!tmax || events[i].t < tmax[i])) ? 1 : 0;
+    return HARE_OK;
     GUARD_END
 }
 

@@ -29,6 +29,7 @@ static_assert(sizeof(CellRec) == 16, "cell record size");
 enum : uint32_t {
     SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
     SHOOT_SIMPLE_KERNEL = 4u,     // use the one-ray-per-lane kernel instead of the persistent one (A/B, diagnostics)
+    SHOOT_RETIRED_RAYS = 8u,      // bounce loop: excl1 == -2 marks a ray hare_reflect retired -> miss record, no traversal, not counted
 };
 
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)

@@ -70,7 +70,7 @@ struct DeviceModule {
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
-    hipFunction_t reflect = nullptr, ctr_reduce = nullptr;
+    hipFunction_t reflect = nullptr, ctr_reduce = nullptr, occlusion = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
     hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
@@ -79,6 +79,29 @@ struct DeviceModule {
     hipFunction_t ob_count = nullptr, ob_fill = nullptr;
     int cu_count = 0;
 };
+
+// Makes `device` the calling thread's current HIP device for the guard's lifetime and restores the previous one
+// afterwards: a host that juggles several devices (torch device guards, one scene per GPU) must find its current
+// device unchanged after any call into the library, and every call must act on the scene's own device.
+struct DeviceGuard {
+    const HipApi* H;
+    int prev = -1;
+    bool switched = false;
+    DeviceGuard(const HipApi* api, int device) : H(api)
+    {
+        if (!H) return;
+        if (H->GetDevice(&prev) != hipSuccess) { prev = -1; (void)H->GetLastError(); }
+        if (prev != device && H->SetDevice(device) == hipSuccess) switched = true;
+    }
+    ~DeviceGuard()
+    {
+        if (H && switched && prev >= 0) (void)H->SetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+struct HostMirror;   // host_trace.cpp: the scene as hare_shoot_one reads it
 
 struct Scene {
     int device = 0;
@@ -113,7 +136,14 @@ struct Scene {
     int64_t staged_cap = 0;
 
     const DeviceModule* module = nullptr;
+
+    // host mirror for hare_shoot_one (single-ray callers): built on first use, read-only afterwards
+    std::mutex mirror_mu;
+    std::atomic<HostMirror*> mirror{nullptr};
+    int32_t oct_levels = 0;                      // interior levels the octree actually has (frames the kernels need)
 };
+void free_host_mirror(Scene& s);             // host_trace.cpp
+void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<QuadRec>& quads);   // api.cpp
 
 // error plumbing (thread-local message)
 void set_error(const std::string& msg);
@@ -145,6 +175,7 @@ int octree_check_args(const Scene& s, int32_t max_depth, int32_t max_polys);
 void octree_root_box(const Topo& T, double bmin[3], double bmax[3]);                      // "Octree - alt.cs":63-88
 void octree_child_box(const double nmin[3], const double nmax[3], int i, double cmin[3], double cmax[3]);   // :96-114
 int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys);
+int32_t octree_levels(const OctreeHost& o);   // api.cpp
 
 // host helpers
 void polygon_normals(const double* verts, const int32_t* nverts, int32_t P, double* out);
@@ -153,3 +184,6 @@ int topology_ingest(const double* soup, const int32_t* nverts, int32_t P, double
                     std::vector<double>& vertices);   // ingest.cpp
 
 }  // namespace hare
+
+// the opaque handle of include/hare_hip.h
+struct hare_scene : hare::Scene {};

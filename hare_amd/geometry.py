@@ -177,12 +177,40 @@ class Spatial_Partition:
 
     # bool Shoot(Ray R, int top_index, out X_Event Ret_event[, int poly_origin1, int poly_origin2 = -1])
     def Shoot(self, R: Ray, top_index: int, poly_origin1: int = -1, poly_origin2: int = -1):
-        rays = np.array([[R.x, R.y, R.z, R.dx, R.dy, R.dz]], np.float64)
-        ev, _ = self.Shoot_batch(rays, top_index, np.array([poly_origin1], np.int32), np.array([poly_origin2], np.int32),
-                                 writeback_origin=True)
-        R.x, R.y, R.z = (float(c) for c in rays[0, :3])   # the reference moves R when it starts outside (F11)
+        """One ray, like the reference call site: runs on the calling host thread (hare_shoot_one -- a GPU round trip
+        per ray would be ~100x slower than the reference), bit-identical to the batch kernels.  Returns (Hit, X_Event)."""
+        ray = np.array([R.x, R.y, R.z, R.dx, R.dy, R.dz], np.float64)
+        ev = np.zeros(1, XEVENT_DTYPE)
+        check(lib.hare_shoot_one(self._h, self._kind, int(top_index), ptr(ray), int(poly_origin1), int(poly_origin2), ptr(ev)))
+        R.x, R.y, R.z = (float(c) for c in ray[:3])       # the reference moves R when it starts outside (F11)
         e = X_Event.from_record(ev[0])
         return e.Hit, e
+
+    def Shoot_one(self, ray6, top_index: int = 0, poly_origin1: int = -1, poly_origin2: int = -1):
+        """hare_shoot_one on a raw [x,y,z,dx,dy,dz] array (updated in place like the reference moves R); returns the record."""
+        ev = np.zeros(1, XEVENT_DTYPE)
+        check(lib.hare_shoot_one(self._h, self._kind, int(top_index), ptr(ray6), int(poly_origin1), int(poly_origin2), ptr(ev)))
+        return ev[0]
+
+    def Occluded_batch(self, rays, t_max=None, top_index: int = 0, poly_origin1=None, poly_origin2=None):
+        """Harness-defined occlusion predicate: closest hit exists and t < t_max (t_max None: any hit).
+        Returns (occluded int32[n], events)."""
+        rays = np.array(rays, np.float64, order="C").reshape(-1, 6)
+        n = rays.shape[0]
+        occ = np.zeros(n, np.int32)
+        out = np.zeros(n, XEVENT_DTYPE)
+        tm = None if t_max is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t_max, np.float64), (n,)))
+        e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
+        e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
+        check(lib.hare_occluded_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), ptr(tm), 0,
+                                      ptr(occ), ptr(out), None))
+        return occ, out
+
+    def occluded_device(self, n: int, d_rays: int, d_events: int, d_occluded: int, d_tmax: int = 0, top_index: int = 0,
+                        d_excl1: int = 0, d_excl2: int = 0, d_counters: int = 0, stream: int = 0, flags: int = 0):
+        check(lib.hare_occluded_device(self._h, self._kind, int(top_index), int(n), d_rays or None, d_excl1 or None,
+                                       d_excl2 or None, d_tmax or None, int(flags), d_events or None, d_occluded or None,
+                                       d_counters or None, stream or None))
 
     def Shoot_batch(self, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
                     writeback_origin: bool = False, count_work: bool = False, simple_kernel: bool = False):

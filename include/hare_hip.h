@@ -17,9 +17,13 @@
  *     the miss record X_Event() (Hare_Geometry_Primitives.cs:454-462).
  *   - threading: build/destroy calls are single-caller; hare_shoot_batch may be called from
  *     several host threads on one scene (calls are serialised on an internal mutex per scene);
- *     hare_shoot_device is stream-ordered and takes no lock.
- *   - there is NO CPU fallback: every shoot runs the HIP kernels and fails with HARE_E_NODEVICE
- *     when no gfx950 device / HIP runtime is available.
+ *     hare_shoot_device is stream-ordered and takes no lock; hare_shoot_one takes no lock either.
+ *   - devices: every call acts on the scene's own device and leaves the calling thread's current
+ *     HIP device as it found it.
+ *   - batches have NO CPU fallback: hare_shoot_batch / hare_shoot_device run the HIP kernels and fail
+ *     with HARE_E_NODEVICE when no gfx950 device / HIP runtime is available.  The single-ray call
+ *     hare_shoot_one -- Spatial_Partition.Shoot exactly as the reference exposes it -- runs on the
+ *     calling host thread (a GPU round trip per ray would be ~100x slower than the reference).
  */
 #ifndef HARE_HIP_H
 #define HARE_HIP_H
@@ -53,6 +57,10 @@ extern "C" {
 #define HARE_SHOOT_WRITEBACK_ORIGIN 1u /* also apply AABB.Intersect's origin move to rays[] (AABB_Main.cs:254-257) */
 #define HARE_SHOOT_COUNT_WORK 2u       /* fill cells/entries/tests of hare_counters (slower diagnostic kernel)       */
 #define HARE_SHOOT_SIMPLE_KERNEL 4u    /* voxel: one-ray-per-lane kernel instead of the persistent one (A/B testing) */
+#define HARE_SHOOT_RETIRED_RAYS 8u     /* hare_shoot_device only (the bounce loop): poly_origin1 == -2 marks a ray that     */
+                                       /* hare_reflect_device retired -> miss record, no traversal, not counted.  Without    */
+                                       /* it -- and always in the host-buffer calls -- a negative poly_origin matches no      */
+                                       /* polygon, as in the reference (Voxel_Grid.cs:477 compares indices only)              */
 
 /* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
  * only serve the reference's mailbox pool and are not needed here. 48 bytes. */
@@ -207,11 +215,38 @@ HARE_API int hare_shoot_device(hare_scene *s, int32_t kind, int32_t top_index, i
                       const void *d_excl1, const void *d_excl2, uint32_t flags, void *d_out,
                       void *d_counters, void *stream);
 
+/* ---- Shoot, one ray (unchanged reference call sites) ----
+ * bool Shoot(Ray R, int top_index, out X_Event Ret_event, int poly_origin1 = -1, int poly_origin2 = -1)
+ * (Spatial_Partition.cs:32-33; Voxel_Grid.cs:351,561; "Octree - alt.cs":154; KDTree.cs:193) for ONE ray, on the calling
+ * host thread: the same trace the simple HIP kernels run (hare_amd/csrc/hare_trace.h), instantiated for the host over a
+ * host mirror of the scene that is built on first use.  Results are bit-identical to the batch calls.  *ray is
+ * updated like the reference mutates R when the origin lies outside the grid (AABB_Main.cs:254-257).  Needs no GPU;
+ * lock-free, callable concurrently from any number of threads (no mailbox: SURVEY.md F7).  out->hit is the return
+ * value of the reference's Shoot. */
+HARE_API int hare_shoot_one(hare_scene *s, int32_t kind, int32_t top_index, hare_ray *ray, int32_t poly_origin1,
+                            int32_t poly_origin2, hare_xevent *out);
+
+/* ---- occlusion predicate (harness-defined, SURVEY.md F13 / 8(a) A9: the reference has no any-hit API; the seam it
+ * would sit beside is Spatial_Partition.cs:32-33) ----
+ * occluded[i] = Shoot(rays[i]) hit something AND that closest hit has t < tmax[i]  (tmax NULL: any hit counts).
+ * Defined on the CLOSEST hit so that it is pinned by the same oracle as Shoot, including the reference's
+ * miss-on-grid-exit rule (Voxel_Grid.cs:716-757).  The closest-hit records themselves are returned in `events`
+ * (device call: required, n x 56 B; host call: nullable). */
+HARE_API int hare_occluded_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
+                                  const void *d_excl1, const void *d_excl2, const void *d_tmax /* n doubles, nullable */,
+                                  uint32_t flags, void *d_events, void *d_occluded /* n int32 */, void *d_counters,
+                                  void *stream);
+HARE_API int hare_occluded_batch(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, hare_ray *rays,
+                                 const int32_t *excl1, const int32_t *excl2, const double *tmax /* nullable */,
+                                 uint32_t flags, int32_t *occluded, hare_xevent *events /* nullable */,
+                                 hare_counters *ctr /* nullable */);
+
 /* ---- specular bounce (harness-defined; the reference leaves reflection to its caller, which
  * re-shoots with poly_origin1 = the previous Poly_id -- Voxel_Grid.cs:351,477) ----
  * For every ray with events[i].hit: origin <- X_Point, direction <- d - (2*(d.n))*n with
  * n = Model[top].Normal(Poly_id), excl_out[i] <- Poly_id.  Rays that missed keep their record
- * and get excl_out[i] = -2 (dead: a later shoot reports a miss for them immediately).
+ * and get excl_out[i] = -2 (dead: a later hare_shoot_device with HARE_SHOOT_RETIRED_RAYS reports a
+ * miss for them immediately and does not count them).
  * Device pointers, stream-ordered. */
 HARE_API int hare_reflect_device(hare_scene *s, int32_t top_index, int64_t n, void *d_rays, const void *d_events,
                         void *d_excl_out, void *stream);

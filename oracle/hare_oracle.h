@@ -155,6 +155,7 @@ int ho_brute_shoot(const ho_topology *T, const ho_ray *R, int32_t poly_origin1, 
 
 /* ---------- harness-defined specular bounce (not in the reference) ---------- */
 void ho_reflect(const ho_topology *T, const ho_ray *R, const ho_xevent *ev, ho_ray *out);
+void ho_reflect_batch(const ho_topology *T, int64_t n, const ho_ray *rays, const ho_xevent *ev, ho_ray *out);
 
 #ifdef __cplusplus
 }

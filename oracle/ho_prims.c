@@ -597,3 +597,13 @@ void ho_reflect(const ho_topology *T, const ho_ray *R, const ho_xevent *ev, ho_r
     out->dy = R->dy - k * N[1];
     out->dz = R->dz - k * N[2];
 }
+
+/* The same bounce over a batch (harness-defined): rays that hit are reflected,
+ * rays that missed keep their record (the caller retires them). */
+void ho_reflect_batch(const ho_topology *T, int64_t n, const ho_ray *rays, const ho_xevent *ev, ho_ray *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        if (ev[i].hit) ho_reflect(T, &rays[i], &ev[i], &out[i]);
+        else out[i] = rays[i];
+    }
+}

@@ -103,6 +103,7 @@ def lib():
         L.ho_kdtree_shoot_batch.argtypes = [vp, vp, i32, i64, vp, vp, vp, i32, C.c_int, vp, vp]
         L.ho_brute_shoot.argtypes = [vp, vp, i32, i32, C.c_int, vp]
         L.ho_reflect.argtypes = [vp, vp, vp, vp]
+        L.ho_reflect_batch.argtypes = [vp, i64, vp, vp, vp]
         _lib = L
     return _lib
 
@@ -337,6 +338,17 @@ def reflect(topo: Topology, rays, events):
     for i in range(rays.shape[0]):
         if events[i]["hit"]:
             L.ho_reflect(C.addressof(t), rays[i].ctypes.data, events[i:i + 1].ctypes.data, out[i].ctypes.data)
+    return out
+
+
+def reflect_batch(topo: Topology, rays, events):
+    """Specular bounce of a whole batch; rays that missed keep their record."""
+    rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+    events = np.ascontiguousarray(events)
+    assert events.dtype == XEVENT_DTYPE and len(events) == len(rays)
+    out = np.empty_like(rays)
+    t = topo.c_struct()
+    lib().ho_reflect_batch(C.addressof(t), rays.shape[0], _p(rays), _p(events), _p(out))
     return out
 
 

@@ -208,7 +208,7 @@ def test_bounce_loop_device_resident(hall):
     cur = rays.copy()
     excl = None
     for b in range(bounces):
-        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st)
+        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st, flags=H.capi.SHOOT_RETIRED_RAYS)
         torch.cuda.synchronize()
         ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)
         ref, _ = o.shoot(cur, excl1=excl, nthreads=16)
@@ -235,11 +235,12 @@ def test_bounce_loop_device_resident(hall):
             d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
 
 
-def test_fp32_cull_never_rejects_a_hit():
+def test_fp32_cull_never_rejects_a_hit(monkeypatch):
     """The persistent kernel's conservative FP32 pre-cull (cull_fp32, hare_math.h) may only drop
     candidates RayXtri is certain to reject.  Audit kernel: every ray x every polygon, count
     (culled AND the exact test accepts) -- must be zero -- on meshes of very different scale."""
     import ctypes as C
+    monkeypatch.setenv("HARE_DEV", "1")      # the audit bit (0x8000) is a developer flag: masked off without this
     from hare_amd import capi
     rng = np.random.default_rng(5)
     cases = []
@@ -434,7 +435,7 @@ def test_bounce_c5_shard_8_bounces_1M_tris(cathedral):
     cur, excl = rays.copy(), np.full(n, -1, np.int32)
     dead = np.zeros(n, bool)
     for b in range(bounces):
-        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st)
+        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st, flags=H.capi.SHOOT_RETIRED_RAYS)
         g.reflect_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_ex.data_ptr(), stream=st)
         torch.cuda.synchronize()
         ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)

@@ -13,7 +13,7 @@ st = torch.cuda.current_stream().cuda_stream
 d_rays = torch.from_numpy(rays).cuda(); d_out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
 d_excl = torch.full((N,), -1, dtype=torch.int32, device="cuda")
 for b in range(3):
-    g.shoot_device(N, d_rays.data_ptr(), d_out.data_ptr(), d_excl1=d_excl.data_ptr(), stream=st)
+    g.shoot_device(N, d_rays.data_ptr(), d_out.data_ptr(), flags=8, d_excl1=d_excl.data_ptr(), stream=st)
     g.reflect_device(N, d_rays.data_ptr(), d_out.data_ptr(), d_excl.data_ptr(), stream=st)
 torch.cuda.synchronize()
 r = d_rays.cpu().numpy().reshape(N, 6).copy(); e = d_excl.cpu().numpy().copy()
