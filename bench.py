@@ -344,7 +344,7 @@ def main() -> None:
         copy_gbs = 2 * a.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del a, b_
         if B == 1:
-            part.Shoot_batch(rays_h[: min(n, 65536)])
+            part.Shoot_batch(rays_h)            # sizes the scene's staging buffers: not part of the measurement
             t1 = time.perf_counter()
             part.Shoot_batch(rays_h)
             e2e = n / (time.perf_counter() - t1) / 1e6

@@ -1,6 +1,7 @@
 // example.cpp -- the C++ mirror in use: a unit cube, one ray, printed like a Hare caller would.
 // Build:  g++ -std=c++17 -I include -I bindings/cpp bindings/cpp/example.cpp -L hare_amd -lhare_hip -Wl,-rpath,$PWD/hare_amd -o /tmp/hare_example
-// Without a GPU the constructor works (host build) and Shoot throws "no HIP device visible".
+// Without a GPU the constructor (host build) and the single-ray Shoot (host trace) work; the batch Shoot, which is
+// GPU-only, throws "no HIP device visible".
 #include <cstdio>
 
 #include "hare.hpp"
@@ -25,6 +26,10 @@ int main()
         X_Event ev;
         if (grid.Shoot(R, 0, ev)) std::printf("hit poly %d at t = %.17g (%.3f, %.3f, %.3f)\n", ev.Poly_id, ev.t, ev.X_Point[0], ev.X_Point[1], ev.X_Point[2]);
         else std::printf("miss\n");
+        std::vector<hare_ray> rays = {{0.5, 0.75, 1.0, 1.0, 0.0, 0.0}, {0.5, 0.75, 1.0, 0.0, 0.0, -1.0}};
+        std::vector<hare_xevent> evs;
+        const unsigned long long hits = grid.Shoot(rays, 0, evs);          // the batch entry: HIP kernels, no CPU fallback
+        std::printf("batch: %llu hits, t = %.17g and %.17g\n", hits, evs[0].t, evs[1].t);
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return 2;

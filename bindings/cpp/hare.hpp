@@ -9,6 +9,7 @@
 // Header-only; link with -lhare_hip.  Errors become exceptions, like in .NET.
 #pragma once
 #include <array>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -109,9 +110,10 @@ public:
     // bool Shoot(Ray R, int top_index, out X_Event Ret_event[, int poly_origin1, int poly_origin2 = -1])
     bool Shoot(Ray& R, int top_index, X_Event& Ret_event, int poly_origin1 = -1, int poly_origin2 = -1)
     {
+        // one ray = the reference call site: traced on the calling host thread (hare_shoot_one; lock-free, no GPU round trip)
         hare_ray r{R.x, R.y, R.z, R.dx, R.dy, R.dz};
         hare_xevent e;
-        check(hare_shoot_batch(scene_, kind_, top_index, 1, &r, &poly_origin1, &poly_origin2, HARE_SHOOT_WRITEBACK_ORIGIN, &e, nullptr));
+        check(hare_shoot_one(scene_, kind_, top_index, &r, poly_origin1, poly_origin2, &e));
         R.x = r.x; R.y = r.y; R.z = r.z;     // the reference moves R when it starts outside the grid
         Ret_event = X_Event(e);
         return Ret_event.Hit;
@@ -126,6 +128,15 @@ public:
         check(hare_shoot_batch(scene_, kind_, top_index, (int64_t)rays.size(), rays.data(), poly_origin1, poly_origin2,
                                move_origins ? HARE_SHOOT_WRITEBACK_ORIGIN : 0u, results.data(), &c));
         return c.hits;
+    }
+    // occlusion predicate (harness-defined): occluded[i] = closest hit of rays[i] exists and t < t_max[i] (null: any hit)
+    std::vector<int32_t> Occluded(std::vector<hare_ray>& rays, int top_index, const double* t_max = nullptr,
+                                  const int32_t* poly_origin1 = nullptr, const int32_t* poly_origin2 = nullptr)
+    {
+        std::vector<int32_t> occ(rays.size());
+        check(hare_occluded_batch(scene_, kind_, top_index, (int64_t)rays.size(), rays.data(), poly_origin1, poly_origin2, t_max, 0u,
+                                  occ.data(), nullptr, nullptr));
+        return occ;
     }
     hare_scene* native() const { return scene_; }
 
@@ -156,7 +167,27 @@ public:
     double Ydim() const { return info_.box_dims[1]; }
     double Zdim() const { return info_.box_dims[2]; }
     std::array<double, 3> MinPt() const { return {{info_.obox_min[0], info_.obox_min[1], info_.obox_min[2]}}; }
-    int VoxelCode(int X, int Y, int Z) const { return info_.ct * info_.ct * Z + info_.ct * X + Y; }
+    int VoxelCode(int X, int Y, int Z) const { return info_.ct * info_.ct * Z + info_.ct * X + Y; }          // Voxel_Grid.cs:264-267
+    void VoxelDecode(int Code, int& X, int& Y, int& Z) const                                                    // :256-262
+    {
+        const int XYTot = info_.ct * info_.ct;
+        Z = Code / XYTot;
+        Code -= Z * XYTot;
+        Y = Code / info_.ct;
+        X = Code - Y * info_.ct;
+    }
+    void PointInVoxel(const double Pt[3], int& X, int& Y, int& Z) const                                         // :322-327
+    {
+        X = (int)std::floor((Pt[0] - info_.obox_min[0]) / info_.voxel_dims[0]);
+        Y = (int)std::floor((Pt[1] - info_.obox_min[1]) / info_.voxel_dims[1]);
+        Z = (int)std::floor((Pt[2] - info_.obox_min[2]) / info_.voxel_dims[2]);
+    }
+    int PointInVoxel(const double Pt[3]) const                                                                   // :329-332
+    {
+        int X, Y, Z;
+        PointInVoxel(Pt, X, Y, Z);
+        return VoxelCode(X, Y, Z);
+    }
     const hare_voxel_info& info() const { return info_; }
 
 private:

@@ -4,8 +4,10 @@
 //   Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys)      Voxel_Grid.cs:128
 //   Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode)  "Octree - alt.cs":45
 //   KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode)  KDTree.cs:51
-// plus one new member, the batch Shoot, which is where the throughput is.  The single-ray overrides
-// are the batch path with n = 1 (correct, but one kernel launch per ray).
+// plus one new member, the batch Shoot, which is where the throughput is.  The single-ray overrides --
+// what an unchanged Pachyderm call site reaches -- run hare_shoot_one: the same trace on the calling host
+// thread (no GPU round trip per ray, no lock; safe from any number of worker threads, like the reference's
+// ThreadID / mailbox-pool design intends), bit-identical to the batch kernels.
 //
 // The scene is read through public members only: Polygon_Count, this[poly, corner], Polys[p].VertextCT,
 // Normal(p), Min, Max -- i.e. AFTER the Topology rounded/merged vertices (Hare_Geometry_Topology.cs:342-377)
@@ -157,10 +159,26 @@ namespace Hare
 
             public override bool Shoot(Ray R, int top_index, out X_Event Ret_event, int poly_origin1, int poly_origin2 = -1)
             {
-                var one = new X_Event[1];
-                Shoot(new Ray[] { R }, top_index, one, new int[] { poly_origin1 }, new int[] { poly_origin2 });
-                Ret_event = one[0];
+                hare_ray r;
+                r.x = R.x; r.y = R.y; r.z = R.z; r.dx = R.dx; r.dy = R.dy; r.dz = R.dz;
+                hare_xevent ev;
+                HareHip.Check(HareHip.hare_shoot_one(scene, Kind, top_index, ref r, poly_origin1, poly_origin2, out ev));
+                R.x = r.x; R.y = r.y; R.z = r.z;                                  // F11: the reference mutates R
+                Ret_event = ev.hit != 0 ? new X_Event(new Point(ev.x, ev.y, ev.z), ev.u, ev.v, ev.t, ev.poly_id) : new X_Event();
                 return Ret_event.Hit;
+            }
+
+            /// <summary>Occlusion predicate for a batch (harness-defined; the reference has no any-hit call, its seam is
+            /// Spatial_Partition.cs:32-33): occluded[i] = the closest hit of rays[i] exists and lies before t_max[i]
+            /// (t_max null: any hit).  Runs on the GPU like the batch Shoot.</summary>
+            public bool[] Occluded(hare_ray[] rays, int top_index, double[] t_max = null, int[] poly_origin1 = null, int[] poly_origin2 = null)
+            {
+                var occ = new int[rays.Length];
+                hare_counters ctr;
+                HareHip.Check(HareHip.hare_occluded_batch(scene, Kind, top_index, rays.Length, rays, poly_origin1, poly_origin2, t_max, 0u, occ, null, out ctr));
+                var res = new bool[rays.Length];
+                for (int i = 0; i < res.Length; i++) res[i] = occ[i] != 0;
+                return res;
             }
 
             void Release()
@@ -218,6 +236,52 @@ namespace Hare
             }
 
             public int VoxelCode(int X, int Y, int Z) { return info.ct * info.ct * Z + info.ct * X + Y; }     // :264-267
+
+            public int PointInVoxel(Point Pt)                                                                 // :329-332
+            {
+                int X, Y, Z;
+                PointInVoxel(Pt, out X, out Y, out Z);
+                return VoxelCode(X, Y, Z);
+            }
+
+            public void VoxelDecode(int Code, out int X, out int Y, out int Z)                                // :256-262
+            {
+                int XYTot = info.ct * info.ct;
+                Z = (int)Math.Floor((double)(Code / XYTot));
+                Code -= Z * XYTot;
+                Y = (int)Math.Floor((double)(Code / info.ct));
+                X = Code - Y * info.ct;
+            }
+
+            System.Collections.Generic.List<int>[,,,] voxel_inv;
+            /// <summary>The reference's public field `List&lt;int&gt;[,,,] Voxel_Inv` (Voxel_Grid.cs:33): polygon indices per
+            /// voxel and topology, ascending.  Materialised on first use from the library's CSR lists (hare_voxel_get_lists);
+            /// the kernels never read it.</summary>
+            public System.Collections.Generic.List<int>[,,,] Voxel_Inv
+            {
+                get
+                {
+                    if (voxel_inv != null) return voxel_inv;
+                    int ct = info.ct, M = Model.Length;
+                    var inv = new System.Collections.Generic.List<int>[ct, ct, ct, M];
+                    var start = new uint[ct * ct * ct + 1];
+                    for (int m = 0; m < M; m++)
+                    {
+                        HareHip.Check(HareHip.hare_voxel_get_lists(scene, m, start, null));
+                        var items = new int[Math.Max(1, (int)start[start.Length - 1])];
+                        HareHip.Check(HareHip.hare_voxel_get_lists(scene, m, start, items));
+                        for (int x = 0; x < ct; x++) for (int y = 0; y < ct; y++) for (int z = 0; z < ct; z++)
+                        {
+                            int c = (x * ct + y) * ct + z;
+                            var l = new System.Collections.Generic.List<int>((int)(start[c + 1] - start[c]));
+                            for (uint k = start[c]; k < start[c + 1]; k++) l.Add(items[k]);
+                            inv[x, y, z, m] = l;
+                        }
+                    }
+                    voxel_inv = inv;
+                    return inv;
+                }
+            }
         }
 
         /// <summary>Octree on the GPU ("Octree - alt.cs").</summary>

@@ -65,6 +65,7 @@ namespace Hare
 
             public const int HARE_KIND_VOXEL = 0, HARE_KIND_OCTREE = 1, HARE_KIND_KDTREE = 2;
             public const uint HARE_SHOOT_WRITEBACK_ORIGIN = 1;
+            public const uint HARE_SHOOT_RETIRED_RAYS = 8;   // device-resident bounce loop only (hare_shoot_device)
 
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr hare_last_error();
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_device_count(out int count);
@@ -90,6 +91,17 @@ namespace Hare
             public static extern unsafe int hare_shoot_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
                                                                      hare_ray* rays, int* excl1, int* excl2, uint flags,
                                                                      hare_xevent* ev, hare_counters* ctr);
+            /// <summary>Spatial_Partition.Shoot for ONE ray on the calling thread (host trace, no GPU round trip, lock-free):
+            /// what the single-ray overrides call.  ray is updated like the reference moves R (AABB_Main.cs:254-257).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_shoot_one(IntPtr scene, int kind, int top_index, ref hare_ray ray, int poly_origin1, int poly_origin2, out hare_xevent ev);
+            /// <summary>Voxel_Inv[x,y,z,top] as CSR: cell = (x*ct + y)*ct + z; items may be null to size the buffer (cell_start[ct^3]).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_voxel_get_lists(IntPtr scene, int top_index, [Out] uint[] cell_start, [Out] int[] items);
+            /// <summary>Occlusion predicate (harness-defined): occluded[i] = closest hit exists and t &lt; tmax[i] (tmax null: any hit).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_occluded_batch(IntPtr scene, int kind, int top_index, long n, [In, Out] hare_ray[] rays, int[] excl1, int[] excl2,
+                                                         double[] tmax, uint flags, [Out] int[] occluded, [Out] hare_xevent[] events, out hare_counters ctr);
             /// <summary>Topology(Point[][]) ingest for hosts holding a raw polygon soup (include/hare_hip.h).</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_topology_ingest([In] double[] soup, [In] int[] nverts, int P, [Out] double[] verts_out,

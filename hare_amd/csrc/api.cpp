@@ -78,6 +78,10 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_persist_quad", &m->voxel_persist_quad},
         {"hare_voxel_persist_tri_g", &m->voxel_persist_tri_g},
         {"hare_voxel_persist_quad_g", &m->voxel_persist_quad_g},
+        {"hare_voxel_pool_tri", &m->voxel_pool_tri},
+        {"hare_voxel_pool_quad", &m->voxel_pool_quad},
+        {"hare_voxel_pool_tri_g", &m->voxel_pool_tri_g},
+        {"hare_voxel_pool_quad_g", &m->voxel_pool_quad_g},
         {"hare_octree_shoot", &m->octree},
         {"hare_octree_shoot_count", &m->octree_count},
         {"hare_octree_persist", &m->octree_persist},
@@ -297,6 +301,7 @@ int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, u
 // Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass when the process
 // opted in with HARE_DEV=1 (tools/, the cull-audit test), so a stray bit from a caller can never reach a kernel.
+constexpr bool kVoxelPoolDefault = false;   // which voxel kernel serves a batch by default (HARE_VOXEL_KERNEL=pool|persist overrides)
 constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS;
 uint32_t sanitize_flags(uint32_t flags)
 {
@@ -413,9 +418,39 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             void* args[] = {&g, &io};
             return launch(H, f, grid, block, 0, st, args);
         }
-        // persistent kernel: a grid that just fills the chip; waves draw ray chunks from a ticket
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;     // the occupancy bitmap, <= 64 KB (occ_layout)
         const bool coarse = s.occ_shift > 0;
+        // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
+        {
+            const char* vk = getenv("HARE_VOXEL_KERNEL");
+            const bool want_pool = vk ? strcmp(vk, "pool") == 0 : kVoxelPoolDefault;
+            const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
+            hipFunction_t pf = !coarse ? (quads ? M.voxel_pool_quad : M.voxel_pool_tri) : (quads ? M.voxel_pool_quad_g : M.voxel_pool_tri_g);
+            if (want_pool && pf && plds <= 160u * 1024u && s.vox.ct <= 1023 && !(flags & 0x6000u)) {
+                unsigned pgrid = (unsigned)std::max(1, M.cu_count);
+                pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
+                if (pgrid == 0) pgrid = 1;
+                const unsigned slot = s.work_slot.fetch_add(1) % 64u;
+                io.part = nullptr;
+                if (io.ctr) {
+                    if (!M.ctr_reduce || !s.d_part) {
+                        set_error("hare_shoot: counter-reduce kernel missing from code object");
+                        return HARE_E_STATE;
+                    }
+                    pgrid = std::min(pgrid, kPartWaves / (unsigned)kPoolWaves);
+                    io.part = (unsigned long long*)s.d_part + (size_t)slot * kPartWaves * 2;
+                }
+                io.ticket_rays = n < 1572864 ? 32 : (n < 6291456 ? 64 : 128);
+                if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
+                io.work = (unsigned int*)s.d_work + slot;
+                HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+                void* args[] = {&g, &io};
+                int rc = launch(H, pf, pgrid, 64u * (unsigned)kPoolWaves, plds, st, args);
+                if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * (unsigned)kPoolWaves, st);
+                return rc;
+            }
+        }
+        // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
         unsigned per_cu = 4;
         if (tune_blocks_per_cu) per_cu = tune_blocks_per_cu;
         if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(160 * 1024 / lds));

@@ -1014,4 +1014,5 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 
 }  // extern "C"
 
+#include "voxel_pool.hip"
 #include "build_kernels.hip"

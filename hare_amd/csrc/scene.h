@@ -68,6 +68,7 @@ struct DeviceModule {
     hipFunction_t voxel_tri = nullptr, voxel_quad = nullptr, voxel_count = nullptr;
     hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
+    hipFunction_t voxel_pool_tri = nullptr, voxel_pool_quad = nullptr, voxel_pool_tri_g = nullptr, voxel_pool_quad_g = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, ctr_reduce = nullptr, occlusion = nullptr;

@@ -311,6 +311,18 @@ class Voxel_Grid(Spatial_Partition):
         i = self.info()
         return tuple(int(np.floor((Pt[a] - i.obox_min[a]) / i.voxel_dims[a])) for a in range(3))
 
+    def PointInVoxel_code(self, Pt) -> int:
+        """int Voxel_Grid.PointInVoxel(Point) (Voxel_Grid.cs:329-332): the VoxelCode of the voxel holding Pt."""
+        return self.VoxelCode(*self.PointInVoxel(Pt))
+
+    def VoxelDecode(self, Code: int):
+        """Voxel_Grid.VoxelDecode (Voxel_Grid.cs:256-262) -> (X, Y, Z)."""
+        ct = self.VoxelCt
+        Z = Code // (ct * ct)
+        Code -= Z * ct * ct
+        Y = Code // ct
+        return Code - Y * ct, Y, Z
+
     def VoxelCode(self, X: int, Y: int, Z: int) -> int:
         """Voxel_Grid.VoxelCode (Voxel_Grid.cs:264-267): XYTot * Z + VoxelCtY * X + Y."""
         ct = self.VoxelCt

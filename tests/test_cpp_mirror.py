@@ -1,5 +1,6 @@
 """The C++ host-side mirror (bindings/cpp/hare.hpp) compiles against include/hare_hip.h, links the
-C-ABI library, and behaves like the reference interface.  Without a GPU its Shoot must throw."""
+C-ABI library, and behaves like the reference interface.  The single-ray Shoot runs on the host (hare_shoot_one)
+and works everywhere; the batch Shoot is GPU-only and must throw without a GPU."""
 import os
 import subprocess
 
@@ -21,8 +22,9 @@ def test_cpp_mirror_compiles_and_fails_loudly_without_gpu(tmp_path, gpu_availabl
     exe = build(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert "Char_Step = 0.5505" in r.stdout             # host build of the grid works everywhere
+    assert "hit poly" in r.stdout and "t = 1.5 " in r.stdout and "(2.000, 0.750, 1.000)" in r.stdout   # so does one ray
     if not gpu_available:
-        assert r.returncode == 2 and "no HIP device visible" in r.stdout
+        assert r.returncode == 2 and "no HIP device visible" in r.stdout and "batch:" not in r.stdout
 
 
 @pytest.mark.gpu
@@ -31,3 +33,4 @@ def test_cpp_mirror_shoots_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "hit poly" in r.stdout and "t = 1.5 " in r.stdout and "(2.000, 0.750, 1.000)" in r.stdout
+    assert "batch: 2 hits, t = 1.5 and 1" in r.stdout

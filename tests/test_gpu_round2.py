@@ -1,0 +1,231 @@
+"""GPU parity tests added in round 2: occlusion predicate (A9), the "retired ray" sentinel only in the bounce loop,
+hare_shoot_one == batch kernels, deep octrees (17+ levels), config 5 at its full per-GPU size, the caller's
+current device left alone."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import hare_amd as H
+from hare_amd import capi
+from oracle import pyoracle as po
+from tests.helpers import assert_events_equal, soup, soup_rays
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hall():
+    m = H.scenes.hall()
+    return m, H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+
+
+def test_occlusion_predicate_batch_and_device(hall):
+    """occluded = closest hit exists and t < t_max (harness-defined) -- pinned by the closest-hit oracle."""
+    import torch
+    m, T, To = hall
+    n = 300_000
+    rays = H.scenes.burst_rays(n, m.size)
+    rng = np.random.default_rng(4)
+    ref, _ = po.VoxelGrid([To], domain=64).shoot(rays, nthreads=16)
+    tmax = ref["t"] * rng.choice([0.5, 1.0, 1.5], n)          # before / exactly at (strict <: not occluded) / behind the hit
+    tmax[::11] = np.inf
+    tmax[5::11] = -1.0
+    g = H.Voxel_Grid([T], 64)
+    want = ((ref["hit"] != 0) & (ref["t"] < tmax)).astype(np.int32)
+    assert 0.2 < want.mean() < 0.8
+    occ, ev = g.Occluded_batch(rays, tmax)
+    assert_events_equal(ev, ref, what="occlusion: closest-hit records")
+    assert np.array_equal(occ, want)
+    occ_any, _ = g.Occluded_batch(rays)                       # t_max None: any hit
+    assert np.array_equal(occ_any, (ref["hit"] != 0).astype(np.int32))
+    # device-resident form
+    d_rays = torch.from_numpy(rays).cuda()
+    d_tmax = torch.from_numpy(tmax).cuda()
+    d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    d_occ = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    g.occluded_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_occ.data_ptr(), d_tmax=d_tmax.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_occ.cpu().numpy(), want)
+    assert np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE).tobytes() == ref.tobytes()
+    # octree path: same predicate on ITS closest-hit records (which differ from the grid's)
+    oc = H.Octree([T], 8, 16)
+    refo, _ = po.Octree([To], 8, 16).shoot(rays[:50_000], nthreads=16)
+    occ, ev = oc.Occluded_batch(rays[:50_000], tmax[:50_000])
+    assert_events_equal(ev, refo, what="occlusion: octree records")
+    assert np.array_equal(occ, ((refo["hit"] != 0) & (refo["t"] < tmax[:50_000])).astype(np.int32))
+
+
+def test_negative_poly_origin_is_no_exclusion_outside_the_bounce_loop(hall):
+    """Shoot(R, 0, out e, -2) == Shoot(R, 0, out e): the reference compares indices only (Voxel_Grid.cs:477).  The -2
+    'retired' mark of hare_reflect_device is honoured only with HARE_SHOOT_RETIRED_RAYS on the device-resident call."""
+    import torch
+    m, T, To = hall
+    n = 50_000
+    rays = H.scenes.burst_rays(n, m.size)
+    e1 = np.full(n, -2, np.int32)
+    e1[::3] = -7
+    for part in (H.Voxel_Grid([T], 64), H.Octree([T], 8, 16)):
+        plain, c0 = part.Shoot_batch(rays)
+        neg, c1 = part.Shoot_batch(rays, poly_origin1=e1)
+        assert neg.tobytes() == plain.tobytes() and c1["rays"] == n and c1["hits"] == c0["hits"]
+        d_rays = torch.from_numpy(rays).cuda()
+        d_e1 = torch.from_numpy(e1).cuda()
+        d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+        d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        part.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_e1.data_ptr(), d_counters=d_ctr.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        assert d_ev.cpu().numpy().tobytes() == plain.tobytes() and int(d_ctr[0]) == n
+        d_ctr.zero_()
+        part.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_e1.data_ptr(), d_counters=d_ctr.data_ptr(), stream=st,
+                          flags=capi.SHOOT_RETIRED_RAYS)
+        torch.cuda.synchronize()
+        ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE)
+        dead = e1 == -2
+        assert not ev["hit"][dead].any() and (ev["poly_id"][dead] == -1).all()
+        assert ev[~dead].tobytes() == plain[~dead].tobytes()
+        assert int(d_ctr[0]) == int((~dead).sum())            # retired rays are not counted
+
+
+def test_developer_flag_bits_are_masked_without_HARE_DEV(hall, monkeypatch):
+    monkeypatch.delenv("HARE_DEV", raising=False)
+    m, T, _ = hall
+    rays = H.scenes.burst_rays(20_000, m.size)
+    g = H.Voxel_Grid([T], 64)
+    plain, _ = g.Shoot_batch(rays)
+    out = np.zeros(len(rays), capi.XEVENT_DTYPE)
+    ctr = capi.Counters()
+    for bits in (0x2000, 0x4000, 0x8000, 0xFFFFFFF0):
+        capi.check(capi.lib.hare_shoot_batch(g._h, 0, 0, len(rays), rays.ctypes.data, None, None, bits, out.ctypes.data,
+                                             C.addressof(ctr)))
+        assert out.tobytes() == plain.tobytes() and ctr.rays == len(rays)
+
+
+def test_shoot_one_equals_the_batch_kernels(hall):
+    """The host single-ray path and the HIP batch path are the same function of (scene, ray): 20k rays each way."""
+    m, T, _ = hall
+    rays = H.scenes.burst_rays(1 << 20, m.size)[:: (1 << 20) // 20_000].copy()
+    for part in (H.Voxel_Grid([T], 64), H.Octree([T], 8, 16)):
+        batch, _ = part.Shoot_batch(rays)
+        one = np.zeros(len(rays), capi.XEVENT_DTYPE)
+        r = rays.copy()
+        for i in range(len(rays)):
+            one[i] = part.Shoot_one(r[i])
+        assert one.tobytes() == batch.tobytes()
+
+
+def deep_scene(depth, seed=1):
+    """A scene whose octree really reaches `depth` levels without exploding.  The reference pads every child box by an
+    ABSOLUTE 0.1 m ("Octree - alt.cs":99-111), so node size tends to 0.4 m and below that every polygon lands in all 8
+    children: a deep tree is only finite when the model is huge (here 0.4 * 2^(depth-2) m) and the crowded spots tiny."""
+    rng = np.random.default_rng(seed)
+    E = 0.4 * 2.0 ** (depth - 2)
+    tris = [np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], float),               # pins the model's min corner
+            np.array([[E, E, E], [E - 1, E, E], [E, E - 1, E]], float)]
+    centres = rng.uniform(0.1, 0.9, (6, 3)) * E
+    for c in centres:
+        for _ in range(3):                                                      # three tiny triangles within a few cm
+            tris.append(c + rng.uniform(-0.03, 0.03, 3) + rng.uniform(-0.02, 0.02, (3, 3)))
+    v = np.zeros((len(tris), 4, 3))
+    v[:, :3] = H.scenes.snap(np.array(tris))
+    nv = np.full(len(tris), 3, np.int32)
+    o = np.concatenate([centres[rng.integers(0, 6, 3000)] + rng.normal(size=(3000, 3)) * 2.0, rng.uniform(0, 1, (1000, 3)) * E])
+    tgt = centres[rng.integers(0, 6, 4000)] + rng.uniform(-0.03, 0.03, (4000, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return v, nv, np.ascontiguousarray(np.concatenate([o, d], 1))
+
+
+def tree_depth(fc):
+    depth, level = 0, [0]
+    while level:
+        nxt = [c for n in level if fc[n] >= 0 for c in range(fc[n], fc[n] + 8)]
+        if nxt:
+            depth += 1
+        level = nxt
+    return depth
+
+
+@pytest.mark.parametrize("depth,maxp", [(17, 1), (20, 2), (24, 1)])
+def test_deep_octrees_17_to_24_levels(depth, maxp):
+    """maxDepth above the 16 levels round 1's persistent kernel stopped at, on trees that really get that deep:
+    persistent, simple and counting kernels vs the oracle."""
+    v, nv, rays = deep_scene(depth)
+    g = H.Octree([H.Topology(v, nv)], depth, maxp)
+    o = po.Octree([po.Topology(v, nv)], depth, maxp)
+    _, fc, _, _, _ = g.nodes()
+    assert g.info().n_nodes == o.n_nodes and tree_depth(fc) == depth
+    ref, rc = o.shoot(rays)
+    assert 100 < ref["hit"].sum() < len(rays)
+    assert_events_equal(g.Shoot_batch(rays)[0], ref, what=f"octree depth {depth} (persistent)")
+    assert_events_equal(g.Shoot_batch(rays, simple_kernel=True)[0], ref, what=f"octree depth {depth} (simple)")
+    ev, ctr = g.Shoot_batch(rays, count_work=True)
+    assert_events_equal(ev, ref, what=f"octree depth {depth} (counting)")
+    assert ctr["cells"] == rc["cells"] and ctr["entries"] == rc["entries"]
+
+
+def test_octree_depth_beyond_the_supported_range_is_a_clean_error():
+    v, nv, _ = soup(20, 0)
+    with pytest.raises(H.HareError) as ei:
+        H.Octree([H.Topology(v, nv)], 25, 1)
+    assert ei.value.code == capi.HARE_E_INVALID and "max_depth" in str(ei.value)
+
+
+def test_calls_leave_the_callers_current_device_alone(hall):
+    """Every entry point acts on the scene's device and restores the calling thread's current device (one GPU here:
+    what can be checked is that torch's current device and stream are as before, and that a scene on an ordinal
+    that does not exist is refused with a code, not a crash)."""
+    import torch
+    m, T, _ = hall
+    before = torch.cuda.current_device()
+    g = H.Voxel_Grid([T], 16)
+    g.Shoot_batch(H.scenes.burst_rays(1000, m.size))
+    g.close()
+    assert torch.cuda.current_device() == before
+    with pytest.raises(H.HareError) as ei:
+        H.Voxel_Grid([T], 16, device=63)
+    assert ei.value.code in (capi.HARE_E_INVALID, capi.HARE_E_HIP)
+    assert torch.cuda.current_device() == before
+
+
+def test_bounce_c5_full_size_1M_rays_x8_1M_tris():
+    """BASELINE config[4] at its per-GPU size: 1 048 576 rays x 8 specular bounces in the 1M-triangle cathedral, D = 128,
+    device-resident; the events of EVERY bounce equal the oracle's, retired rays come back as X_Event()."""
+    import torch
+    m = H.scenes.cathedral()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    n, bounces = 1 << 20, 8
+    rays = H.scenes.burst_rays(8 << 20, m.size, start=3 << 20, count=n)     # one rank's shard of the 8M-ray burst
+    g = H.Voxel_Grid([T], 128)
+    o = po.VoxelGrid([To], domain=128)
+    d_rays = torch.from_numpy(rays.copy()).cuda()
+    d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    d_ex = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cur, excl = rays.copy(), np.full(n, -1, np.int32)
+    dead = np.zeros(n, bool)
+    casts = hits = 0
+    for b in range(bounces):
+        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), d_counters=d_ctr.data_ptr(), stream=st,
+                       flags=capi.SHOOT_RETIRED_RAYS)
+        g.reflect_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_ex.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE)
+        live = ~dead
+        ref = np.zeros(n, po.XEVENT_DTYPE)
+        ref["poly_id"] = -1
+        ref[live], c = o.shoot(cur[live], excl1=excl[live], nthreads=16)
+        casts += c["rays"]
+        hits += c["hits"]
+        assert_events_equal(ev, ref, what=f"C5 full size, bounce {b}")
+        alive = (ref["hit"] == 1) & live
+        cur = po.reflect_batch(To, cur, ref)
+        excl = np.where(alive, ref["poly_id"], -2).astype(np.int32)
+        dead |= ~alive
+        assert np.array_equal(d_rays.cpu().numpy(), cur)
+        assert np.array_equal(d_ex.cpu().numpy(), excl)
+    assert (int(d_ctr[0]), int(d_ctr[1])) == (casts, hits)
+    assert dead.mean() < 0.01
