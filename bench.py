@@ -200,20 +200,17 @@ def main() -> None:
     if args.kind == "voxel":
         part = H.Voxel_Grid([topo], args.domain, device=device)
         kdesc = f"Voxel_Grid Domain={args.domain}"
-        coarse = args.domain > 80
-        kernel_name = "hare_voxel_persist_tri_g" if coarse else "hare_voxel_persist_tri"
     elif args.kind == "octree":
         part = H.Octree([topo], 8, 16, device=device)
         kdesc = "Octree maxDepth=8 maxPolys=16"
-        kernel_name = "hare_octree_persist"
     else:
         part = H.KDTree([topo], 12, 16, device=device)
         kdesc = "KDTree maxDepth=12 maxPolys=16"
-        kernel_name = "hare_kdtree_shoot"
     build_s = time.time() - t0
 
     n = args.rays
     B = args.bounces
+    kernel_name = part.kernel_name(n)
     n_total = n * world
     lo, hi = shard_range(n_total, rank, world)
     rays_h = H.scenes.burst_rays(n_total, mesh.size, start=lo, count=hi - lo)

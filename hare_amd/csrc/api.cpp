@@ -301,7 +301,23 @@ int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, u
 // Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass when the process
 // opted in with HARE_DEV=1 (tools/, the cull-audit test), so a stray bit from a caller can never reach a kernel.
-constexpr bool kVoxelPoolDefault = false;   // which voxel kernel serves a batch by default (HARE_VOXEL_KERNEL=pool|persist overrides)
+// Which production voxel kernel serves a batch (measured on MI355X): K1q (hare_voxel_pool_*, rays outnumber
+// lanes) wins once a launch is long enough for its steady state to outweigh its longer ramp and drain -- from ~1.5M
+// rays on a fine grid, and from 1M rays on the coarse-bitmap grids (D > 80), whose rays are several times longer; K1p
+// (hare_voxel_persist_*) below that.  HARE_VOXEL_KERNEL=pool|persist overrides (developer A/B).
+bool voxel_pool_wanted(int64_t n, bool coarse)
+{
+    if (const char* vk = getenv("HARE_VOXEL_KERNEL")) {
+        if (strcmp(vk, "pool") == 0) return true;
+        if (strcmp(vk, "persist") == 0) return false;
+    }
+    return n >= (coarse ? (1ll << 20) : 1572864ll);
+}
+bool voxel_pool_usable(const Scene& s, uint32_t flags)
+{
+    const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
+    return lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= 160u * 1024u && s.vox.ct <= 512 && !(flags & 0x4000u);
+}
 constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS;
 uint32_t sanitize_flags(uint32_t flags)
 {
@@ -422,11 +438,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         const bool coarse = s.occ_shift > 0;
         // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
         {
-            const char* vk = getenv("HARE_VOXEL_KERNEL");
-            const bool want_pool = vk ? strcmp(vk, "pool") == 0 : kVoxelPoolDefault;
             const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
             hipFunction_t pf = !coarse ? (quads ? M.voxel_pool_quad : M.voxel_pool_tri) : (quads ? M.voxel_pool_quad_g : M.voxel_pool_tri_g);
-            if (want_pool && pf && plds <= 160u * 1024u && s.vox.ct <= 1023 && !(flags & 0x6000u)) {
+            if (pf && voxel_pool_wanted(n, coarse) && voxel_pool_usable(s, flags)) {
+                if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
                 unsigned pgrid = (unsigned)std::max(1, M.cu_count);
                 pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
                 if (pgrid == 0) pgrid = 1;
@@ -1211,6 +1226,25 @@ int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_ray
     const unsigned block = 256;
     return launch(H, s->module->reflect, (unsigned)((n + block - 1) / block), block, 0, (hipStream_t)stream, args);
     GUARD_END
+}
+
+const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t top_index, int64_t n, uint32_t flags)
+{
+    if (!s || top_index < 0 || top_index >= (int32_t)s->topos.size()) return "";
+    flags = sanitize_flags(flags);
+    const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0, simple = (flags & HARE_SHOOT_SIMPLE_KERNEL) != 0;
+    const bool quads = s->topos[(size_t)top_index].has_quads;
+    if (kind == HARE_KIND_VOXEL) {
+        if (count) return "hare_voxel_shoot_count";
+        if (simple || n >= 0x7FFFFF00ll) return quads ? "hare_voxel_shoot_quad" : "hare_voxel_shoot_tri";
+        const bool coarse = s->occ_shift > 0;
+        if (voxel_pool_wanted(n, coarse) && voxel_pool_usable(*s, flags))
+            return !coarse ? (quads ? "hare_voxel_pool_quad" : "hare_voxel_pool_tri") : (quads ? "hare_voxel_pool_quad_g" : "hare_voxel_pool_tri_g");
+        return !coarse ? (quads ? "hare_voxel_persist_quad" : "hare_voxel_persist_tri") : (quads ? "hare_voxel_persist_quad_g" : "hare_voxel_persist_tri_g");
+    }
+    if (kind == HARE_KIND_OCTREE) return count ? "hare_octree_shoot_count" : ((simple || n >= 0x7FFFFF00ll) ? "hare_octree_shoot" : "hare_octree_persist");
+    if (kind == HARE_KIND_KDTREE) return count ? "hare_kdtree_shoot_count" : "hare_kdtree_shoot";
+    return "";
 }
 
 int hare_occluded_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, void* d_rays, const void* d_excl1,

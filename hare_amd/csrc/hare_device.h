@@ -107,15 +107,17 @@ static_assert(sizeof(OctTask) == 64, "octree task size");
 
 // K1q (voxel_pool.hip): launch geometry shared by the kernel and the host launcher
 #ifndef HARE_K1Q_WAVES
-#define HARE_K1Q_WAVES 8          // waves per workgroup (one workgroup per CU: 2 waves per SIMD)
+#define HARE_K1Q_WAVES 12         // waves per workgroup (one workgroup per CU: 3 waves per SIMD)
 #endif
 #ifndef HARE_K1Q_SLOTS
 #define HARE_K1Q_SLOTS 128        // rays per wave (power of two): 2 per lane
 #endif
 constexpr int kPoolWaves = HARE_K1Q_WAVES;
 constexpr int kPoolSlots = HARE_K1Q_SLOTS;
-constexpr int kPoolWaveBytes = kPoolSlots * (7 * 8 + 13 * 4 + 4 * 2);   // per wave: 7 doubles, 13 words, 4 queue entries per slot
-static_assert((kPoolSlots & (kPoolSlots - 1)) == 0 && kPoolSlots >= 64 && kPoolSlots <= 4096, "K1q slots: power of two, 64..4096");
+constexpr int kPoolRing = kPoolSlots <= 64 ? 64 : (kPoolSlots <= 128 ? 128 : 256);   // queue capacity: the power of two >= slots
+constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4) + 5 * kPoolRing;   // per wave: 6 doubles + 7 words per slot, 5 byte queues
+static_assert(kPoolSlots >= 64 && kPoolSlots <= 256 && kPoolSlots % 2 == 0, "K1q slots: even, 64..256");
+static_assert(kPoolWaveBytes % 8 == 0, "K1q: per-wave LDS block keeps the doubles aligned");
 
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN

@@ -92,7 +92,11 @@ struct DeviceGuard {
     {
         if (!H) return;
         if (H->GetDevice(&prev) != hipSuccess) { prev = -1; (void)H->GetLastError(); }
-        if (prev != device && H->SetDevice(device) == hipSuccess) switched = true;
+        if (prev != device) {
+            if (H->SetDevice(device) == hipSuccess) switched = true;
+            else (void)H->GetLastError();   // e.g. an ordinal that does not exist: the entry point reports it; the host's
+                                            // runtime must not be left with a sticky "last error" (torch checks it)
+        }
     }
     ~DeviceGuard()
     {

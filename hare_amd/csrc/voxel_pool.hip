@@ -3,21 +3,26 @@
 // Why: in K1p (hare_voxel_persist_*) a lane owns one ray, and a ray alternates between walking (~10 empty voxels),
 // culling (~3 candidates) and, rarely, an exact test -- so whatever phase the wave executes, about half of its
 // lanes hold a ray that is in another phase (measured: 40 % lane occupancy, 2.9x the instructions the work needs).
-// Here a wave owns a POOL of SLOTS rays (2 per lane) whose state lives in LDS, and three queues of slot numbers --
-// rays that have to walk, rays that hold candidates to cull, rays whose candidate survived the cull and needs the
-// exact test.  Each round the wave picks the fullest queue, pops up to 64 rays, and runs that ONE phase on them at
-// (nearly) full lane occupancy; rays move between queues as their phase changes, finished rays free their slot and
-// new rays are set up 64 at a time.  Pools and queues are private to a wave: no atomics, no barriers, no
-// inter-wave protocol -- queue heads and counts are wave-uniform scalars.
+// Here a wave owns a POOL of SLOTS rays (2 per lane) whose traversal state lives in LDS, and queues of slot numbers:
+//   walk   rays that cross empty voxels until the next non-empty one (no hit pending)
+//   cull   rays that hold candidates for the conservative FP32 pre-cull
+//   exact  rays whose candidate survived the cull and needs the reference's FP64 RayXtri
+//   pend   rays that hold a hit and walk on until a voxel contains the hit point (Voxel_Grid.cs:705), or the grid ends
+// Each round the wave picks a queue, pops up to 64 rays and runs that ONE phase on them at (nearly) full lane
+// occupancy; rays move between queues as their phase changes, finished rays free their slot and new rays are set up
+// 64 at a time.  Pools and queues are private to a wave: no atomics, no barriers, no inter-wave protocol -- queue
+// heads and counts are wave-uniform scalars.
 //
 // A ray's own sequence of operations is exactly K1p's (and therefore the reference's, Voxel_Grid.cs:561-761): same
 // cells in the same order, same candidate order, FP32 pre-cull in front of the exact RayXtri, pending-hit /
 // IsPointInBox rule, miss on grid exit; only the interleaving BETWEEN rays differs.
 //
-// LDS per workgroup: the occupancy bitmap (<= 64 KB) + per wave SLOTS x 116 B (7 doubles, 13 words, 4 queue entries).
-// o and d are NOT kept: the phases that need them (cull, exact) re-read the 48-byte ray record, which is
-// cache-resident for the ray's short life.  The ray's own X_Event slot is its scratch until it finishes: the pending
-// hit point, and for a ray whose origin AABB.Intersect moved, t_start and the moved origin.
+// State.  LDS per slot, 81 B: tMax, tDelta (6 doubles), ray index, packed voxel + flags, q, qe, idx, nexti, the last
+// polygon tested (7 words), one byte in each of the five queues.  o and d are not kept: cull and exact re-read the
+// 48-byte ray record (cache-resident for the ray's short life) in the same batch of loads as the polygon records.
+// The ray's own X_Event slot is its scratch until it finishes: .t = tmin of the hit so far (DBL_MAX: none),
+// .x .y .z = that hit's point, the {Hit, Poly_id} word = its polygon, .u = t_start of a ray whose origin
+// AABB.Intersect moved (the moved origin itself is o + d * t_start, the expression of AABB_Main.cs:254-256).
 #ifndef HARE_K1Q_WALK_STEPS
 #define HARE_K1Q_WALK_STEPS 16    // DDA steps per walk task at most
 #endif
@@ -28,10 +33,19 @@
 #define HARE_K1Q_CULL_PAIRS 2     // pairs of candidates per cull task
 #endif
 #ifndef HARE_K1Q_EXACT_MIN
-#define HARE_K1Q_EXACT_MIN 24     // run the exact phase when this many rays wait for it (or nothing else can run)
+#define HARE_K1Q_EXACT_MIN 40     // run the exact phase when this many rays wait for it (or nothing else can run)
+#endif
+#ifndef HARE_K1Q_PEND_MIN
+#define HARE_K1Q_PEND_MIN 16      // the same for the pending-hit walk
+#endif
+#ifndef HARE_K1Q_TAIL
+#define HARE_K1Q_TAIL 128         // tickets dry and at most this many rays left: every non-empty phase runs each round
+#endif
+#ifndef HARE_K1Q_TAIL_STEPS
+#define HARE_K1Q_TAIL_STEPS 32    // DDA steps per walk task in that regime
 #endif
 #ifndef HARE_K1Q_REFILL_MIN
-#define HARE_K1Q_REFILL_MIN 32    // set up new rays when this many slots are free
+#define HARE_K1Q_REFILL_MIN 64    // set up new rays when this many slots are free (a full wave of set-ups)
 #endif
 
 namespace {
@@ -40,7 +54,7 @@ template <bool QUADS, bool COARSE>
 __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr unsigned S = kPoolSlots, SM = kPoolSlots - 1;
+    constexpr unsigned S = kPoolSlots, R = kPoolRing, SM = kPoolRing - 1;   // slots; queue (ring) capacity and its mask
     uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);
     const int nw4 = (g.occ_words + 3) >> 2;
     {
@@ -58,40 +72,38 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     double* const L_tdx = L_tmz + S;
     double* const L_tdy = L_tdx + S;
     double* const L_tdz = L_tdy + S;
-    double* const L_tmin = L_tdz + S;
-    uint32_t* const L_ray = reinterpret_cast<uint32_t*>(L_tmin + S);
-    uint32_t* const L_xyz = L_ray + S;        // X | Y << 10 | Z << 20 | (dx<0) << 30 | (dy<0) << 31 ; (dz<0) is in L_flags
-    int32_t* const L_cell = reinterpret_cast<int32_t*>(L_xyz + S);
-    uint32_t* const L_q = reinterpret_cast<uint32_t*>(L_cell + S);
+    uint32_t* const L_ray = reinterpret_cast<uint32_t*>(L_tdz + S);
+    uint32_t* const L_xyzf = L_ray + S;       // X | Y << 9 | Z << 18 | flags (below)
+    uint32_t* const L_q = L_xyzf + S;
     uint32_t* const L_qe = L_q + S;
     int32_t* const L_idx = reinterpret_cast<int32_t*>(L_qe + S);
     int32_t* const L_nexti = L_idx + S;
-    int32_t* const L_pid = L_nexti + S;
-    int32_t* const L_e1 = L_pid + S;
-    int32_t* const L_e2 = L_e1 + S;
-    int32_t* const L_d1 = L_e2 + S;
-    int32_t* const L_d2 = L_d1 + S;
-    uint32_t* const L_flags = reinterpret_cast<uint32_t*>(L_d2 + S);   // bit0: dz<0, bit1: moved (t_start parked in out[ray].t)
-    uint16_t* const Q_walk = reinterpret_cast<uint16_t*>(L_flags + S);
-    uint16_t* const Q_cull = Q_walk + S;
-    uint16_t* const Q_exact = Q_cull + S;
-    uint16_t* const Q_free = Q_exact + S;
+    int32_t* const L_d1 = L_nexti + S;
+    uint8_t* const Q_walk = reinterpret_cast<uint8_t*>(L_d1 + S);
+    uint8_t* const Q_cull = Q_walk + R;
+    uint8_t* const Q_exact = Q_cull + R;
+    uint8_t* const Q_pend = Q_exact + R;
+    uint8_t* const Q_free = Q_pend + R;
+    constexpr uint32_t F_NX = 1u << 27, F_NY = 1u << 28, F_NZ = 1u << 29;   // direction component < 0 (Voxel_Grid.cs:589-632)
+    constexpr uint32_t F_MOVED = 1u << 30;                                   // origin clipped to OBox: t_start in the scratch
+    constexpr uint32_t F_HIT = 1u << 31;                                     // a hit is pending (tmin, point, polygon in the scratch)
 
-    for (unsigned k = lane; k < S; k += 64) Q_free[k] = (uint16_t)k;
+    for (unsigned k = lane; k < S; k += 64) Q_free[k] = (uint8_t)k;
     __syncthreads();      // the bitmap is shared by the workgroup; everything after this point is wave-private
 
     const int ct = g.ct;
     const double fct = (double)ct;
     // wave-uniform queue state
-    unsigned hW = 0, nW = 0, hC = 0, nC = 0, hE = 0, nE = 0, hF = 0, nF = S;
-    auto push = [&](uint16_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
+    unsigned hW = 0, nW = 0, hC = 0, nC = 0, hE = 0, nE = 0, hP = 0, nP = 0, hF = 0, nF = S;
+    auto push = [&](uint8_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
         const unsigned long long m = __ballot(flag);
-        if (flag) Q[(head + cnt + (unsigned)__popcll(m & lane_lt)) & SM] = (uint16_t)slot;
+        if (flag) Q[(head + cnt + (unsigned)__popcll(m & lane_lt)) & SM] = (uint8_t)slot;
         cnt += (unsigned)__popcll(m);
     };
-    auto pop = [&](const uint16_t* Q, unsigned& head, unsigned& cnt, unsigned n, bool& active) -> unsigned {
+    auto pop = [&](const uint8_t* Q, unsigned& head, unsigned& cnt, bool& active) -> unsigned {
+        const unsigned n = cnt < 64u ? cnt : 64u;
         active = lane < n;
-        const unsigned slot = active ? Q[(head + lane) & SM] : 0u;
+        const unsigned slot = Q[(head + (active ? lane : 0u)) & SM];
         head = (head + n) & SM;
         cnt -= n;
         return slot;
@@ -99,7 +111,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 
     // ray chunks: static first chunk per wave (XCD-contiguous), then tickets -- as in K1p
     const unsigned n32 = (unsigned)io.n;
-    const unsigned RAY_CHUNK = 128;
+#ifndef HARE_K1Q_STATIC
+#define HARE_K1Q_STATIC 128
+#endif
+    const unsigned RAY_CHUNK = HARE_K1Q_STATIC;
     const unsigned n_static = gridDim.x * (unsigned)kPoolWaves * RAY_CHUNK;
     unsigned chunk_id = blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave;
     if ((gridDim.x & 7u) == 0) chunk_id = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * (unsigned)kPoolWaves + (unsigned)wave;
@@ -108,48 +123,64 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     if (ce > n32) ce = n32;
     bool drained = false;
     unsigned nhits = 0, nrays = 0;
+    const bool writeback = (io.flags & SHOOT_WRITEBACK_ORIGIN) != 0;
 
     auto store_miss = [&](unsigned ray) {
         XEventRec ev;
         set_miss(ev);
         store_event_streaming(&io.out[ray], ev);
     };
-    // hit: X_Point is already in the record (written when the hit was accepted); t_start was parked in .t by the set-up
-    auto store_hit = [&](unsigned ray, bool moved, double tmin, int pid) {
-        double* q = reinterpret_cast<double*>(&io.out[ray]);
-        double t_start = 0;
-        if (moved) t_start = q[0];
-        q[0] = tmin + t_start;                                      // Voxel_Grid.cs:707
-        q[1] = 0;
-        q[2] = 0;
-        q[6] = __hiloint2double(1, pid);
-    };
     auto occupied = [&](int X, int Y, int Z, int cell) -> bool {
         const uint32_t bit = COARSE ? (uint32_t)(((X >> g.occ_shift) * g.occ_cd + (Y >> g.occ_shift)) * g.occ_cd + (Z >> g.occ_shift))
                                     : (uint32_t)cell;
         return (locc[bit >> 5] >> (bit & 31)) & 1u;
     };
+    // one DDA step, Voxel_Grid.cs:713-759 written with selects (same booleans, same order; see K1p)
+#define HARE_K1Q_STEP()                                                                          \
+    {                                                                                            \
+        const bool cxy = tMaxX < tMaxY, cxz = tMaxX < tMaxZ, cyz = tMaxY < tMaxZ;                \
+        const bool sx = cxy & cxz;                                                               \
+        const bool sy = (!cxy) & cyz;                                                            \
+        const bool sz = !(sx | sy);                                                              \
+        const double nX = tMaxX + tDeltaX, nY = tMaxY + tDeltaY, nZ = tMaxZ + tDeltaZ;           \
+        X += sx ? dx1 : 0;                                                                       \
+        Y += sy ? dy1 : 0;                                                                       \
+        Z += sz ? dz1 : 0;                                                                       \
+        tMaxX = sx ? nX : tMaxX;                                                                 \
+        tMaxY = sy ? nY : tMaxY;                                                                 \
+        tMaxZ = sz ? nZ : tMaxZ;                                                                 \
+    }
 
+    // developer timeline (flag 0x2000, tools/timeline_prof.py): per wave {start, tickets dry, end, rounds} on the 100 MHz clock
+    auto timeline = [&](int slot, unsigned long long v) {
+        if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
+            if (lane == 0) io.prof[32 + 4ull * (blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave) + slot] = v;
+        }
+    };
+    timeline(0, __builtin_amdgcn_s_memrealtime());
+    unsigned rounds_done = 0;
     // a wave serves ~n / (waves in the grid) rays in a few rounds each; the cap only exists so that a defect can never
     // turn into a wave that does not finish (rays it left behind would keep their scratch values and fail every parity test)
     for (unsigned round = 0; round < (1u << 24); ++round) {
         // ------------------------------------------------------------------ set-up of new rays into free slots
-        if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE == 0)) {
+        if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP == 0)) {
             if (cn >= ce) {
                 unsigned base = 0;
                 const unsigned dyn = (unsigned)io.ticket_rays;
                 if (lane == 0) base = atomicAdd(io.work, dyn);
                 base = __shfl(base, 0, 64);
                 cn = base + n_static;
-                if (cn >= n32) { drained = true; cn = ce = n32; }
+                if (cn >= n32) { drained = true; cn = ce = n32; timeline(1, __builtin_amdgcn_s_memrealtime()); }
                 else ce = (n32 - cn > dyn) ? cn + dyn : n32;
             }
             unsigned m = ce - cn;
             if (m > 64u) m = 64u;
             if (m > nF) m = nF;
             if (m > 0) {
-                bool act;
-                const unsigned slot = pop(Q_free, hF, nF, m, act);
+                const bool act = lane < m;
+                const unsigned slot = Q_free[(hF + (act ? lane : 0u)) & SM];
+                hF = (hF + m) & SM;
+                nF -= m;
                 const unsigned ray = cn + lane;
                 cn += m;
                 bool to_walk = false, to_cull = false, freed = false;
@@ -158,11 +189,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     const RayRec r = io.rays[ray];
                     V3 o = {r.x, r.y, r.z};
                     const V3 d = {r.dx, r.dy, r.dz};
-                    const int e1 = io.excl1 ? io.excl1[ray] : -1;
-                    const int e2 = io.excl2 ? io.excl2[ray] : -1;
                     bool alive = true, moved = false;
-                    if (e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {      // retired by the bounce loop: miss, not counted
-                        store_miss(ray);
+                    double t_start = 0;
+                    if ((io.flags & SHOOT_RETIRED_RAYS) && io.excl1 && io.excl1[ray] == -2) {   // retired by the bounce loop: miss, not counted
                         alive = false;
                     } else {
                         nrays++;
@@ -171,32 +200,16 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         double fz = floor((o.z - g.omin[2]) / g.vd[2]);
                         bool inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
                         if (!inside) {
-                            double t_start = 0;
                             if (!aabb_clip_move(g.omin, g.omax, o, d, t_start)) {
-                                store_miss(ray);
                                 alive = false;
                             } else {
                                 moved = true;
-                                if (io.flags & SHOOT_WRITEBACK_ORIGIN) {
-                                    io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z;
-                                }
+                                if (writeback) { io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z; }
                                 fx = floor((o.x - g.omin[0] + d.x * 1E-6) / g.vd[0]);
                                 fy = floor((o.y - g.omin[1] + d.y * 1E-6) / g.vd[1]);
                                 fz = floor((o.z - g.omin[2] + d.z * 1E-6) / g.vd[2]);
                                 inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
-                                if (!inside) {
-                                    store_miss(ray);
-                                    alive = false;
-                                } else {
-                                    // the ray's own X_Event slot is its scratch until it finishes: .t = t_start (added to the
-                                    // hit's t, Voxel_Grid.cs:707), .u .v + the {Poly_id, Hit} word = the moved origin (the cull and
-                                    // exact phases re-read the origin instead of keeping it), .x .y .z = the pending hit point
-                                    double* sc = reinterpret_cast<double*>(&io.out[ray]);
-                                    sc[0] = t_start;
-                                    sc[1] = o.x;
-                                    sc[2] = o.y;
-                                    sc[6] = o.z;
-                                }
+                                if (!inside) alive = false;
                             }
                         }
                         if (alive) {
@@ -211,13 +224,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                             else         { tMaxZ = (voxel_hi(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * 1.0; }
                             L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
                             L_tdx[slot] = tDeltaX; L_tdy[slot] = tDeltaY; L_tdz[slot] = tDeltaZ;
-                            L_tmin[slot] = kDblMax;
                             L_ray[slot] = ray;
-                            L_xyz[slot] = (uint32_t)X | ((uint32_t)Y << 10) | ((uint32_t)Z << 20) | (d.x < 0 ? 1u << 30 : 0u) | (d.y < 0 ? 1u << 31 : 0u);
-                            L_cell[slot] = cell;
-                            L_pid[slot] = -1;
-                            L_e1[slot] = e1; L_e2[slot] = e2; L_d1[slot] = -1; L_d2[slot] = -1;
-                            L_flags[slot] = (d.z < 0 ? 1u : 0u) | (moved ? 2u : 0u);
+                            L_xyzf[slot] = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (d.x < 0 ? F_NX : 0u) | (d.y < 0 ? F_NY : 0u) |
+                                           (d.z < 0 ? F_NZ : 0u) | (moved ? F_MOVED : 0u);
+                            L_d1[slot] = -1;
+                            double* sc = reinterpret_cast<double*>(&io.out[ray]);      // the ray's scratch (see the header)
+                            sc[0] = kDblMax;
+                            if (moved) sc[1] = t_start;
                             unsigned q = 0, qe = 0;
                             int idx = -1, nexti = -1;
                             if (occupied(X, Y, Z, cell)) {
@@ -229,41 +242,175 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                             to_walk = !to_cull;
                         }
                     }
-                    freed = !alive;
+                    if (!alive) {
+                        store_miss(ray);
+                        freed = true;
+                    }
                 }
                 push(Q_walk, hW, nW, to_walk, slot);
                 push(Q_cull, hC, nC, to_cull, slot);
                 push(Q_free, hF, nF, freed, slot);
             }
         }
-        if (nW + nC + nE == 0) {
+        if (nW + nC + nE + nP == 0) {
             if (drained) break;
             continue;
         }
+        ++rounds_done;
 
         // ------------------------------------------------------------------ pick the phase for this round
-        const bool do_exact = nE >= (unsigned)HARE_K1Q_EXACT_MIN || (nW + nC == 0);
-        const bool do_cull = !do_exact && nC > 0 && (nC >= nW || nC >= 64u);
-        if (do_exact) {
+        // Normally ONE phase per round, the one that fills the lanes best.  Once the tickets are dry and few rays are
+        // left, every non-empty phase runs each round, in the order a ray passes through them (walk -> cull -> exact ->
+        // pend), so that a ray advances several phases per round: at the end of a launch latency is all that counts.
+        const unsigned big = nW > nC ? nW : nC;
+        const bool tail = drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_TAIL;
+        const int sel = (nE >= (unsigned)HARE_K1Q_EXACT_MIN || (big == 0 && nP == 0)) ? 0
+                        : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
+        if (tail ? nW > 0 : sel == 3) {
+            // -------------------------------------------------------------- DDA walk over empty voxels (no hit pending)
+            bool act;
+            const unsigned slot = pop(Q_walk, hW, nW, act);
+            bool walking = act;
+            double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0;
+            int X = 0, Y = 0, Z = 0, dx1 = 1, dy1 = 1, dz1 = 1;
+            uint32_t xf = 0;
+            if (act) {
+                tMaxX = L_tmx[slot]; tMaxY = L_tmy[slot]; tMaxZ = L_tmz[slot];
+                tDeltaX = L_tdx[slot]; tDeltaY = L_tdy[slot]; tDeltaZ = L_tdz[slot];
+                xf = L_xyzf[slot];
+                X = (int)(xf & 511u); Y = (int)((xf >> 9) & 511u); Z = (int)((xf >> 18) & 511u);
+                dx1 = (xf & F_NX) ? -1 : 1; dy1 = (xf & F_NY) ? -1 : 1; dz1 = (xf & F_NZ) ? -1 : 1;
+            }
+            // the task ends early once few of its lanes still walk (the others have found their voxel): a third of what it
+            // started with, so that a thin batch -- the end of the launch -- is not cut down to one step per round
+            const int n0 = __popcll(__ballot(walking));
+            const int walk_min = tail ? 1 : (n0 / 3 < HARE_K1Q_WALK_MIN ? n0 / 3 : HARE_K1Q_WALK_MIN);
+            const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : HARE_K1Q_WALK_STEPS;   // end of the launch: fewer, longer tasks
+#pragma unroll 1
+            for (int k = 0; k < walk_steps; ++k) {
+                const unsigned long long wm = __ballot(walking);
+                if (wm == 0 || (k > 0 && __popcll(wm) < walk_min)) break;
+                if (walking) {
+                    HARE_K1Q_STEP();
+                    const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
+                    const int cell = out ? 0 : (X * ct + Y) * ct + Z;
+                    const bool occ = occupied(out ? 0 : X, out ? 0 : Y, out ? 0 : Z, cell);
+                    walking = !out && !occ;
+                }
+            }
+            const bool exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
+            bool to_cull = act && !walking && !exited;
+            if (exited) store_miss(L_ray[slot]);                            // leaving the grid: miss
+            unsigned q = 0, qe = 0;
+            int idx = -1, nexti = -1;
+            if (to_cull) {
+                const CellRec c = g.cells[(X * ct + Y) * ct + Z];
+                q = c.start; qe = c.start + c.count; idx = c.i0; nexti = c.i1;
+                if (COARSE && c.count == 0) { to_cull = false; walking = true; }   // the block is occupied, this voxel is not: walk on
+            }
+            if (act && !exited) {
+                L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
+                L_xyzf[slot] = (xf & 0xF8000000u) | (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18);
+                if (to_cull) { L_q[slot] = q; L_qe[slot] = qe; L_idx[slot] = idx; L_nexti[slot] = nexti; }
+            }
+            push(Q_walk, hW, nW, walking, slot);                            // still walking: next round
+            push(Q_cull, hC, nC, to_cull, slot);
+            push(Q_free, hF, nF, exited, slot);
+        }
+        if (tail ? nC > 0 : sel == 2) {
+            // -------------------------------------------------------------- FP32 pre-cull, 2 x CULL_PAIRS candidates per ray at most
+            bool act;
+            const unsigned slot = pop(Q_cull, hC, nC, act);
+            bool to_walk = false, to_cull = false, to_exact = false, to_pend = false;
+            if (act) {
+                const unsigned ray = L_ray[slot];
+                unsigned q = L_q[slot];
+                const unsigned qe = L_qe[slot];
+                int idx = L_idx[slot], nexti = L_nexti[slot], done1 = L_d1[slot];
+                const uint32_t xf = L_xyzf[slot];
+                int e1 = -1, e2 = -1;
+                if (io.excl1) e1 = io.excl1[ray];                           // poly_origin1 / 2 (Voxel_Grid.cs:477); wave-uniform branches
+                if (io.excl2) e2 = io.excl2[ray];
+                const RayRec r = io.rays[ray];
+                double ox = r.x, oy = r.y, oz = r.z;
+                if ((xf & F_MOVED) && !writeback) {
+                    const double ts = reinterpret_cast<const double*>(&io.out[ray])[1];
+                    ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
+                }
+                const float dfx = (float)r.dx, dfy = (float)r.dy, dfz = (float)r.dz;
+                const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                bool culling = true, parked = false;
+#pragma unroll
+                for (int kp = 0; kp < HARE_K1Q_CULL_PAIRS; ++kp) {
+                    // candidates idx (at q) and nexti (at q + 1): both records and the two list entries after them are
+                    // requested together; everything below is straight-line selects (a lane that is done computes on its
+                    // stale, still valid indices and keeps nothing)
+                    const bool has1 = q + 1 < qe;
+                    const unsigned qa = q + 2 < qe ? q + 2 : qe - 1, qb = q + 3 < qe ? q + 3 : qe - 1;
+                    const int i2 = g.items[qa], i3 = g.items[qb];
+                    const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;   // a finished lane may hold -1: stay inside the array
+                    const unsigned char* reca = reinterpret_cast<const unsigned char*>(g.polys + ia);
+                    const unsigned char* recb = reinterpret_cast<const unsigned char*>(g.polys + ib);
+                    const double2 a0 = *reinterpret_cast<const double2*>(reca);          // v0.x v0.y
+                    const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);         // v0.z | e1f.x e1f.y
+                    const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);       // e1f.z e2f.x e2f.y e2f.z
+                    const float2 a3 = *reinterpret_cast<const float2*>(reca + 48);       // ee emax
+                    const double2 b0 = *reinterpret_cast<const double2*>(recb);
+                    const uint4 b1 = *reinterpret_cast<const uint4*>(recb + 16);
+                    const float4 b2 = *reinterpret_cast<const float4*>(recb + 32);
+                    const float2 b3 = *reinterpret_cast<const float2*>(recb + 48);
+                    const float ae1[3] = {__uint_as_float(a1.z), __uint_as_float(a1.w), a2.x}, ae2[3] = {a2.y, a2.z, a2.w};
+                    const float be1[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), b2.x}, be2[3] = {b2.y, b2.z, b2.w};
+                    const bool ca = cull_fp32((float)(ox - a0.x), (float)(oy - a0.y), (float)(oz - __hiloint2double((int)a1.y, (int)a1.x)),
+                                              dfx, dfy, dfz, dm, ae1, ae2, a3.x, a3.y);
+                    const bool cb = cull_fp32((float)(ox - b0.x), (float)(oy - b0.y), (float)(oz - __hiloint2double((int)b1.y, (int)b1.x)),
+                                              dfx, dfy, dfz, dm, be1, be2, b3.x, b3.y);
+                    // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the one this ray
+                    // tested last is exact (Voxel_Grid.cs:477 + K1p's register mailbox)
+                    const bool sk0 = idx == e1 || idx == e2 || idx == done1;
+                    const bool keep0 = culling && !sk0 && !ca;              // candidate 0 survives: it goes to the exact phase
+                    const bool step0 = culling && !keep0;                   // candidate 0 consumed
+                    const int dn0 = (step0 && !sk0) ? idx : done1;          // a certain miss counts as tested
+                    const bool go1 = step0 && has1;
+                    const bool sk1 = nexti == e1 || nexti == e2 || nexti == dn0;
+                    const bool keep1 = go1 && !sk1 && !cb;
+                    const bool step1 = go1 && !keep1;
+                    done1 = (step1 && !sk1) ? nexti : dn0;
+                    q += (step0 ? 1u : 0u) + (step1 ? 1u : 0u);
+                    const int nidx = step1 ? i2 : (step0 ? nexti : idx);
+                    const int nnext = step1 ? i3 : (step0 ? i2 : nexti);
+                    idx = nidx; nexti = nnext;
+                    parked = parked || keep0 || keep1;
+                    culling = culling && !keep0 && !keep1 && q < qe;
+                }
+                L_q[slot] = q; L_idx[slot] = idx; L_nexti[slot] = nexti; L_d1[slot] = done1;
+                to_exact = parked;
+                to_cull = culling;                                          // quota used up, list not exhausted
+                const bool exhausted = !parked && !culling;
+                to_pend = exhausted && (xf & F_HIT);
+                to_walk = exhausted && !(xf & F_HIT);
+            }
+            push(Q_walk, hW, nW, to_walk, slot);
+            push(Q_cull, hC, nC, to_cull, slot);
+            push(Q_exact, hE, nE, to_exact, slot);
+            push(Q_pend, hP, nP, to_pend, slot);
+        }
+        if (tail ? nE > 0 : sel == 0) {
             // -------------------------------------------------------------- exact FP64 test of one candidate per ray
             bool act;
-            const unsigned slot = pop(Q_exact, hE, nE, nE < 64u ? nE : 64u, act);
-            bool to_walk = false, to_cull = false;
+            const unsigned slot = pop(Q_exact, hE, nE, act);
+            bool to_walk = false, to_cull = false, to_pend = false;
             if (act) {
                 const unsigned ray = L_ray[slot];
                 const int i = L_idx[slot];
                 unsigned q = L_q[slot];
                 const unsigned qe = L_qe[slot];
-                const double tmin = L_tmin[slot];
-                int after = -1;                                             // items[q + 2]: nexti once this candidate is done
-                if (q + 2 < qe) after = g.items[q + 2];
+                uint32_t xf = L_xyzf[slot];
+                double* sc = reinterpret_cast<double*>(&io.out[ray]);
+                const unsigned qa = q + 2 < qe ? q + 2 : qe - 1;
+                const int after = g.items[qa];                              // items[q + 2]: nexti once this candidate is done
+                const double tmin = sc[0];
                 const RayRec r = io.rays[ray];
-                V3 o = {r.x, r.y, r.z};
-                if (L_flags[slot] & 2u) {                                   // origin was clipped to OBox (AABB_Main.cs:254-257)
-                    const double* sc = reinterpret_cast<const double*>(&io.out[ray]);
-                    o.x = sc[1]; o.y = sc[2]; o.z = sc[6];
-                }
-                const V3 d = {r.dx, r.dy, r.dz};
                 const PolyRec& p = g.polys[i];
                 const double v0[3] = {p.v0[0], p.v0[1], p.v0[2]}, v1[3] = {p.v1[0], p.v1[1], p.v1[2]};
                 const double v2[3] = {p.v2[0], p.v2[1], p.v2[2]}, nn[3] = {p.n[0], p.n[1], p.n[2]};
@@ -276,6 +423,12 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         qnv = qr.nverts;
                     }
                 }
+                V3 o = {r.x, r.y, r.z};
+                const V3 d = {r.dx, r.dy, r.dz};
+                if ((xf & F_MOVED) && !writeback) {                         // AABB_Main.cs:254-256, same expression => same bits
+                    const double ts = sc[1];
+                    o.x = o.x + d.x * ts; o.y = o.y + d.y * ts; o.z = o.z + d.z * ts;
+                }
                 const bool side = ray_side(d, nn);                          // Polygons.cs:641-648
                 double a[3], c[3];
 #pragma unroll
@@ -287,207 +440,106 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if (!ok && qnv == 4) ok = tri_fast(o, d, c, v3, a, t);     // (P2,P3,P0) / (P0,P3,P2)
                 }
                 if (ok && t > kTMin && t < tmin) {                              // Voxel_Grid.cs:691-693
-                    L_tmin[slot] = t;
-                    L_pid[slot] = i;
-                    XEventRec* e = &io.out[ray];
-                    // X_Point of the pending hit (Polygons.cs:652); .t is left alone: it may hold t_start
-                    e->x = o.x + d.x * t;
-                    e->y = o.y + d.y * t;
-                    e->z = o.z + d.z * t;
+                    sc[0] = t;
+                    sc[3] = o.x + d.x * t;                                      // X_Point (Polygons.cs:652)
+                    sc[4] = o.y + d.y * t;
+                    sc[5] = o.z + d.z * t;
+                    sc[6] = __hiloint2double(1, i);
+                    xf |= F_HIT;
+                    L_xyzf[slot] = xf;
                 }
-                L_d2[slot] = L_d1[slot];
                 L_d1[slot] = i;
                 // next_candidate()
                 ++q;
-                if (q < qe) {
-                    L_idx[slot] = L_nexti[slot];
-                    if (q + 1 < qe) L_nexti[slot] = after;
-                }
+                L_idx[slot] = L_nexti[slot];
+                L_nexti[slot] = after;
                 L_q[slot] = q;
                 to_cull = q < qe;
-                to_walk = !to_cull;
+                to_pend = !to_cull && (xf & F_HIT);
+                to_walk = !to_cull && !to_pend;
             }
             push(Q_walk, hW, nW, to_walk, slot);
             push(Q_cull, hC, nC, to_cull, slot);
-        } else if (do_cull) {
-            // -------------------------------------------------------------- FP32 pre-cull, up to 2 x CULL_PAIRS candidates per ray
+            push(Q_pend, hP, nP, to_pend, slot);
+        }
+        if (tail ? nP > 0 : sel == 1) {
+            // -------------------------------------------------------------- walk with a pending hit (Voxel_Grid.cs:705-759)
             bool act;
-            const unsigned slot = pop(Q_cull, hC, nC, nC < 64u ? nC : 64u, act);
-            bool to_walk = false, to_cull = false, to_exact = false;
-            unsigned q = 0, qe = 0;
-            int idx = -1, nexti = -1, e1 = -1, e2 = -1, done1 = -1, done2 = -1;
-            double ox = 0, oy = 0, oz = 0;
-            float dfx = 0, dfy = 0, dfz = 0, dm = 0;
-            bool culling = act;
-            if (act) {
-                const unsigned ray = L_ray[slot];
-                q = L_q[slot]; qe = L_qe[slot]; idx = L_idx[slot]; nexti = L_nexti[slot];
-                e1 = L_e1[slot]; e2 = L_e2[slot]; done1 = L_d1[slot]; done2 = L_d2[slot];
-                const RayRec r = io.rays[ray];
-                ox = r.x; oy = r.y; oz = r.z;
-                if (L_flags[slot] & 2u) {                                   // origin was clipped to OBox
-                    const double* sc = reinterpret_cast<const double*>(&io.out[ray]);
-                    ox = sc[1]; oy = sc[2]; oz = sc[6];
-                }
-                dfx = (float)r.dx; dfy = (float)r.dy; dfz = (float)r.dz;
-                dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
-            }
-            struct CullRec { double2 c0; uint4 r1; float4 fb; float2 fc; };
-            auto load_rec = [&](int i) {
-                const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + i);
-                CullRec r;
-                r.c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
-                r.r1 = *reinterpret_cast<const uint4*>(rec + 16);       // v0.z | e1f.x e1f.y
-                r.fb = *reinterpret_cast<const float4*>(rec + 32);      // e1f.z e2f.x e2f.y e2f.z
-                r.fc = *reinterpret_cast<const float2*>(rec + 48);      // ee emax
-                return r;
-            };
-            auto culled = [&](const CullRec& r) {
-                const double c1x = __hiloint2double((int)r.r1.y, (int)r.r1.x);
-                const float e1f[3] = {__uint_as_float(r.r1.z), __uint_as_float(r.r1.w), r.fb.x}, e2f[3] = {r.fb.y, r.fb.z, r.fb.w};
-                return cull_fp32((float)(ox - r.c0.x), (float)(oy - r.c0.y), (float)(oz - c1x), dfx, dfy, dfz, dm, e1f, e2f, r.fc.x, r.fc.y);
-            };
-            // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the two this ray tested
-            // last is exact (Voxel_Grid.cs:477 + the register mailbox of K1p)
-            auto skip = [&](int i) { return i == e1 || i == e2 || i == done1 || i == done2; };
-#pragma unroll 1
-            for (int kp = 0; kp < HARE_K1Q_CULL_PAIRS; ++kp) {
-                if (__ballot(culling) == 0) break;
-                if (culling) {
-                    // candidates idx (at q) and nexti (at q + 1); the one after those is requested now, used next iteration
-                    const bool has1 = q + 1 < qe;
-                    const bool has2 = q + 2 < qe;
-                    const bool sk0 = skip(idx);
-                    const bool sk1 = !has1 || skip(nexti) || nexti == idx;
-                    int i2 = -1, i3 = -1;
-                    if (has2) i2 = g.items[q + 2];
-                    if (q + 3 < qe) i3 = g.items[q + 3];
-                    CullRec ra, rb;
-                    if (!sk0) ra = load_rec(idx);
-                    if (!sk1) rb = load_rec(nexti);
-                    bool parked = false;
-                    if (!sk0) {
-                        if (culled(ra)) { done2 = done1; done1 = idx; }
-                        else parked = true;                                 // idx (at q) goes to the exact phase
-                    }
-                    if (!parked) {
-                        ++q;                                                // candidate 0 consumed
-                        if (has1) {
-                            bool keep1 = false;
-                            if (!sk1) {
-                                if (culled(rb)) { done2 = done1; done1 = nexti; }
-                                else keep1 = true;
-                            }
-                            if (keep1) {                                    // nexti (now at q) goes to the exact phase
-                                idx = nexti; nexti = i2;
-                                parked = true;
-                            } else {
-                                ++q;                                        // candidate 1 consumed
-                                idx = i2; nexti = i3;
-                            }
-                        }
-                    }
-                    if (parked) { to_exact = true; culling = false; }
-                    else if (q >= qe) { to_walk = true; culling = false; }
-                }
-            }
-            if (act) {
-                if (culling) to_cull = true;                                // quota used up, list not exhausted
-                L_q[slot] = q; L_idx[slot] = idx; L_nexti[slot] = nexti;
-                L_d1[slot] = done1; L_d2[slot] = done2;
-            }
-            push(Q_walk, hW, nW, to_walk, slot);
-            push(Q_cull, hC, nC, to_cull, slot);
-            push(Q_exact, hE, nE, to_exact, slot);
-        } else {
-            // -------------------------------------------------------------- DDA walk until the next non-empty voxel
-            bool act;
-            const unsigned slot = pop(Q_walk, hW, nW, nW < 64u ? nW : 64u, act);
+            const unsigned slot = pop(Q_pend, hP, nP, act);
             bool to_cull = false, freed = false;
             bool walking = act;
-            double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0, tmin = 0;
-            double hx = 0, hy = 0, hz = 0;
-            int X = 0, Y = 0, Z = 0, cell = 0, pid = -1, dx1 = 1, dy1 = 1, dz1 = 1;
-            unsigned ray = 0, fl = 0, q = 0, qe = 0;
-            int idx = -1, nexti = -1;
+            double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0, tmin = 0, hx = 0, hy = 0, hz = 0;
+            int X = 0, Y = 0, Z = 0, dx1 = 1, dy1 = 1, dz1 = 1;
+            unsigned ray = 0;
+            uint32_t xf = 0;
             if (act) {
                 tMaxX = L_tmx[slot]; tMaxY = L_tmy[slot]; tMaxZ = L_tmz[slot];
                 tDeltaX = L_tdx[slot]; tDeltaY = L_tdy[slot]; tDeltaZ = L_tdz[slot];
-                const uint32_t xyz = L_xyz[slot];
-                X = (int)(xyz & 1023u); Y = (int)((xyz >> 10) & 1023u); Z = (int)((xyz >> 20) & 1023u);
-                fl = L_flags[slot];
-                dx1 = (xyz >> 30) & 1u ? -1 : 1; dy1 = (xyz >> 31) & 1u ? -1 : 1; dz1 = (fl & 1u) ? -1 : 1;
-                cell = L_cell[slot];
-                pid = L_pid[slot];
+                xf = L_xyzf[slot];
                 ray = L_ray[slot];
-                if (pid >= 0) {
-                    tmin = L_tmin[slot];
-                    const XEventRec* e = &io.out[ray];
-                    hx = e->x; hy = e->y; hz = e->z;
-                }
+                X = (int)(xf & 511u); Y = (int)((xf >> 9) & 511u); Z = (int)((xf >> 18) & 511u);
+                dx1 = (xf & F_NX) ? -1 : 1; dy1 = (xf & F_NY) ? -1 : 1; dz1 = (xf & F_NZ) ? -1 : 1;
+                const double* sc = reinterpret_cast<const double*>(&io.out[ray]);
+                tmin = sc[0]; hx = sc[3]; hy = sc[4]; hz = sc[5];
             }
-            const int dcx = dx1 * ct * ct, dcy = dy1 * ct, dcz = dz1;
+            bool exited = false;
+            const int pend_steps = tail ? HARE_K1Q_TAIL_STEPS : HARE_K1Q_WALK_STEPS;
 #pragma unroll 1
-            for (int k = 0; k < HARE_K1Q_WALK_STEPS; ++k) {
-                const unsigned long long wm = __ballot(walking);
-                if (wm == 0 || (k > 0 && __popcll(wm) < HARE_K1Q_WALK_MIN)) break;
+            for (int k = 0; k < pend_steps; ++k) {
+                if (__ballot(walking) == 0) break;
                 if (walking) {
-                    // Voxel_Grid.cs:705: pending hit inside the CURRENT padded voxel?
-                    bool done = false;
-                    if (pid >= 0) {
-                        const double lox = voxel_lo(X, g.vd[0], g.omin[0]), hix = voxel_hi(X, g.vd[0], g.omin[0]);
-                        const double loy = voxel_lo(Y, g.vd[1], g.omin[1]), hiy = voxel_hi(Y, g.vd[1], g.omin[1]);
-                        const double loz = voxel_lo(Z, g.vd[2], g.omin[2]), hiz = voxel_hi(Z, g.vd[2], g.omin[2]);
-                        if (!(hx < lox) && !(hy < loy) && !(hz < loz) && !(hx > hix) && !(hy > hiy) && !(hz > hiz)) {
-                            store_hit(ray, (fl & 2u) != 0, tmin, pid);
-                            nhits++;
-                            done = true;
-                            walking = false;
-                            freed = true;
-                        }
-                    }
-                    if (!done) {
-                        // Voxel_Grid.cs:713-759 with selects (same booleans, same order; see K1p)
-                        const bool cxy = tMaxX < tMaxY, cxz = tMaxX < tMaxZ, cyz = tMaxY < tMaxZ;
-                        const bool sx = cxy & cxz;
-                        const bool sy = (!cxy) & cyz;
-                        const bool sz = !(sx | sy);
-                        const double nX = tMaxX + tDeltaX, nY = tMaxY + tDeltaY, nZ = tMaxZ + tDeltaZ;
-                        X += sx ? dx1 : 0;
-                        Y += sy ? dy1 : 0;
-                        Z += sz ? dz1 : 0;
-                        tMaxX = sx ? nX : tMaxX;
-                        tMaxY = sy ? nY : tMaxY;
-                        tMaxZ = sz ? nZ : tMaxZ;
-                        cell += sx ? dcx : (sy ? dcy : dcz);
+                    // Voxel_Grid.cs:705: hit point inside the CURRENT padded voxel?
+                    const double lox = voxel_lo(X, g.vd[0], g.omin[0]), hix = voxel_hi(X, g.vd[0], g.omin[0]);
+                    const double loy = voxel_lo(Y, g.vd[1], g.omin[1]), hiy = voxel_hi(Y, g.vd[1], g.omin[1]);
+                    const double loz = voxel_lo(Z, g.vd[2], g.omin[2]), hiz = voxel_hi(Z, g.vd[2], g.omin[2]);
+                    const bool in = !(hx < lox) && !(hy < loy) && !(hz < loz) && !(hx > hix) && !(hy > hiy) && !(hz > hiz);
+                    if (in) {
+                        freed = true;
+                        walking = false;
+                    } else {
+                        HARE_K1Q_STEP();
                         const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
-                        if (out) {                                          // leaving the grid: miss, even with a pending hit (F12)
-                            store_miss(ray);
-                            walking = false;
-                            freed = true;
-                        } else if (occupied(X, Y, Z, cell)) {
-                            walking = false;                                // the cell record is fetched after the loop: a load
-                            to_cull = true;                                 // in here would stall all 64 lanes at every step
-                        }
+                        const int cell = out ? 0 : (X * ct + Y) * ct + Z;
+                        const bool occ = occupied(out ? 0 : X, out ? 0 : Y, out ? 0 : Z, cell);
+                        exited = out;                                       // leaving the grid: miss, even with the hit pending (F12)
+                        to_cull = !out && occ;
+                        walking = !out && !occ;
                     }
                 }
             }
+            if (freed) {                                                    // the hit stands: Voxel_Grid.cs:707
+                double* sc = reinterpret_cast<double*>(&io.out[ray]);
+                double t_start = 0;
+                if (xf & F_MOVED) t_start = sc[1];
+                sc[0] = tmin + t_start;
+                sc[1] = 0;
+                sc[2] = 0;
+                nhits++;
+            }
+            if (exited) {
+                store_miss(ray);
+                freed = true;
+            }
+            unsigned q = 0, qe = 0;
+            int idx = -1, nexti = -1;
             if (to_cull) {
-                const CellRec c = g.cells[cell];
+                const CellRec c = g.cells[(X * ct + Y) * ct + Z];
                 q = c.start; qe = c.start + c.count; idx = c.i0; nexti = c.i1;
-                if (COARSE && c.count == 0) { to_cull = false; walking = true; }   // the block is occupied, this voxel is not: walk on
+                if (COARSE && c.count == 0) { to_cull = false; walking = true; }   // the block is occupied, this voxel is not
             }
             if (act && !freed) {
                 L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
-                L_xyz[slot] = (uint32_t)X | ((uint32_t)Y << 10) | ((uint32_t)Z << 20) | (dx1 < 0 ? 1u << 30 : 0u) | (dy1 < 0 ? 1u << 31 : 0u);
-                L_cell[slot] = cell;
+                L_xyzf[slot] = (xf & 0xF8000000u) | (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18);
                 if (to_cull) { L_q[slot] = q; L_qe[slot] = qe; L_idx[slot] = idx; L_nexti[slot] = nexti; }
             }
-            push(Q_walk, hW, nW, walking, slot);                            // still walking: next round
+            push(Q_pend, hP, nP, walking, slot);
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_free, hF, nF, freed, slot);
         }
     }
+#undef HARE_K1Q_STEP
+    timeline(2, __builtin_amdgcn_s_memrealtime());
+    timeline(3, rounds_done);
 
     // batch counters: per-wave partials, summed by hare_ctr_reduce
     if (io.ctr) {

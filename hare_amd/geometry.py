@@ -264,6 +264,10 @@ class Spatial_Partition:
         check(lib.hare_shoot_device(self._h, self._kind, int(top_index), int(n), d_rays or None, d_excl1 or None,
                                     d_excl2 or None, int(flags), d_out or None, d_counters or None, stream or None))
 
+    def kernel_name(self, n: int, top_index: int = 0, flags: int = 0) -> str:
+        """The gfx950 kernel a shoot of n rays launches (what rocprofv3 will list)."""
+        return (lib.hare_shoot_kernel_name(self._h, self._kind, int(top_index), int(n), int(flags)) or b"").decode()
+
     def reflect_device(self, n: int, d_rays: int, d_events: int, d_excl_out: int, top_index: int = 0, stream: int = 0):
         check(lib.hare_reflect_device(self._h, int(top_index), int(n), d_rays, d_events, d_excl_out, stream or None))
 

@@ -215,6 +215,10 @@ HARE_API int hare_shoot_device(hare_scene *s, int32_t kind, int32_t top_index, i
                       const void *d_excl1, const void *d_excl2, uint32_t flags, void *d_out,
                       void *d_counters, void *stream);
 
+/* Name of the gfx950 kernel a hare_shoot_device / hare_shoot_batch call with these arguments launches (for profiles:
+ * rocprofv3 lists kernels by this name).  The voxel path has two production kernels and picks by batch size. */
+HARE_API const char *hare_shoot_kernel_name(const hare_scene *s, int32_t kind, int32_t top_index, int64_t n, uint32_t flags);
+
 /* ---- Shoot, one ray (unchanged reference call sites) ----
  * bool Shoot(Ray R, int top_index, out X_Event Ret_event, int poly_origin1 = -1, int poly_origin2 = -1)
  * (Spatial_Partition.cs:32-33; Voxel_Grid.cs:351,561; "Octree - alt.cs":154; KDTree.cs:193) for ONE ray, on the calling

@@ -229,3 +229,122 @@ def test_bounce_c5_full_size_1M_rays_x8_1M_tris():
         assert np.array_equal(d_ex.cpu().numpy(), excl)
     assert (int(d_ctr[0]), int(d_ctr[1])) == (casts, hits)
     assert dead.mean() < 0.01
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The voxel path has two production kernels (K1p hare_voxel_persist_*, K1q hare_voxel_pool_*); the library picks by
+# batch size.  HARE_VOXEL_KERNEL forces one, so every case below runs on BOTH regardless of where the crossover sits.
+@pytest.mark.parametrize("kernel", ["pool", "persist"])
+def test_both_voxel_kernels_full_size_and_large_batches(hall, kernel, monkeypatch):
+    monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
+    m, T, To = hall
+    g = H.Voxel_Grid([T], 64)
+    o = po.VoxelGrid([To], domain=64)
+    for n in (1 << 20, 3_000_001):
+        assert g.kernel_name(n) == f"hare_voxel_{kernel}_tri"
+        rays = H.scenes.burst_rays(n, m.size)
+        ev, c = g.Shoot_batch(rays)
+        ref, rc = o.shoot(rays, nthreads=16)
+        assert_events_equal(ev, ref, what=f"{kernel} kernel, {n} rays")
+        assert (c["rays"], c["hits"]) == (n, rc["hits"])
+
+
+@pytest.mark.parametrize("kernel", ["pool", "persist"])
+def test_both_voxel_kernels_quads_exclusions_outside_origins_and_writeback(kernel, monkeypatch):
+    monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
+    v, nv, size = soup()
+    rays = soup_rays(30000, size)
+    rng = np.random.default_rng(1)
+    e1 = rng.integers(-3, len(nv), len(rays)).astype(np.int32)
+    e2 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+    g = H.Voxel_Grid([H.Topology(v, nv)], 12)
+    assert g.kernel_name(len(rays)) == f"hare_voxel_{kernel}_quad"
+    o = po.VoxelGrid([po.Topology(v, nv)], domain=12)
+    r1 = rays.copy()
+    ev, _ = g.Shoot_batch(r1, poly_origin1=e1, poly_origin2=e2, writeback_origin=True)
+    ref, _, moved = o.shoot(rays, excl1=e1, excl2=e2, mutate=True)
+    assert_events_equal(ev, ref, what=f"{kernel}: soup with exclusions")
+    assert r1.tobytes() == moved.tobytes() and (moved != rays).any()          # AABB.Intersect's origin move, written back
+    ev, _ = g.Shoot_batch(rays)                                                # and without write-back: same events, rays untouched
+    assert_events_equal(ev, o.shoot(rays)[0], what=f"{kernel}: soup, no write-back")
+
+
+@pytest.mark.parametrize("kernel", ["pool", "persist"])
+@pytest.mark.parametrize("domain", [1, 7, 33, 72, 96, 128, 200])
+def test_both_voxel_kernels_over_grid_sizes(hall, kernel, domain, monkeypatch):
+    """1 bit per voxel up to 80^3, per 2^3 block up to 160^3, per 4^3 above; K1q needs the bitmap to leave room for its
+    pools (<= 32 KB), so 65..80 stay with K1p whatever is asked for -- the name tells."""
+    monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
+    m, T, To = hall
+    n = 150_000
+    rays = H.scenes.burst_rays(n, m.size)
+    g = H.Voxel_Grid([T], domain)
+    name = g.kernel_name(n)
+    assert name.startswith("hare_voxel_pool" if (kernel == "pool" and not 64 < domain <= 80) else "hare_voxel_persist"), name
+    assert name.endswith("_g") == (domain > 80)
+    ref, _ = po.VoxelGrid([To], domain=domain).shoot(rays, nthreads=16)
+    assert_events_equal(g.Shoot_batch(rays)[0], ref, what=f"{kernel} D={domain}")
+
+
+@pytest.mark.parametrize("kernel", ["pool", "persist"])
+def test_both_voxel_kernels_degenerate_rays_and_two_topologies(kernel, monkeypatch):
+    from tests.test_gpu_parity import bits_equal, degenerate_rays
+    monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
+    m = H.scenes.shoebox()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    for domain in (1, 8, 33):
+        rays = degenerate_rays(m.size, domain)
+        ref, rc = po.VoxelGrid([To], domain=domain).shoot(rays.copy())
+        ev, c = H.Voxel_Grid([T], domain).Shoot_batch(rays.copy())
+        bits_equal(ev, ref, f"{kernel} D={domain} degenerate rays")
+        assert c["hits"] == rc["hits"]
+    v, nv, size = soup(150, 40)
+    rays = soup_rays(5000, size)
+    g = H.Voxel_Grid([T, H.Topology(v, nv)], 8)
+    o = po.VoxelGrid([To, po.Topology(v, nv)], domain=8)
+    for top in (0, 1):
+        assert_events_equal(g.Shoot_batch(rays, top)[0], o.shoot(rays, top)[0], what=f"{kernel} top {top}")
+    ev, c = g.Shoot_batch(rays[:0])
+    assert len(ev) == 0 and c["rays"] == 0
+    for n in (1, 63, 65, 129, 12289):                                          # ragged batches around the pool / wave sizes
+        ev, c = g.Shoot_batch(rays[:n] if n <= len(rays) else np.resize(rays, (n, 6)))
+        want = o.shoot(rays[:n] if n <= len(rays) else np.resize(rays, (n, 6)))[0]
+        assert_events_equal(ev, want, what=f"{kernel} n={n}")
+        assert c["rays"] == n
+
+
+@pytest.mark.parametrize("kernel", ["pool", "persist"])
+def test_both_voxel_kernels_bounce_loop_with_retired_rays(hall, kernel, monkeypatch):
+    import torch
+    monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
+    m, T, To = hall
+    n, bounces = 200_000, 5
+    rays = H.scenes.burst_rays(n, m.size)
+    rays[::97, 3:] = rays[::97, 3:] * 0 + [0.0, 0.0, 0.0]                       # zero directions: miss at once, retired on bounce 1
+    g = H.Voxel_Grid([T], 64)
+    o = po.VoxelGrid([To], domain=64)
+    d_rays = torch.from_numpy(rays.copy()).cuda()
+    d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    d_ex = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    cur, excl = rays.copy(), np.full(n, -1, np.int32)
+    dead = np.zeros(n, bool)
+    casts = 0
+    for b in range(bounces):
+        g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), d_counters=d_ctr.data_ptr(), stream=st,
+                       flags=capi.SHOOT_RETIRED_RAYS)
+        g.reflect_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_ex.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE)
+        live = ~dead
+        ref = np.zeros(n, po.XEVENT_DTYPE)
+        ref["poly_id"] = -1
+        ref[live], c = o.shoot(cur[live], excl1=excl[live], nthreads=16)
+        casts += c["rays"]
+        assert_events_equal(ev, ref, what=f"{kernel} bounce {b}")
+        alive = (ref["hit"] == 1) & live
+        cur = po.reflect_batch(To, cur, ref)
+        excl = np.where(alive, ref["poly_id"], -2).astype(np.int32)
+        dead |= ~alive
+    assert int(d_ctr[0]) == casts and dead.sum() >= n // 97

@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import hare_amd as H
+os.environ["HARE_DEV"] = "1"      # the timeline bit is a developer flag
 N = int(os.environ.get("RAYS", 1 << 20)); D = 64
 mesh = H.scenes.hall(); g = H.Voxel_Grid([H.Topology(mesh.verts, mesh.nverts)], D)
 rays = H.scenes.burst_rays(N, mesh.size)
@@ -23,6 +24,19 @@ for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET v
     t0 = tl[live, 0].min()
     start = (tl[:, 0] - t0) / 100.0; last = (tl[:, 1] - t0) / 100.0; end = (tl[:, 2] - t0) / 100.0   # microseconds
     print("== %s: kernel span %.0f us, waves live %d" % (cfg, end[live].max(), live.sum()))
+    if os.environ.get("HARE_VOXEL_KERNEL") == "pool":      # K1q: one workgroup per CU; slot 1 = tickets dry, slot 3 = rounds
+        dry = last
+        m = live
+        print("  tickets dry p10/50/90 %.0f/%.0f/%.0f  end p10/50/90/max %.0f/%.0f/%.0f/%.0f  tail(end-dry) mean %.0f  rounds/wave mean %.0f"
+              % (*np.percentile(dry[m], [10, 50, 90]), *np.percentile(end[m], [10, 50, 90]), end[m].max(), (end[m] - dry[m]).mean(), tl[m, 3].mean()))
+        e = np.sort(end[live]); tot = e.max()
+        print("  waves still running at 50/60/70/80/90/95%% of span: %s" % [int((e > tot * f).sum()) for f in (0.5, 0.6, 0.7, 0.8, 0.9, 0.95)])
+        nw = int(os.environ.get("POOL_WAVES", 12))
+        order = np.argsort(-end * live)[:12]
+        print("  latest waves (block, wave, xcd=block%8, dry us, end us, rounds):", [(int(w // nw), int(w % nw), int((w // nw) % 8), int(dry[w]), int(end[w]), int(tl[w, 3])) for w in order])
+        late = live & (end > np.percentile(end[live], 97))
+        print("  the latest 3%%: blocks %s, rounds mean %.0f vs all %.0f, dry mean %.0f vs all %.0f" % (sorted(set(int(w // nw) for w in np.nonzero(late)[0]))[:40], tl[late, 3].mean(), tl[live, 3].mean(), dry[late].mean(), dry[live].mean()))
+        continue
     tier = (np.arange(W) // 4) // 256
     for k in range(4):
         m = live & (tier == k)
