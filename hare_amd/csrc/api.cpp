@@ -85,6 +85,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_shoot", &m->octree},
         {"hare_octree_shoot_count", &m->octree_count},
         {"hare_octree_persist", &m->octree_persist},
+        {"hare_octree_pool", &m->octree_pool},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
@@ -313,6 +314,16 @@ bool voxel_pool_wanted(int64_t n, bool coarse)
     }
     return n >= (coarse ? (1ll << 20) : 1572864ll);
 }
+constexpr bool kOctreePoolDefault = false;
+// The octree's production kernels: K2q (hare_octree_pool) / K2p (hare_octree_persist); HARE_OCTREE_KERNEL=pool|persist overrides.
+bool octree_pool_wanted(int64_t n)
+{
+    if (const char* k = getenv("HARE_OCTREE_KERNEL")) {
+        if (strcmp(k, "pool") == 0) return true;
+        if (strcmp(k, "persist") == 0) return false;
+    }
+    return kOctreePoolDefault && n >= 65536;
+}
 bool voxel_pool_usable(const Scene& s, uint32_t flags)
 {
     const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
@@ -519,6 +530,59 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return HARE_E_UNSUPPORTED;
         }
         const unsigned plds = (unsigned)g.max_depth * 256u * 24u;   // persistent kernel: 24 bytes x levels x 256 lanes per workgroup
+        // K2q (octree_pool.hip): more rays than lanes; frames below the top one in a device scratch block per launch in flight
+        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_pool && n < 0x7FFFFF00ll && g.n_nodes < (1 << 23) && octree_pool_wanted(n)) {
+            const unsigned stride = 24u + 24u * (unsigned)g.max_depth;
+            unsigned pgrid = (unsigned)std::max(1, M.cu_count);
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 64 * kOctPoolWaves - 1) / (64 * kOctPoolWaves)));
+            if (pgrid == 0) pgrid = 1;
+            pgrid = std::min(pgrid, kPartWaves / (unsigned)kOctPoolWaves);
+            const size_t need = (size_t)std::max(1, M.cu_count) * kOctPoolWaves * kOctPoolSlots * stride;
+            unsigned char* scratch = nullptr;
+            unsigned ring = 0;
+            {
+                std::lock_guard<std::mutex> lk(s.oct_scratch_mu);
+                if (s.oct_scratch_bytes < need) {          // first use, or a deeper tree since: (re)allocate the ring
+                    for (int k = 0; k < kOctScratchRing; ++k) {
+                        if (s.oct_scratch_ev[k]) (void)H->EventSynchronize(s.oct_scratch_ev[k]);
+                        dev_free(H, s.d_oct_scratch[k]);
+                    }
+                    s.oct_scratch_bytes = 0;
+                    for (int k = 0; k < kOctScratchRing; ++k) {
+                        HIP_TRY(H->Malloc(&s.d_oct_scratch[k], need));
+                        if (!s.oct_scratch_ev[k]) HIP_TRY(H->EventCreate(&s.oct_scratch_ev[k]));
+                    }
+                    s.oct_scratch_bytes = need;
+                    s.oct_scratch_next = 0;
+                }
+                ring = s.oct_scratch_next.fetch_add(1) % (unsigned)kOctScratchRing;
+                scratch = (unsigned char*)s.d_oct_scratch[ring];
+                // the launch that used this block last must have finished before this one may start (another stream, maybe)
+                if (s.oct_scratch_next.load() > (unsigned)kOctScratchRing) HIP_TRY(H->StreamWaitEvent(st, s.oct_scratch_ev[ring], 0));
+            }
+            const unsigned slot = s.work_slot.fetch_add(1) % 64u;
+            io.part = nullptr;
+            if (io.ctr) {
+                if (!M.ctr_reduce || !s.d_part) {
+                    set_error("hare_shoot: counter-reduce kernel missing from code object");
+                    return HARE_E_STATE;
+                }
+                io.part = (unsigned long long*)s.d_part + (size_t)slot * kPartWaves * 2;
+            }
+            io.ticket_rays = 32;
+            if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
+            io.work = (unsigned int*)s.d_work + slot;
+            HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+            unsigned stride_arg = stride;
+            void* qargs[] = {&g, &io, &scratch, &stride_arg};
+            int rc = launch(H, M.octree_pool, pgrid, 64u * (unsigned)kOctPoolWaves, (unsigned)kOctPoolWaves * (unsigned)kOctPoolWaveBytes, st, qargs);
+            if (rc == HARE_OK) {
+                std::lock_guard<std::mutex> lk(s.oct_scratch_mu);
+                HIP_TRY(H->EventRecord(s.oct_scratch_ev[ring], st));
+            }
+            if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * (unsigned)kOctPoolWaves, st);
+            return rc;
+        }
         if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && plds <= kLdsMax) {
             unsigned per_cu = std::min(4u, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
@@ -714,6 +778,10 @@ void hare_scene_destroy(hare_scene* s)
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_part, &s->d_rays,
                          &s->d_e1, &s->d_e2, &s->d_out, &s->d_ctr})
             dev_free(H, *p);
+        for (int k = 0; k < kOctScratchRing; ++k) {
+            dev_free(H, s->d_oct_scratch[k]);
+            if (s->oct_scratch_ev[k]) (void)H->EventDestroy(s->oct_scratch_ev[k]);
+        }
         if (s->stream) (void)H->StreamDestroy(s->stream);
         for (hipStream_t& x : s->extra_streams)
             if (x) (void)H->StreamDestroy(x);
@@ -1242,7 +1310,8 @@ const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t to
             return !coarse ? (quads ? "hare_voxel_pool_quad" : "hare_voxel_pool_tri") : (quads ? "hare_voxel_pool_quad_g" : "hare_voxel_pool_tri_g");
         return !coarse ? (quads ? "hare_voxel_persist_quad" : "hare_voxel_persist_tri") : (quads ? "hare_voxel_persist_quad_g" : "hare_voxel_persist_tri_g");
     }
-    if (kind == HARE_KIND_OCTREE) return count ? "hare_octree_shoot_count" : ((simple || n >= 0x7FFFFF00ll) ? "hare_octree_shoot" : "hare_octree_persist");
+    if (kind == HARE_KIND_OCTREE)
+        return count ? "hare_octree_shoot_count" : ((simple || n >= 0x7FFFFF00ll) ? "hare_octree_shoot" : (octree_pool_wanted(n) ? "hare_octree_pool" : "hare_octree_persist"));
     if (kind == HARE_KIND_KDTREE) return count ? "hare_kdtree_shoot_count" : "hare_kdtree_shoot";
     return "";
 }

@@ -119,6 +119,20 @@ constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4) + 5 * kPoolRing;   /
 static_assert(kPoolSlots >= 64 && kPoolSlots <= 256 && kPoolSlots % 2 == 0, "K1q slots: even, 64..256");
 static_assert(kPoolWaveBytes % 8 == 0, "K1q: per-wave LDS block keeps the doubles aligned");
 
+// K2q (octree_pool.hip): launch geometry shared by the kernel and the host launcher
+#ifndef HARE_K2Q_WAVES
+#define HARE_K2Q_WAVES 12
+#endif
+#ifndef HARE_K2Q_SLOTS
+#define HARE_K2Q_SLOTS 128
+#endif
+constexpr int kOctPoolWaves = HARE_K2Q_WAVES;
+constexpr int kOctPoolSlots = HARE_K2Q_SLOTS;
+constexpr int kOctPoolRing = kOctPoolSlots <= 64 ? 64 : (kOctPoolSlots <= 128 ? 128 : 256);
+constexpr int kOctPoolWaveBytes = kOctPoolSlots * (5 * 8 + 11 * 4) + 4 * kOctPoolRing;   // per wave: 5 doubles + 11 words per slot, 4 byte queues
+static_assert(kOctPoolSlots >= 64 && kOctPoolSlots <= 256 && kOctPoolSlots % 2 == 0 && kOctPoolWaveBytes % 8 == 0, "K2q pool geometry");
+constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool kernel that may be in flight (each owns a scratch block)
+
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN
     const int32_t* excl1;      // nullable: poly_origin1 per ray

@@ -37,6 +37,7 @@ struct HipApi {
     hipError_t (*EventDestroy)(hipEvent_t);
     hipError_t (*EventRecord)(hipEvent_t, hipStream_t);
     hipError_t (*EventSynchronize)(hipEvent_t);
+    hipError_t (*StreamWaitEvent)(hipStream_t, hipEvent_t, unsigned int);
     hipError_t (*EventElapsedTime)(float*, hipEvent_t, hipEvent_t);
     hipError_t (*HostMalloc)(void**, size_t, unsigned int);
     hipError_t (*HostFree)(void*);

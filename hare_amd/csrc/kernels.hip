@@ -25,6 +25,7 @@
 // change the result because the accept is the strict `t < tmin`; the production kernels
 // only remember the last few polygons a ray tested, in registers.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "hare_device.h"
 #include "hare_trace.h"
 
@@ -634,7 +635,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     if (ce > n32) ce = n32;
     bool drained = false;
 
-    bool alive = false, parked = false, hit = false;
+    bool alive = false, parked = false, hit = false, tame = true;
     unsigned int ray = 0;
     V3 o = {0, 0, 0}, d = {0, 0, 0};
     double invDx = 0, invDy = 0, invDz = 0;
@@ -731,6 +732,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     e1 = io.excl1 ? io.excl1[ray] : -1;
                     e2 = io.excl2 ? io.excl2[ray] : -1;
                     hit = false; parked = false; alive = true;
+                    tame = fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300 && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
                     closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                     m0 = m1 = m2 = m3 = -1;
                     lvl = -1; q = 0; qe = 0;
@@ -768,7 +770,13 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         for (int k = 0; k < STEPS; ++k) {
             const bool pop = alive && !parked && q == qe;
             if (__ballot(pop) == 0) break;
-            if (pop) {
+            // Rays whose components are all finite and far from overflow never produce a NaN here (1/d is finite and non-zero,
+            // boxes are finite), so for them Math.Max / Math.Min are the hardware's v_max_f64 / v_min_f64 (the sign of a zero
+            // result is only ever compared); anything else takes the NaN-propagating compare-selects.
+            auto pstep = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                auto mx = [](double a, double b) { return FAST ? __builtin_fmax(a, b) : omax(a, b); };
+                auto mn = [](double a, double b) { return FAST ? __builtin_fmin(a, b) : omin(a, b); };
                 if (lvl < 0) {
                     finish();                                                // stack empty: :276-283
                 } else {
@@ -783,11 +791,11 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     } else {
                         fpk[lvl * nt + tid] = pk - 1;
                         const int oct = cur ^ mask;                          // order[cur] (:286-306)
-                        const double tmn = omax(omax((oct & 4) ? nhx : nlx, (oct & 2) ? nhy : nly), (oct & 1) ? nhz : nlz);
-                        const double tmx = omin(omin((oct & 4) ? fhx : flx, (oct & 2) ? fhy : fly), (oct & 1) ? fhz : flz);
+                        const double tmn = mx(mx((oct & 4) ? nhx : nlx, (oct & 2) ? nhy : nly), (oct & 1) ? nhz : nlz);
+                        const double tmx = mn(mn((oct & 4) ? fhx : flx, (oct & 2) ? fhy : fly), (oct & 1) ? fhz : flz);
                         const double pa = fa[lvl * nt + tid], pb = fb[lvl * nt + tid];
                         if (!(tmx < tmn || tmx < 0 || tmn > pb || tmx < pa)) {           // pushed (:268)
-                            const double ca = omax(tmn, pa), cb = omin(tmx, pb);        // :271
+                            const double ca = mx(tmn, pa), cb = mn(tmx, pb);            // :271
                             if (!(cb < ca || cb < 0) && !(hit && closestT <= ca)) {      // popped and kept (:207-211)
                                 const int c = (pk >> 4) + oct;
                                 visit(c, g.nodes[c], ca, cb);
@@ -795,6 +803,11 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         }
                     }
                 }
+            };
+            const bool all_tame = __ballot(pop && !tame) == 0;
+            if (pop) {
+                if (all_tame) pstep(std::true_type{});
+                else pstep(std::false_type{});
             }
         }
 
@@ -1015,4 +1028,5 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 }  // extern "C"
 
 #include "voxel_pool.hip"
+#include "octree_pool.hip"
 #include "build_kernels.hip"

@@ -69,7 +69,7 @@ struct DeviceModule {
     hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t voxel_pool_tri = nullptr, voxel_pool_quad = nullptr, voxel_pool_tri_g = nullptr, voxel_pool_quad_g = nullptr;
-    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr;
+    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, ctr_reduce = nullptr, occlusion = nullptr;
     hipFunction_t cull_audit = nullptr;
@@ -141,6 +141,13 @@ struct Scene {
     int64_t staged_cap = 0;
 
     const DeviceModule* module = nullptr;
+
+    // K2q scratch: one block per launch in flight (ring), each guarded by an event recorded behind the launch that used it
+    void* d_oct_scratch[kOctScratchRing] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t oct_scratch_ev[kOctScratchRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t oct_scratch_bytes = 0;
+    std::atomic<unsigned> oct_scratch_next{0};
+    std::mutex oct_scratch_mu;
 
     // host mirror for hare_shoot_one (single-ray callers): built on first use, read-only afterwards
     std::mutex mirror_mu;

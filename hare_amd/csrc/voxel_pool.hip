@@ -159,6 +159,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     };
     timeline(0, __builtin_amdgcn_s_memrealtime());
     unsigned rounds_done = 0;
+    unsigned long long stat_lanes = 0, stat_distinct = 0, stat_batches = 0;
     // a wave serves ~n / (waves in the grid) rays in a few rounds each; the cap only exists so that a defect can never
     // turn into a wave that does not finish (rays it left behind would keep their scratch values and fail every parity test)
     for (unsigned round = 0; round < (1u << 24); ++round) {
@@ -322,6 +323,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             bool act;
             const unsigned slot = pop(Q_cull, hC, nC, act);
             bool to_walk = false, to_cull = false, to_exact = false, to_pend = false;
+            int share_idx = -1;
             if (act) {
                 const unsigned ray = L_ray[slot];
                 unsigned q = L_q[slot];
@@ -340,6 +342,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const float dfx = (float)r.dx, dfy = (float)r.dy, dfz = (float)r.dz;
                 const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
                 bool culling = true, parked = false;
+                share_idx = idx;
 #pragma unroll
                 for (int kp = 0; kp < HARE_K1Q_CULL_PAIRS; ++kp) {
                     // candidates idx (at q) and nexti (at q + 1): both records and the two list entries after them are
@@ -389,6 +392,19 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const bool exhausted = !parked && !culling;
                 to_pend = exhausted && (xf & F_HIT);
                 to_walk = exhausted && !(xf & F_HIT);
+            }
+            if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
+                // developer statistic (tools/share_stat.py): how many DIFFERENT polygons do the lanes of one cull batch look at?
+                // (what a wave-shared LDS tile of polygon records could save: lanes - distinct record fetches)
+                unsigned long long left = __ballot(act);
+                unsigned distinct = 0;
+                const unsigned lanes = (unsigned)__popcll(left);
+                while (left) {
+                    const int v = __builtin_amdgcn_readlane(share_idx, (int)__builtin_ctzll(left));
+                    left &= ~__ballot(act && share_idx == v);
+                    ++distinct;
+                }
+                stat_lanes += lanes; stat_distinct += distinct; stat_batches += 1;
             }
             push(Q_walk, hW, nW, to_walk, slot);
             push(Q_cull, hC, nC, to_cull, slot);
@@ -540,6 +556,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #undef HARE_K1Q_STEP
     timeline(2, __builtin_amdgcn_s_memrealtime());
     timeline(3, rounds_done);
+    if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
+        if (lane == 0) {
+            atomicAdd(&io.prof[0], stat_lanes);
+            atomicAdd(&io.prof[1], stat_distinct);
+            atomicAdd(&io.prof[2], stat_batches);
+        }
+    }
 
     // batch counters: per-wave partials, summed by hare_ctr_reduce
     if (io.ctr) {

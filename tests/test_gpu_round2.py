@@ -348,3 +348,49 @@ def test_both_voxel_kernels_bounce_loop_with_retired_rays(hall, kernel, monkeypa
         excl = np.where(alive, ref["poly_id"], -2).astype(np.int32)
         dead |= ~alive
     assert int(d_ctr[0]) == casts and dead.sum() >= n // 97
+
+
+@pytest.mark.parametrize("kernel", ["pool", "persist"])
+def test_both_octree_kernels(hall, kernel, monkeypatch):
+    """K2p (hare_octree_persist, the default) and K2q (hare_octree_pool, opt-in: rays outnumber lanes, frames below the top
+    one in a device scratch block): bench workload at 300k rays, tree shapes from a single leaf to 12 levels with
+    quadrilaterals and exclusions, a 20-level tree, degenerate rays, and more launches in flight than K2q has scratch blocks."""
+    import torch
+    from tests.test_gpu_parity import bits_equal, degenerate_rays
+    monkeypatch.setenv("HARE_OCTREE_KERNEL", kernel)
+    m, T, To = hall
+    n = 300_000
+    rays = H.scenes.burst_rays(n, m.size)
+    g = H.Octree([T], 8, 16)
+    assert g.kernel_name(n) == f"hare_octree_{kernel}"
+    ref, rc = po.Octree([To], 8, 16).shoot(rays, nthreads=16)
+    ev, c = g.Shoot_batch(rays)
+    assert_events_equal(ev, ref, what=f"octree {kernel}: hall")
+    assert (c["rays"], c["hits"]) == (n, rc["hits"])
+    v, nv, size = soup()
+    sr = soup_rays(20000, size)
+    rng = np.random.default_rng(1)
+    e1 = rng.integers(-1, len(nv), len(sr)).astype(np.int32)
+    e2 = rng.integers(-1, len(nv), len(sr)).astype(np.int32)
+    for depth, maxp in ((0, 4), (1, 1), (3, 2), (6, 8), (12, 64)):
+        gs, os_ = H.Octree([H.Topology(v, nv)], depth, maxp), po.Octree([po.Topology(v, nv)], depth, maxp)
+        assert_events_equal(gs.Shoot_batch(sr)[0], os_.shoot(sr)[0], what=f"octree {kernel} depth {depth}")
+        assert_events_equal(gs.Shoot_batch(sr, poly_origin1=e1, poly_origin2=e2)[0], os_.shoot(sr, excl1=e1, excl2=e2)[0],
+                            what=f"octree {kernel} depth {depth} excl")
+    dv, dnv, dr = deep_scene(20)
+    assert_events_equal(H.Octree([H.Topology(dv, dnv)], 20, 2).Shoot_batch(dr)[0], po.Octree([po.Topology(dv, dnv)], 20, 2).shoot(dr)[0],
+                        what=f"octree {kernel} 20 levels")
+    sm = H.scenes.shoebox()
+    deg = degenerate_rays(sm.size, 8)
+    oref, _ = po.Octree([po.Topology(sm.verts, sm.nverts)], 5, 8).shoot(deg.copy())
+    bits_equal(H.Octree([H.Topology(sm.verts, sm.nverts)], 5, 8).Shoot_batch(deg.copy())[0], oref, f"octree {kernel} degenerate rays")
+    # eight launches back to back on one stream and on two streams: K2q owns 4 scratch blocks and orders re-use with events
+    d_rays = torch.from_numpy(rays).cuda()
+    outs = [torch.empty(n * 56, dtype=torch.uint8, device="cuda") for _ in range(8)]
+    s2 = torch.cuda.Stream()
+    for k in range(8):
+        stream = torch.cuda.current_stream() if k % 2 == 0 else s2
+        g.shoot_device(n, d_rays.data_ptr(), outs[k].data_ptr(), stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(8):
+        assert outs[k].cpu().numpy().tobytes() == ref.tobytes(), f"launch {k}"
