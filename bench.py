@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--bounces", type=int, default=1,
                     help="casts per step: >1 = device-resident specular bounce loop (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle pass (no roofline / cpu_baseline / parity)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg: profiling runs want only full-size launches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: rehearsal with ranks sharing one GPU)")
     return ap.parse_args(argv)
@@ -340,7 +341,7 @@ def main() -> None:
         torch.cuda.synchronize()
         copy_gbs = 2 * a.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del a, b_
-        if B == 1:
+        if B == 1 and not args.no_e2e:
             part.Shoot_batch(rays_h)            # sizes the scene's staging buffers: not part of the measurement
             t1 = time.perf_counter()
             part.Shoot_batch(rays_h)

@@ -207,8 +207,9 @@ void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<Qua
         r.emax = up(emax);
         r.ee = up(n1 * (double)r.emax);
         if (T.nverts[p] == 4) {
-            r.emax = INFINITY;                  // quadrilaterals are never pre-culled
+            r.emax = INFINITY;                  // quadrilaterals are never pre-culled:
             r.ee = INFINITY;
+            r.e1f[0] = NAN;                     // with a NaN edge every comparison of cull_fp32 fails
             for (int a = 0; a < 3; ++a) quads[p].v3[a] = V[9 + a];
         }
         if (T.has_quads) quads[p].nverts = T.nverts[p];

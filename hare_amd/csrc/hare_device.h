@@ -115,7 +115,10 @@ static_assert(sizeof(OctTask) == 64, "octree task size");
 constexpr int kPoolWaves = HARE_K1Q_WAVES;
 constexpr int kPoolSlots = HARE_K1Q_SLOTS;
 constexpr int kPoolRing = kPoolSlots <= 64 ? 64 : (kPoolSlots <= 128 ? 128 : 256);   // queue capacity: the power of two >= slots
-constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4) + 5 * kPoolRing;   // per wave: 6 doubles + 7 words per slot, 5 byte queues
+#ifndef HARE_K1Q_RAY_LDS
+#define HARE_K1Q_RAY_LDS 0        // 1: the (moved) origin and the FP32 direction also live in LDS: no ray re-read in the cull phase
+#endif
+constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4 + (HARE_K1Q_RAY_LDS ? 3 * 8 + 3 * 4 : 0)) + 5 * kPoolRing;   // per wave: 6 (9) doubles + 7 (10) words per slot, 5 byte queues
 static_assert(kPoolSlots >= 64 && kPoolSlots <= 256 && kPoolSlots % 2 == 0, "K1q slots: even, 64..256");
 static_assert(kPoolWaveBytes % 8 == 0, "K1q: per-wave LDS block keeps the doubles aligned");
 

@@ -21,14 +21,14 @@ struct V3 {
 };
 
 // One polygon = one 128-byte record = one L2 line: a lane that tests polygon i touches exactly one
-// line.  The first 56 bytes serve the conservative FP32 pre-cull (v0 + the two edges from v0 as
-// floats + two error-bound factors); the exact FP64 test reads the rest.
+// line.  The first 48 bytes serve the conservative FP32 pre-cull (v0 + the two edges from v0 as
+// floats: three 16-byte gathers); the exact FP64 test reads the rest.
 struct alignas(128) PolyRec {
     double v0[3];      //   0
     float e1f[3];      //  24  (float)(v1 - v0)
     float e2f[3];      //  36  (float)(v2 - v0)
-    float ee;          //  48  |e1|_1 * emax, rounded up (margin factor of the determinant)
-    float emax;        //  52  max(|e1|_inf, |e2|_inf), rounded up; +inf: never cull (quadrilaterals)
+    float ee;          //  48  |e1|_1 * emax, rounded up  } kept for tools; the kernels form both factors from e1f / e2f
+    float emax;        //  52  max(|e1|_inf, |e2|_inf)     } (cull_fp32); a quadrilateral has NaN in e1f[0]: never culled
     double v1[3];      //  56
     double v2[3];      //  80
     double n[3];       // 104  Polygon.Normal
@@ -184,12 +184,19 @@ HARE_HD bool poly_full(const PolyRec& p, const double* v3, const V3& o, const V3
 //   M_det = G * |d|_1 * ee                     (det;    ee   >= |e1|_1 * emax)
 // plus 1e-30 against underflow.  Candidates whose determinant sign is not certain (|det| <= M_det)
 // are kept.  NaN/inf anywhere makes every comparison false: the candidate is kept.
+// The two factors of the margins are formed here from the FP32 edges themselves (8 instructions) rather than read from the
+// record: a fourth 16-byte gather per candidate costs more in the texture-address unit than the arithmetic does in the
+// VALU.  Rounding of the edges to FP32 and of the sums below loses at most ~8 x 2^-24 relative; both factors are inflated
+// by 2^-20 twice over that.  A quadrilateral's record carries NaN in e1f[0]: every comparison fails, it is never culled.
 HARE_HD bool cull_fp32(float tvx, float tvy, float tvz, float dx, float dy, float dz, float dm /*|d|_1*/,
-                       const float* e1, const float* e2, float ee, float emax)
+                       const float* e1, const float* e2)
 {
     // Explicit fused multiply-adds (the build contracts nothing by itself): this is the filter, not the
     // reference arithmetic -- a fused term has one rounding instead of two, so the bound above still holds.
     const float G = 3.814697265625e-06f;   // 2^-18
+    const float UP = 1.00000095367431640625f;   // 1 + 2^-20
+    const float emax = fmaxf(fmaxf(fmaxf(fabsf(e1[0]), fabsf(e1[1])), fabsf(e1[2])), fmaxf(fmaxf(fabsf(e2[0]), fabsf(e2[1])), fabsf(e2[2]))) * UP;
+    const float ee = (fabsf(e1[0]) + fabsf(e1[1]) + fabsf(e1[2])) * emax * UP;
     const float px = __builtin_fmaf(dy, e2[2], -(dz * e2[1]));
     const float py = __builtin_fmaf(dz, e2[0], -(dx * e2[2]));
     const float pz = __builtin_fmaf(dx, e2[1], -(dy * e2[0]));

@@ -249,7 +249,7 @@ HARE_HD void trace_octree(const OctreeArgs& g, const OctFrames& fr, int tid, int
                     if (i == m0 || i == m1 || i == m2 || i == m3) continue;
                     m3 = m2; m2 = m1; m1 = m0; m0 = i;
                     if (cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
-                                  p.e1f, p.e2f, p.ee, p.emax))
+                                  p.e1f, p.e2f))
                         continue;
                 }
                 double t, u, v;

@@ -36,6 +36,9 @@ namespace {
 
 // Events are written exactly once per launch (59 MB per 1M rays) while the scene is re-read all the time: stream
 // them past the caches (non-temporal) so that they do not evict it (+1.3 %; the same for the ray loads measured worse).
+// (Seven 8-byte stores: a record is only 8-byte aligned.  Three 16-byte stores + one 8-byte store, chosen by the record's
+//  alignment, were measured: the extra address arithmetic took K1p from 124 to 133 VGPRs, i.e. from 4 to 3 waves per SIMD,
+//  and 0.50 -> 0.74 ms; the bytes saved never mattered at 6 % HBM utilisation.)
 __device__ __forceinline__ void store_event_streaming(XEventRec* dst, const XEventRec& e)
 {
     double* q = reinterpret_cast<double*>(dst);      // 56-byte records: 8-byte aligned only
@@ -425,16 +428,15 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             if (skip(idx)) {                                                // Voxel_Grid.cs:477 (+ mailbox)
                 next_candidate();
             } else {
-                // first 56 bytes of the record: v0 (FP64) + e1f e2f ee emax (FP32)
+                // first 48 bytes of the record: v0 (FP64) + e1f e2f (FP32)
                 const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + idx);
                 const double2 c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
                 const uint4 r1 = *reinterpret_cast<const uint4*>(rec + 16);          // v0.z | e1f.x e1f.y
                 const float4 fb = *reinterpret_cast<const float4*>(rec + 32);        // e1f.z e2f.x e2f.y e2f.z
-                const float2 fc = *reinterpret_cast<const float2*>(rec + 48);        // ee emax
                 const double c1x = __hiloint2double((int)r1.y, (int)r1.x);
                 const float e1f[3] = {__uint_as_float(r1.z), __uint_as_float(r1.w), fb.x}, e2f[3] = {fb.y, fb.z, fb.w};
                 const float tvx = (float)(o.x - c0.x), tvy = (float)(o.y - c0.y), tvz = (float)(o.z - c1x);
-                if (cull_fp32(tvx, tvy, tvz, dfx, dfy, dfz, dm, e1f, e2f, fc.x, fc.y)) {
+                if (cull_fp32(tvx, tvy, tvz, dfx, dfy, dfz, dm, e1f, e2f)) {
                     done2 = done1;       // a certain miss counts as tested
                     done1 = idx;
                     next_candidate();
@@ -530,7 +532,7 @@ __device__ __forceinline__ void audit_body(const VoxelArgs& g, const ShootIO& io
         for (int k = 0; k < P; ++k) {
             const PolyRec& p = g.polys[k];
             const bool c = cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
-                                     p.e1f, p.e2f, p.ee, p.emax);
+                                     p.e1f, p.e2f);
             double t;
             const bool hit = poly_fast(p, nullptr, o, d, t);
             cands++;
@@ -815,20 +817,19 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         // Two candidates per iteration: both list entries, then both polygon records, are requested together and the culls
         // run back to back -- two culls per pair of dependent loads instead of one.  (This kernel is held to three workgroups
         // per CU by its LDS frames, so the second record in flight costs no occupancy; the voxel kernel has no such room.)
-        struct CullRec { double2 c0; uint4 r1; float4 fb; float2 fc; };
+        struct CullRec { double2 c0; uint4 r1; float4 fb; };
         auto load_rec = [&](int i) {
             const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + i);
             CullRec r;
             r.c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
             r.r1 = *reinterpret_cast<const uint4*>(rec + 16);       // v0.z | e1f.x e1f.y
             r.fb = *reinterpret_cast<const float4*>(rec + 32);      // e1f.z e2f.x e2f.y e2f.z
-            r.fc = *reinterpret_cast<const float2*>(rec + 48);      // ee emax
             return r;
         };
         auto culled = [&](const CullRec& r) {
             const double c1x = __hiloint2double((int)r.r1.y, (int)r.r1.x);
             const float e1f[3] = {__uint_as_float(r.r1.z), __uint_as_float(r.r1.w), r.fb.x}, e2f[3] = {r.fb.y, r.fb.z, r.fb.w};
-            return cull_fp32((float)(o.x - r.c0.x), (float)(o.y - r.c0.y), (float)(o.z - c1x), dfx, dfy, dfz, dm, e1f, e2f, r.fc.x, r.fc.y);
+            return cull_fp32((float)(o.x - r.c0.x), (float)(o.y - r.c0.y), (float)(o.z - c1x), dfx, dfy, dfz, dm, e1f, e2f);
         };
         auto recently = [&](int i) { return i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3; };   // :218 (+ mailbox)
 #pragma unroll 1

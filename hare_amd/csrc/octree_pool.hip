@@ -368,17 +368,15 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
                     const double2 a0 = *reinterpret_cast<const double2*>(reca);
                     const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);
                     const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);
-                    const float2 a3 = *reinterpret_cast<const float2*>(reca + 48);
                     const double2 b0 = *reinterpret_cast<const double2*>(recb);
                     const uint4 b1 = *reinterpret_cast<const uint4*>(recb + 16);
                     const float4 b2 = *reinterpret_cast<const float4*>(recb + 32);
-                    const float2 b3 = *reinterpret_cast<const float2*>(recb + 48);
                     const float ae1[3] = {__uint_as_float(a1.z), __uint_as_float(a1.w), a2.x}, ae2[3] = {a2.y, a2.z, a2.w};
                     const float be1[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), b2.x}, be2[3] = {b2.y, b2.z, b2.w};
                     const bool ca = cull_fp32((float)(r.x - a0.x), (float)(r.y - a0.y), (float)(r.z - __hiloint2double((int)a1.y, (int)a1.x)),
-                                              dfx, dfy, dfz, dm, ae1, ae2, a3.x, a3.y);
+                                              dfx, dfy, dfz, dm, ae1, ae2);
                     const bool cb = cull_fp32((float)(r.x - b0.x), (float)(r.y - b0.y), (float)(r.z - __hiloint2double((int)b1.y, (int)b1.x)),
-                                              dfx, dfy, dfz, dm, be1, be2, b3.x, b3.y);
+                                              dfx, dfy, dfz, dm, be1, be2);
                     // Not in the reference (its mailbox is commented out, :221-222): loose leaves overlap, so a ray meets the
                     // same polygon in several leaves; skipping one it has just tested, and candidates the conservative cull
                     // proves to be misses, cannot change any accepted hit (strict `t < closestT`)

@@ -79,7 +79,18 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     int32_t* const L_idx = reinterpret_cast<int32_t*>(L_qe + S);
     int32_t* const L_nexti = L_idx + S;
     int32_t* const L_d1 = L_nexti + S;
+#if HARE_K1Q_RAY_LDS
+    // doubles first (alignment): origin after the set-up's clip; then the FP32 direction
+    double* const L_ox = reinterpret_cast<double*>(L_d1 + S);
+    double* const L_oy = L_ox + S;
+    double* const L_oz = L_oy + S;
+    float* const L_dfx = reinterpret_cast<float*>(L_oz + S);
+    float* const L_dfy = L_dfx + S;
+    float* const L_dfz = L_dfy + S;
+    uint8_t* const Q_walk = reinterpret_cast<uint8_t*>(L_dfz + S);
+#else
     uint8_t* const Q_walk = reinterpret_cast<uint8_t*>(L_d1 + S);
+#endif
     uint8_t* const Q_cull = Q_walk + R;
     uint8_t* const Q_exact = Q_cull + R;
     uint8_t* const Q_pend = Q_exact + R;
@@ -229,6 +240,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                             L_xyzf[slot] = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (d.x < 0 ? F_NX : 0u) | (d.y < 0 ? F_NY : 0u) |
                                            (d.z < 0 ? F_NZ : 0u) | (moved ? F_MOVED : 0u);
                             L_d1[slot] = -1;
+#if HARE_K1Q_RAY_LDS
+                            L_ox[slot] = o.x; L_oy[slot] = o.y; L_oz[slot] = o.z;
+                            L_dfx[slot] = (float)d.x; L_dfy[slot] = (float)d.y; L_dfz[slot] = (float)d.z;
+#endif
                             double* sc = reinterpret_cast<double*>(&io.out[ray]);      // the ray's scratch (see the header)
                             sc[0] = kDblMax;
                             if (moved) sc[1] = t_start;
@@ -333,6 +348,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 int e1 = -1, e2 = -1;
                 if (io.excl1) e1 = io.excl1[ray];                           // poly_origin1 / 2 (Voxel_Grid.cs:477); wave-uniform branches
                 if (io.excl2) e2 = io.excl2[ray];
+#if HARE_K1Q_RAY_LDS
+                const double ox = L_ox[slot], oy = L_oy[slot], oz = L_oz[slot];
+                const float dfx = L_dfx[slot], dfy = L_dfy[slot], dfz = L_dfz[slot];
+#else
                 const RayRec r = io.rays[ray];
                 double ox = r.x, oy = r.y, oz = r.z;
                 if ((xf & F_MOVED) && !writeback) {
@@ -340,6 +359,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
                 }
                 const float dfx = (float)r.dx, dfy = (float)r.dy, dfz = (float)r.dz;
+#endif
                 const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
                 bool culling = true, parked = false;
                 share_idx = idx;
@@ -349,25 +369,31 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     // requested together; everything below is straight-line selects (a lane that is done computes on its
                     // stale, still valid indices and keeps nothing)
                     const bool has1 = q + 1 < qe;
-                    const unsigned qa = q + 2 < qe ? q + 2 : qe - 1, qb = q + 3 < qe ? q + 3 : qe - 1;
-                    const int i2 = g.items[qa], i3 = g.items[qb];
+                    // the two list entries after the pair: ONE 8-byte gather (4-byte aligned is all the hardware asks for); near
+                    // the end of the list the window slides back so that it stays inside it
+                    int i2, i3;
+                    if (qe - q >= 4u) {
+                        const int2 w = *reinterpret_cast<const int2*>(g.items + q + 2);
+                        i2 = w.x; i3 = w.y;
+                    } else {
+                        const unsigned qa = q + 2 < qe ? q + 2 : qe - 1;
+                        i2 = g.items[qa]; i3 = i2;                           // q + 3 >= qe: i3 is never a candidate
+                    }
                     const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;   // a finished lane may hold -1: stay inside the array
                     const unsigned char* reca = reinterpret_cast<const unsigned char*>(g.polys + ia);
                     const unsigned char* recb = reinterpret_cast<const unsigned char*>(g.polys + ib);
                     const double2 a0 = *reinterpret_cast<const double2*>(reca);          // v0.x v0.y
                     const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);         // v0.z | e1f.x e1f.y
                     const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);       // e1f.z e2f.x e2f.y e2f.z
-                    const float2 a3 = *reinterpret_cast<const float2*>(reca + 48);       // ee emax
                     const double2 b0 = *reinterpret_cast<const double2*>(recb);
                     const uint4 b1 = *reinterpret_cast<const uint4*>(recb + 16);
                     const float4 b2 = *reinterpret_cast<const float4*>(recb + 32);
-                    const float2 b3 = *reinterpret_cast<const float2*>(recb + 48);
                     const float ae1[3] = {__uint_as_float(a1.z), __uint_as_float(a1.w), a2.x}, ae2[3] = {a2.y, a2.z, a2.w};
                     const float be1[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), b2.x}, be2[3] = {b2.y, b2.z, b2.w};
                     const bool ca = cull_fp32((float)(ox - a0.x), (float)(oy - a0.y), (float)(oz - __hiloint2double((int)a1.y, (int)a1.x)),
-                                              dfx, dfy, dfz, dm, ae1, ae2, a3.x, a3.y);
+                                              dfx, dfy, dfz, dm, ae1, ae2);
                     const bool cb = cull_fp32((float)(ox - b0.x), (float)(oy - b0.y), (float)(oz - __hiloint2double((int)b1.y, (int)b1.x)),
-                                              dfx, dfy, dfz, dm, be1, be2, b3.x, b3.y);
+                                              dfx, dfy, dfz, dm, be1, be2);
                     // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the one this ray
                     // tested last is exact (Voxel_Grid.cs:477 + K1p's register mailbox)
                     const bool sk0 = idx == e1 || idx == e2 || idx == done1;

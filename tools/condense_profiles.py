@@ -1,0 +1,71 @@
+"""Condenses the rocprofv3 output of tools/make_profiles.sh into the small files kept under profiles/:
+per configuration the kernel-stats table (top rows), the per-dispatch means of the PMC counters for the hare_* shoot
+kernels, and profiles/traffic.json (HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, FETCH doubled per the
+gfx950 note of MI355X_MICROARCH.md; keyed like bench.py's workload key, stamped with the kernel-source hash)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha)
+
+SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_reflect", "hare_ctr_reduce")
+KEYS = {"c2": "hall-voxel-D64-n1048576", "c2_4M": "hall-voxel-D64-n4194304", "c3": "hall-octree-n1048576",
+        "c4shard": "cathedral-voxel-D128-n2097152", "c5": "cathedral-voxel-D128-n1048576-b8"}
+
+
+def counters(d):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+def main(src):
+    out = os.path.join(ROOT, "profiles")
+    rows = [("config", "kernel", "counter", "mean_per_dispatch", "dispatches")]
+    traffic = {}
+    for tag, key in KEYS.items():
+        ks = glob.glob(os.path.join(src, tag + "_kt", "**", "*kernel_stats.csv"), recursive=True)
+        if ks:
+            lines = open(ks[0]).read().splitlines()
+            with open(os.path.join(out, f"r02_{tag}_kernel_stats.csv"), "w") as f:
+                f.write("\n".join(lines[:9]) + "\n")
+        per = {}
+        for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "TA"):
+            for k, cs in counters(os.path.join(src, f"{tag}_{cset}")).items():
+                if not k.startswith(SHOOT[:4]):
+                    continue
+                for c, v in cs.items():
+                    rows.append((tag, k, c, "%.6g" % (sum(v) / len(v)), len(v)))
+                    per.setdefault(k, {})[c] = sum(v) / len(v)
+        for k, cs in per.items():
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                traffic[key] = {"kernel": k, "FETCH_SIZE_KB": cs["FETCH_SIZE"], "WRITE_SIZE_KB": cs["WRITE_SIZE"],
+                                "hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
+                                "SQ_INSTS_VALU": cs.get("SQ_INSTS_VALU"), "kernel_sha16": bench.kernel_source_sha(),
+                                "note": "separate --pmc passes (rocprofv3); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH doubled per "
+                                        "MI355X_MICROARCH.md (gfx950 tallies 128-B reads at 64 B; calibrated for wide coalesced reads, so an "
+                                        "upper bound for this kernel's 16-B gathers)"}
+        b = os.path.join(src, tag + "_bench.json")
+        if os.path.exists(b):
+            txt = [ln for ln in open(b).read().splitlines() if ln.startswith("{")]
+            if txt:
+                open(os.path.join(out, f"r02_{tag}_bench.json"), "w").write(txt[-1] + "\n")
+    with open(os.path.join(out, "r02_pmc_summary.csv"), "w") as f:
+        for r in rows:
+            f.write(",".join(str(x) for x in r) + "\n")
+    old = {}
+    tj = os.path.join(out, "traffic.json")
+    if os.path.exists(tj):
+        old = {k: v for k, v in json.load(open(tj)).items() if k not in traffic and "(" in k}     # keep the labelled history entries
+    old.update(traffic)
+    json.dump(old, open(tj, "w"), indent=1)
+    for r in rows:
+        print(*r)
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
