@@ -36,7 +36,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("hare_amd/csrc/kernels.hip", "hare_amd/csrc/hare_math.h", "hare_amd/csrc/hare_device.h")
+KERNEL_SOURCES = ("hare_amd/csrc/kernels.hip", "hare_amd/csrc/voxel_pool.hip", "hare_amd/csrc/octree_pool.hip", "hare_amd/csrc/hare_math.h",
+                  "hare_amd/csrc/hare_trace.h", "hare_amd/csrc/hare_device.h")
 
 
 def parse_args(argv=None):
@@ -342,10 +343,23 @@ def main() -> None:
         copy_gbs = 2 * a.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del a, b_
         if B == 1 and not args.no_e2e:
-            part.Shoot_batch(rays_h)            # sizes the scene's staging buffers: not part of the measurement
-            t1 = time.perf_counter()
-            part.Shoot_batch(rays_h)
-            e2e = n / (time.perf_counter() - t1) / 1e6
+            # host buffers in, host buffers out (H2D + kernel + D2H inside one hare_shoot_batch): the PCIe-inclusive rate
+            import ctypes as C
+            ev_h = np.zeros(n, H.capi.XEVENT_DTYPE)
+            ctr_h = H.capi.Counters()
+
+            def host_call():
+                H.capi.check(H.capi.lib.hare_shoot_batch(part._h, part._kind, 0, n, rays_h.ctypes.data, None, None, 0, ev_h.ctypes.data,
+                                                         C.addressof(ctr_h)))
+
+            host_call()                         # sizes the scene's staging buffers: not part of the measurement
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                host_call()
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            e2e = n / best / 1e6
 
     if rank != 0:
         if dist is not None:
