@@ -111,8 +111,9 @@ def spawn_ranks(world: int, argv, script: str | None = None) -> int:
         sys.stderr.write(f"bench.py: rank {failed[0]} exited with code {failed[1]}\n")
         return 1
     t.join(timeout=10)
-    out = "".join(lines)
-    sys.stdout.write(out)
+    # stdout carries the ONE JSON line; anything else rank 0 (or a library under it) printed goes to stderr
+    for ln in lines:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
     sys.stdout.flush()
     if not any(ln.lstrip().startswith("{") for ln in lines):
         sys.stderr.write("bench.py: rank 0 printed no JSON line\n")

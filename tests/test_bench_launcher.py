@@ -26,7 +26,8 @@ def test_launcher_starts_n_ranks_and_relays_rank0_json():
     r = _launch((2, []))
     assert r.returncode == 0, r.stderr
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(line) == 1
+    assert len(line) == 1 and r.stdout.strip() == line[0]      # stdout is the JSON line and nothing else
+    assert "noise before the line" in r.stderr
     j = json.loads(line[0])
     assert j == {"n_gpus": 2, "sum": 3, "tens": 20, "local_rank": "0", "master": "127.0.0.1"}
 
