@@ -776,16 +776,18 @@ void hare_scene_destroy(hare_scene* s)
         if (s->stream) (void)H->StreamSynchronize(s->stream);
         for (auto* v : {&s->d_polys, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
-        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_part, &s->d_rays,
-                         &s->d_e1, &s->d_e2, &s->d_out, &s->d_ctr})
+        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_part})
             dev_free(H, *p);
+        for (Scene::BatchCtx& c : s->ctx) {
+            for (hipStream_t& x : c.st)
+                if (x) { (void)H->StreamSynchronize(x); (void)H->StreamDestroy(x); x = nullptr; }
+            for (void** p : {&c.d_rays, &c.d_e1, &c.d_e2, &c.d_out, &c.d_ctr}) dev_free(H, *p);
+        }
         for (int k = 0; k < kOctScratchRing; ++k) {
             dev_free(H, s->d_oct_scratch[k]);
             if (s->oct_scratch_ev[k]) (void)H->EventDestroy(s->oct_scratch_ev[k]);
         }
         if (s->stream) (void)H->StreamDestroy(s->stream);
-        for (hipStream_t& x : s->extra_streams)
-            if (x) (void)H->StreamDestroy(x);
     }
     delete s;
 }
@@ -1111,31 +1113,46 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     // value) excludes nothing.  Only the device-resident bounce loop (hare_reflect_device + hare_shoot_device) may
     // retire rays, so the retire flag never passes here, nor do developer bits.
     flags = sanitize_flags(flags) & ~HARE_SHOOT_RETIRED_RAYS;
-    std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard dev_guard(hip_api(nullptr), s->device);
     const HipApi* H = nullptr;
-    int rc = ensure_device(*s, H);
-    if (rc) return rc;
-    if (ctr) memset(ctr, 0, sizeof *ctr);
-    if (n == 0) return HARE_OK;
-    if (n > s->staged_cap) {
-        for (void** p : {&s->d_rays, &s->d_e1, &s->d_e2, &s->d_out}) dev_free(H, *p);
-        s->staged_cap = 0;
-        HIP_TRY(H->Malloc(&s->d_rays, (size_t)n * sizeof(hare_ray)));
-        HIP_TRY(H->Malloc(&s->d_e1, (size_t)n * sizeof(int32_t)));
-        HIP_TRY(H->Malloc(&s->d_e2, (size_t)n * sizeof(int32_t)));
-        HIP_TRY(H->Malloc(&s->d_out, (size_t)n * sizeof(hare_xevent)));
-        s->staged_cap = n;
+    Scene::BatchCtx* c = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(s->mu);
+        int rc = ensure_device(*s, H);
+        if (rc) return rc;
+        if (ctr) memset(ctr, 0, sizeof *ctr);
+        if (n == 0) return HARE_OK;
+        // a free staging context, or wait for one: concurrent callers (Pachyderm's worker threads) run side by side
+        s->cv.wait(lk, [&] { for (Scene::BatchCtx& x : s->ctx) if (!x.busy) return true; return false; });
+        for (Scene::BatchCtx& x : s->ctx)
+            if (!x.busy && x.cap >= n) { c = &x; break; }          // prefer one that is already large enough
+        if (!c)
+            for (Scene::BatchCtx& x : s->ctx)
+                if (!x.busy) { c = &x; break; }
+        c->busy = true;
     }
+    struct Release {
+        hare_scene* s; Scene::BatchCtx* c;
+        ~Release() { { std::lock_guard<std::mutex> lk(s->mu); c->busy = false; } s->cv.notify_one(); }
+    } release{s, c};
     constexpr int kMaxChunks = 3;
-    if (!s->d_ctr) HIP_TRY(H->Malloc(&s->d_ctr, kMaxChunks * sizeof(hare_counters)));
+    if (n > c->cap) {
+        for (void** p : {&c->d_rays, &c->d_e1, &c->d_e2, &c->d_out}) dev_free(H, *p);
+        c->cap = 0;
+        HIP_TRY(H->Malloc(&c->d_rays, (size_t)n * sizeof(hare_ray)));
+        HIP_TRY(H->Malloc(&c->d_e1, (size_t)n * sizeof(int32_t)));
+        HIP_TRY(H->Malloc(&c->d_e2, (size_t)n * sizeof(int32_t)));
+        HIP_TRY(H->Malloc(&c->d_out, (size_t)n * sizeof(hare_xevent)));
+        c->cap = n;
+    }
+    if (!c->d_ctr) HIP_TRY(H->Malloc(&c->d_ctr, kMaxChunks * sizeof(hare_counters)));
     // A large batch is pipelined as up to three chunks, each on its own stream and driven by its own host thread:
     // upload, kernel and download of different chunks overlap (both PCIe directions busy), which measured +24 % on
     // pageable host buffers (402 -> 499 Mrays/s for 1M rays, 426 -> 537 for 4M).  More chunks lose again: small launches are inefficient.
     int K = n >= 196608 ? kMaxChunks : 1;
     if (const char* e = getenv("HARE_BATCH_CHUNKS")) K = std::max(1, std::min(kMaxChunks, atoi(e)));
-    for (int k = 1; k < K; ++k)
-        if (!s->extra_streams[k - 1]) HIP_TRY(H->StreamCreate(&s->extra_streams[k - 1]));
+    for (int k = 0; k < K; ++k)
+        if (!c->st[k]) HIP_TRY(H->StreamCreate(&c->st[k]));
     hare_counters parts[kMaxChunks];
     memset(parts, 0, sizeof parts);
     int rcs[kMaxChunks] = {HARE_OK, HARE_OK, HARE_OK};
@@ -1143,11 +1160,11 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     auto chunk_body = [&](int k, hipStream_t st) -> int {
         const int64_t lo = (int64_t)((__int128)n * k / K), m = (int64_t)((__int128)n * (k + 1) / K) - lo;
         if (m == 0) return HARE_OK;
-        hare_ray* dr = (hare_ray*)s->d_rays + lo;
-        int32_t* de1 = (int32_t*)s->d_e1 + lo;
-        int32_t* de2 = (int32_t*)s->d_e2 + lo;
-        hare_xevent* dout = (hare_xevent*)s->d_out + lo;
-        hare_counters* dctr = (hare_counters*)s->d_ctr + k;
+        hare_ray* dr = (hare_ray*)c->d_rays + lo;
+        int32_t* de1 = (int32_t*)c->d_e1 + lo;
+        int32_t* de2 = (int32_t*)c->d_e2 + lo;
+        hare_xevent* dout = (hare_xevent*)c->d_out + lo;
+        hare_counters* dctr = (hare_counters*)c->d_ctr + k;
         HIP_TRY(H->MemcpyAsync(dr, rays + lo, (size_t)m * sizeof(hare_ray), hipMemcpyHostToDevice, st));
         if (excl1) HIP_TRY(H->MemcpyAsync(de1, excl1 + lo, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (excl2) HIP_TRY(H->MemcpyAsync(de2, excl2 + lo, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1163,7 +1180,7 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     };
     auto chunk = [&](int k) -> int {
         DeviceGuard g(H, s->device);                            // the current device is per host thread
-        hipStream_t st = k == 0 ? s->stream : s->extra_streams[k - 1];
+        hipStream_t st = c->st[k];
         const int r = chunk_body(k, st);
         // a failed step leaves earlier async copies into the caller's buffers in flight: drain them before the
         // error reaches a caller who may free those buffers

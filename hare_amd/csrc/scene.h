@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -129,16 +130,24 @@ struct Scene {
     std::atomic<unsigned> work_slot{0};
     void* d_part = nullptr;                      // per-wave {rays, hits} partials: kPartSlots launches x kPartWaves waves
 
-    // staging for hare_shoot_batch (guarded by mu)
+    // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
+    // over), so that host threads calling on one scene run side by side instead of queueing on one mutex; `mu` guards
+    // the one-time device set-up and the hand-out of contexts only, never a transfer or a kernel
+    struct BatchCtx {
+        hipStream_t st[3] = {nullptr, nullptr, nullptr};
+        void* d_rays = nullptr;
+        void* d_e1 = nullptr;
+        void* d_e2 = nullptr;
+        void* d_out = nullptr;
+        void* d_ctr = nullptr;
+        int64_t cap = 0;
+        bool busy = false;
+    };
+    static constexpr int kBatchCtx = 4;
     std::mutex mu;
-    hipStream_t stream = nullptr;
-    hipStream_t extra_streams[2] = {nullptr, nullptr};   // hare_shoot_batch pipelines a large batch as up to 3 chunks
-    void* d_rays = nullptr;
-    void* d_e1 = nullptr;
-    void* d_e2 = nullptr;
-    void* d_out = nullptr;
-    void* d_ctr = nullptr;
-    int64_t staged_cap = 0;
+    std::condition_variable cv;
+    BatchCtx ctx[kBatchCtx];
+    hipStream_t stream = nullptr;                // the scene's own stream (builders)
 
     const DeviceModule* module = nullptr;
 

@@ -16,8 +16,10 @@
  *   - per-ray conditions (origin outside the grid, NaN direction, ...) are not errors: they give
  *     the miss record X_Event() (Hare_Geometry_Primitives.cs:454-462).
  *   - threading: build/destroy calls are single-caller; hare_shoot_batch may be called from
- *     several host threads on one scene (calls are serialised on an internal mutex per scene);
- *     hare_shoot_device is stream-ordered and takes no lock; hare_shoot_one takes no lock either.
+ *     several host threads on one scene: up to four calls run side by side, each on its own
+ *     staging buffers and streams, further callers wait for a free set (what the reference's
+ *     Ray.ThreadID / mailbox pool serve, Voxel_Grid.cs:334-342); hare_shoot_device is
+ *     stream-ordered and takes no lock; hare_shoot_one takes no lock either.
  *   - devices: every call acts on the scene's own device and leaves the calling thread's current
  *     HIP device as it found it.
  *   - batches have NO CPU fallback: hare_shoot_batch / hare_shoot_device run the HIP kernels and fail

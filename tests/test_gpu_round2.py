@@ -394,3 +394,34 @@ def test_both_octree_kernels(hall, kernel, monkeypatch):
     torch.cuda.synchronize()
     for k in range(8):
         assert outs[k].cpu().numpy().tobytes() == ref.tobytes(), f"launch {k}"
+
+
+def test_concurrent_batch_callers_on_one_scene(hall):
+    """Pachyderm shoots from many worker threads at once: six host threads call Shoot_batch on ONE scene at the same time
+    (four staging contexts: two of them wait their turn), different ray sets and sizes, voxel and octree; every result
+    equals the oracle's and the counters add up."""
+    import threading
+    m, T, To = hall
+    g, o = H.Voxel_Grid([T], 64), po.VoxelGrid([To], domain=64)
+    sizes = [300_000, 70_000, 1_000, 250_000, 33, 120_000]
+    burst = H.scenes.burst_rays(1 << 22, m.size)
+    sets = [burst[k::7][:n].copy() for k, n in enumerate(sizes)]
+    assert [len(r) for r in sets] == sizes
+    refs = [o.shoot(r, nthreads=8) for r in sets]
+    got = [None] * len(sets)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                got[k] = g.Shoot_batch(sets[k])
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(sets))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for k, ((ev, c), (ref, rc)) in enumerate(zip(got, refs)):
+        assert_events_equal(ev, ref, what=f"thread {k}")
+        assert (c["rays"], c["hits"]) == (sizes[k], rc["hits"])
