@@ -221,6 +221,13 @@ def main() -> None:
     d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     sp = stream.cuda_stream
+    # A caller streams NEW rays in and events out every batch.  Re-casting one pair of buffers would leave them warm in the
+    # 256 MiB Infinity Cache from step to step; the timed steps therefore rotate through enough copies (same rays) that a
+    # buffer's lines have been evicted by the time it comes round again: rays are read from HBM, events written to HBM.
+    per_set = n * (48 + 56)
+    n_sets = 1 if args.bounces > 1 else max(2, min(8, -(-640 * 1024 * 1024 // per_set)))
+    ray_sets = [d_rays] + [d_rays.clone() for _ in range(n_sets - 1)]
+    out_sets = [d_out] + [torch.empty_like(d_out) for _ in range(n_sets - 1)]
 
     d_rays0 = d_rays.clone() if B > 1 else None
     d_excl = torch.full((n,), -1, dtype=torch.int32, device="cuda") if B > 1 else None
@@ -229,7 +236,7 @@ def main() -> None:
     ctrs = [torch.zeros(8, dtype=torch.int64, device="cuda"), torch.zeros(8, dtype=torch.int64, device="cuda")]
     pending = [None, None]
     reduced = [None, None]
-    state = {"k": 0}
+    state = {"k": 0, "set": 0}
 
     def cast_pass(c_ptr, events=None):
         """One pass of the hot path over this rank's batch: 1 cast, or B casts with a specular bounce between them."""
@@ -246,9 +253,10 @@ def main() -> None:
                 if b + 1 < B:
                     part.reflect_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl.data_ptr(), stream=sp)
         else:
+            i = state["set"] = (state["set"] + 1) % n_sets
             if events is not None:
                 events[0].record(stream)
-            part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=c_ptr, stream=sp)
+            part.shoot_device(n, ray_sets[i].data_ptr(), out_sets[i].data_ptr(), d_counters=c_ptr, stream=sp)
             if events is not None:
                 events[1].record(stream)
 
@@ -324,7 +332,7 @@ def main() -> None:
     torch.cuda.synchronize()
     per_cast_ms = [sum(evs[r][2 * b].elapsed_time(evs[r][2 * b + 1]) for r in range(nrep)) / nrep for b in range(B)]
     kern_ms = sum(per_cast_ms) / B            # average duration of one shoot launch
-    events_dev = d_out.cpu().numpy().tobytes() if B == 1 else None   # the bench buffers themselves, for the parity check
+    events_dev = out_sets[state["set"]].cpu().numpy().tobytes() if B == 1 else None   # the bench buffers themselves, for the parity check
 
     # measured device-copy bandwidth (what "HBM peak" means in practice on this box) and the host-buffer (PCIe-inclusive) rate
     copy_gbs = None
@@ -473,6 +481,7 @@ def main() -> None:
                                f"({mesh.P} triangles), {kdesc}, closest hit (X_Event)"
                                + (f", x{B} specular bounces device-resident (value = casts/s)" if B > 1 else ""),
                    "rays_per_gpu": n, "triangles": mesh.P, "partition": kdesc, "sharding": f"rays x{world}, scene replicated",
+                   "buffer_sets": n_sets,
                    "backend": ("none" if world == 1 else ("rccl" if args.backend == "nccl" else "gloo (rehearsal)"))},
         "ms_per_step_per_rank": {"max": round(max(walls) * 1e3 / args.steps, 4), "min": round(min(walls) * 1e3 / args.steps, 4)},
         "device_ms_per_step": round(dev_ms / args.steps, 4), "kernel_only_mrays_s": round(n / kern_ms / 1e3, 2),

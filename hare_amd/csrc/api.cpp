@@ -525,12 +525,12 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return HARE_E_STATE;
         }
         constexpr unsigned kLdsMax = 160u * 1024u;
-        if ((size_t)g.max_depth * 64u * 24u > kLdsMax) {   // cannot happen while hare_octree_build caps maxDepth at 24
+        if ((size_t)g.max_depth * 64u * 24u > kLdsMax) {   // (24 bytes per level and lane: the simple kernel's frames)   // cannot happen while hare_octree_build caps maxDepth at 24
             set_error("hare_shoot: octree is deeper than the per-lane frames the kernels keep in LDS (" +
                       std::to_string(g.max_depth) + " levels)");
             return HARE_E_UNSUPPORTED;
         }
-        const unsigned plds = (unsigned)g.max_depth * 256u * 24u;   // persistent kernel: 24 bytes x levels x 256 lanes per workgroup
+        const unsigned plds = (unsigned)g.max_depth * 256u * 20u;   // persistent kernel: 20 bytes x levels x 256 lanes per workgroup (interval + child word)
         // K2q (octree_pool.hip): more rays than lanes; frames below the top one in a device scratch block per launch in flight
         if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_pool && n < 0x7FFFFF00ll && g.n_nodes < (1 << 23) && octree_pool_wanted(n)) {
             const unsigned stride = 24u + 24u * (unsigned)g.max_depth;
@@ -584,8 +584,13 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * (unsigned)kOctPoolWaves, st);
             return rc;
         }
-        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && plds <= kLdsMax) {
-            unsigned per_cu = std::min(4u, std::max(1u, (unsigned)(kLdsMax / plds)));
+        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && plds <= kLdsMax && g.n_nodes < (1 << 23)) {
+            // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
+            // grid must not exceed what is resident, or the extra workgroups start when the others have finished
+#ifndef HARE_K2P_WAVES_PER_EU
+#define HARE_K2P_WAVES_PER_EU 4
+#endif
+            unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;

@@ -241,7 +241,10 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the ones
     // this ray has just tested is exact; it replaces the reference's Poly_Ray_ID mailbox
     // (Voxel_Grid.cs:687-689) for the common case of a polygon listed in consecutive voxels.
-    auto skip = [&](int i) { return i == e1 || i == e2 || i == done1 || i == done2; };
+#ifndef HARE_K1P_MAILBOX
+#define HARE_K1P_MAILBOX 0    // measured at C2: the compares on every candidate cost more than re-culling the 15 % repeats (0.502 -> 0.492 ms)
+#endif
+    auto skip = [&](int i) { return i == e1 || i == e2 || (HARE_K1P_MAILBOX >= 1 && i == done1) || (HARE_K1P_MAILBOX >= 2 && i == done2); };
     auto finish = [&](bool hit) {
         XEventRec ev;
         if (hit) {
@@ -612,15 +615,14 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     const int levels = g.max_depth > 0 ? g.max_depth : 1;
     double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] interval start of the frame's node
     double* const fb = fa + (size_t)levels * nt;                    // [levels][nt] interval end
-    int* const fpk = reinterpret_cast<int*>(fb + (size_t)levels * nt);   // [levels][nt] first_child << 4 | (cursor + 1)
-    int* const fnode = fpk + (size_t)levels * nt;                   // [levels][nt] node index of the frame
+    int* const fpk = reinterpret_cast<int*>(fb + (size_t)levels * nt);   // [levels][nt] first_child << 8 | children still to pop (by cursor position)
 
     const int lane = tid & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     // tuned on C3 (tools/sweep_oct.py): parking survivors does not pay here, several culls per round do
 #ifndef HARE_K2P_STEPS
 #define HARE_K2P_STEPS 4
-#define HARE_K2P_CULLS 8
+#define HARE_K2P_CULLS 12
 #define HARE_K2P_REFILL 8
 #define HARE_K2P_EXACT 1
 #endif
@@ -648,10 +650,11 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     double leaf_ca = 0;                 // nodeTmin of the current leaf
     double closestT = kDblMax, bu = 0, bv = 0;
     int pid = -1;
-    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the four polygons tested last (8 measured no better)
+#ifndef HARE_K2P_MAILBOX
+#define HARE_K2P_MAILBOX 0    // measured: 96 of the 100 list entries a ray scans are distinct polygons; the compares cost more than the 4 repeats
+#endif
+    int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the polygons tested last (HARE_K2P_MAILBOX of them)
     unsigned int nhits = 0, nrays = 0;
-    // ray parameters of the top frame's child planes: [axis] low child (near, far), high child (near, far)
-    double nlx = 0, flx = 0, nhx = 0, fhx = 0, nly = 0, fly = 0, nhy = 0, fhy = 0, nlz = 0, flz = 0, nhz = 0, fhz = 0;
 
     auto finish = [&]() {
         XEventRec ev;
@@ -667,41 +670,61 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         store_event_streaming(&io.out[ray], ev);
         alive = false;
     };
-    // child planes of a node box and their ray parameters ("Octree - alt.cs":96-111, :253-263)
-    auto planes = [&](const double* bmin, const double* bmax) {
-        {
-            const double c = (bmax[0] + bmin[0]) / 2;
-            const double a0 = ((bmin[0] - 0.1) - o.x) * invDx, a1 = ((c + 0.1) - o.x) * invDx;
-            const double b0 = ((c - 0.1) - o.x) * invDx, b1 = ((bmax[0] + 0.1) - o.x) * invDx;
-            const bool neg = invDx < 0;
-            nlx = neg ? a1 : a0; flx = neg ? a0 : a1; nhx = neg ? b1 : b0; fhx = neg ? b0 : b1;
-        }
-        {
-            const double c = (bmax[1] + bmin[1]) / 2;
-            const double a0 = ((bmin[1] - 0.1) - o.y) * invDy, a1 = ((c + 0.1) - o.y) * invDy;
-            const double b0 = ((c - 0.1) - o.y) * invDy, b1 = ((bmax[1] + 0.1) - o.y) * invDy;
-            const bool neg = invDy < 0;
-            nly = neg ? a1 : a0; fly = neg ? a0 : a1; nhy = neg ? b1 : b0; fhy = neg ? b0 : b1;
-        }
-        {
-            const double c = (bmax[2] + bmin[2]) / 2;
-            const double a0 = ((bmin[2] - 0.1) - o.z) * invDz, a1 = ((c + 0.1) - o.z) * invDz;
-            const double b0 = ((c - 0.1) - o.z) * invDz, b1 = ((bmax[2] + 0.1) - o.z) * invDz;
-            const bool neg = invDz < 0;
-            nlz = neg ? a1 : a0; flz = neg ? a0 : a1; nhz = neg ? b1 : b0; fhz = neg ? b0 : b1;
-        }
-    };
-    // a node that passed the pop-time tests with interval [ca, cb]
-    auto visit = [&](int node, const OctNode& nd, double ca, double cb) {
+    // A node that passed the pop-time tests with interval [ca, cb].  A leaf hands the lane its list.  An interior node opens
+    // a frame: the PUSH test of :268 -- it depends on the ray, the child box and this interval only, never on the hit so far
+    // -- is made for all eight children at once, on planes derived from the node's own box with BuildOctree's expressions
+    // (:96-111; bit-identical to the stored child boxes), and kept as a mask over cursor positions.  Children are then
+    // popped from order[7] down to order[0] (:286-306); each popped child's interval comes from ITS OWN record, which the
+    // visit needs anyway -- so nothing of the parent has to be re-read or recomputed when the walk comes back to a frame.
+    auto visit = [&](const OctNode& nd, double ca, double cb, auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        auto mx = [](double a, double b) { return FAST ? __builtin_fmax(a, b) : omax(a, b); };
+        auto mn = [](double a, double b) { return FAST ? __builtin_fmin(a, b) : omin(a, b); };
         if (nd.first_child < 0) {
             q = nd.item_start; qe = nd.item_start + nd.item_count; leaf_ca = ca;
         } else {
+            double nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];     // entry / exit parameter of the low (0) and high (1) child slab
+            {
+                const double c = (nd.bmax[0] + nd.bmin[0]) / 2;
+                const double a0 = ((nd.bmin[0] - 0.1) - o.x) * invDx, a1 = ((c + 0.1) - o.x) * invDx;
+                const double b0 = ((c - 0.1) - o.x) * invDx, b1 = ((nd.bmax[0] + 0.1) - o.x) * invDx;
+                const bool neg = invDx < 0;
+                nx[0] = neg ? a1 : a0; fx[0] = neg ? a0 : a1; nx[1] = neg ? b1 : b0; fx[1] = neg ? b0 : b1;
+            }
+            {
+                const double c = (nd.bmax[1] + nd.bmin[1]) / 2;
+                const double a0 = ((nd.bmin[1] - 0.1) - o.y) * invDy, a1 = ((c + 0.1) - o.y) * invDy;
+                const double b0 = ((c - 0.1) - o.y) * invDy, b1 = ((nd.bmax[1] + 0.1) - o.y) * invDy;
+                const bool neg = invDy < 0;
+                ny[0] = neg ? a1 : a0; fy[0] = neg ? a0 : a1; ny[1] = neg ? b1 : b0; fy[1] = neg ? b0 : b1;
+            }
+            {
+                const double c = (nd.bmax[2] + nd.bmin[2]) / 2;
+                const double a0 = ((nd.bmin[2] - 0.1) - o.z) * invDz, a1 = ((c + 0.1) - o.z) * invDz;
+                const double b0 = ((c - 0.1) - o.z) * invDz, b1 = ((nd.bmax[2] + 0.1) - o.z) * invDz;
+                const bool neg = invDz < 0;
+                nz[0] = neg ? a1 : a0; fz[0] = neg ? a0 : a1; nz[1] = neg ? b1 : b0; fz[1] = neg ? b0 : b1;
+            }
+            double nxy[2][2], fxy[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { nxy[i][j] = mx(nx[i], ny[j]); fxy[i][j] = mn(fx[i], fy[j]); }
+            unsigned pushed = 0;
+#pragma unroll
+            for (int oct = 0; oct < 8; ++oct) {
+                const double tmn = mx(nxy[(oct >> 2) & 1][(oct >> 1) & 1], nz[oct & 1]);
+                const double tmx = mn(fxy[(oct >> 2) & 1][(oct >> 1) & 1], fz[oct & 1]);
+                const bool p = !(tmx < tmn || tmx < 0 || tmn > cb || tmx < ca);                   // :268
+                pushed |= p ? (1u << oct) : 0u;
+            }
+            unsigned byc = 0;                                      // octant bit -> cursor bit: cursor k examines octant k ^ mask
+#pragma unroll
+            for (int k = 0; k < 8; ++k) byc |= ((pushed >> (k ^ mask)) & 1u) << k;
             ++lvl;
             fa[lvl * nt + tid] = ca;
             fb[lvl * nt + tid] = cb;
-            fpk[lvl * nt + tid] = (nd.first_child << 4) | 8;      // cursor = 7
-            fnode[lvl * nt + tid] = node;
-            planes(nd.bmin, nd.bmax);
+            fpk[lvl * nt + tid] = (int)(((unsigned)nd.first_child << 8) | byc);
         }
     };
 
@@ -757,7 +780,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
                         const double rmin = omax(omax(tx0, ty0), tz0), rmax = omin(omin(tx1, ty1), tz1);   // :182-183
                         if (rmax < rmin || rmax < 0) finish();               // :185 (and the identical pop test :207)
-                        else visit(0, root, rmin, rmax);
+                        else visit(root, rmin, rmax, std::false_type{});
                     }
                 }
             }
@@ -783,26 +806,26 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     finish();                                                // stack empty: :276-283
                 } else {
                     const int pk = fpk[lvl * nt + tid];
-                    const int cur = (pk & 15) - 1;
-                    if (cur < 0) {
-                        --lvl;                                               // frame exhausted: back to the parent
-                        if (lvl >= 0) {
-                            const OctNode& pn = g.nodes[fnode[lvl * nt + tid]];
-                            planes(pn.bmin, pn.bmax);
-                        }
+                    const unsigned rem = (unsigned)pk & 255u;
+                    if (rem == 0) {
+                        --lvl;                                               // frame exhausted: back to the parent, nothing to re-read
                     } else {
-                        fpk[lvl * nt + tid] = pk - 1;
-                        const int oct = cur ^ mask;                          // order[cur] (:286-306)
-                        const double tmn = mx(mx((oct & 4) ? nhx : nlx, (oct & 2) ? nhy : nly), (oct & 1) ? nhz : nlz);
-                        const double tmx = mn(mn((oct & 4) ? fhx : flx, (oct & 2) ? fhy : fly), (oct & 1) ? fhz : flz);
+                        const int cur = 31 - __builtin_clz(rem);             // pop order: order[7] down to order[0]
+                        fpk[lvl * nt + tid] = pk & ~(1 << cur);
+                        const int c = (int)((unsigned)pk >> 8) + (cur ^ mask);
+                        const OctNode& nd = g.nodes[c];
+                        // the child's slab interval from its own box (:253-266)
+                        double tx0 = (nd.bmin[0] - o.x) * invDx, tx1 = (nd.bmax[0] - o.x) * invDx;
+                        double ty0 = (nd.bmin[1] - o.y) * invDy, ty1 = (nd.bmax[1] - o.y) * invDy;
+                        double tz0 = (nd.bmin[2] - o.z) * invDz, tz1 = (nd.bmax[2] - o.z) * invDz;
+                        if (invDx < 0) { const double sw = tx0; tx0 = tx1; tx1 = sw; }
+                        if (invDy < 0) { const double sw = ty0; ty0 = ty1; ty1 = sw; }
+                        if (invDz < 0) { const double sw = tz0; tz0 = tz1; tz1 = sw; }
+                        const double tmn = mx(mx(tx0, ty0), tz0), tmx = mn(mn(tx1, ty1), tz1);
                         const double pa = fa[lvl * nt + tid], pb = fb[lvl * nt + tid];
-                        if (!(tmx < tmn || tmx < 0 || tmn > pb || tmx < pa)) {           // pushed (:268)
-                            const double ca = mx(tmn, pa), cb = mn(tmx, pb);            // :271
-                            if (!(cb < ca || cb < 0) && !(hit && closestT <= ca)) {      // popped and kept (:207-211)
-                                const int c = (pk >> 4) + oct;
-                                visit(c, g.nodes[c], ca, cb);
-                            }
-                        }
+                        const double ca = mx(tmn, pa), cb = mn(tmx, pb);                     // :271
+                        if (!(cb < ca || cb < 0) && !(hit && closestT <= ca))              // popped and kept (:207-211)
+                            visit(nd, ca, cb, fast_tag);
                     }
                 }
             };
@@ -831,7 +854,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             const float e1f[3] = {__uint_as_float(r.r1.z), __uint_as_float(r.r1.w), r.fb.x}, e2f[3] = {r.fb.y, r.fb.z, r.fb.w};
             return cull_fp32((float)(o.x - r.c0.x), (float)(o.y - r.c0.y), (float)(o.z - c1x), dfx, dfy, dfz, dm, e1f, e2f);
         };
-        auto recently = [&](int i) { return i == e1 || i == e2 || i == m0 || i == m1 || i == m2 || i == m3; };   // :218 (+ mailbox)
+        auto recently = [&](int i) {                                                                    // :218 (+ mailbox)
+            return i == e1 || i == e2 || (HARE_K2P_MAILBOX >= 1 && i == m0) || (HARE_K2P_MAILBOX >= 2 && i == m1) ||
+                   (HARE_K2P_MAILBOX >= 4 && (i == m2 || i == m3));
+        };
 #pragma unroll 1
         for (int kc = 0; kc < CULLS / 2; ++kc) {
             const bool culling = alive && !parked && q < qe;
@@ -848,7 +874,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 if (!sk1) rb = load_rec(i1);
                 bool consumed0 = true;
                 if (!sk0) {
-                    m3 = m2; m2 = m1; m1 = m0; m0 = i0;
+                    if (HARE_K2P_MAILBOX >= 4) { m3 = m2; m2 = m1; }
+                    if (HARE_K2P_MAILBOX >= 2) m1 = m0;
+                    if (HARE_K2P_MAILBOX >= 1) m0 = i0;
                     if (culled(ra)) ++q;
                     else { parked = true; consumed0 = false; }           // phase B2 tests items[q]
                 } else {
@@ -858,7 +886,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     if (sk1) {
                         ++q;
                     } else {
-                        m3 = m2; m2 = m1; m1 = m0; m0 = i1;
+                        if (HARE_K2P_MAILBOX >= 4) { m3 = m2; m2 = m1; }
+                        if (HARE_K2P_MAILBOX >= 2) m1 = m0;
+                        if (HARE_K2P_MAILBOX >= 1) m0 = i1;
                         if (culled(rb)) ++q;
                         else parked = true;
                     }
@@ -957,15 +987,18 @@ __global__ __launch_bounds__(256) void hare_voxel_persist_prof(VoxelArgs g, Shoo
 __global__ __launch_bounds__(256) void hare_cull_audit(VoxelArgs g, ShootIO io) { audit_body(g, io); }
 
 // K2: Octree.Shoot ("Octree - alt.cs":159-284); dynamic LDS = levels * blockDim * 24 bytes
-__global__ void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }
-__global__ void hare_octree_shoot_count(OctreeArgs g, ShootIO io) { octree_shoot_body<true>(g, io); }
+__global__ __launch_bounds__(256) void hare_octree_shoot(OctreeArgs g, ShootIO io) { octree_shoot_body<false>(g, io); }
+__global__ __launch_bounds__(256) void hare_octree_shoot_count(OctreeArgs g, ShootIO io) { octree_shoot_body<true>(g, io); }
 
 // K2p: persistent Octree.Shoot (default octree kernel); dynamic LDS = levels * blockDim * 24 bytes
-__global__ __launch_bounds__(256) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body(g, io); }
+#ifndef HARE_K2P_WAVES_PER_EU
+#define HARE_K2P_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
-__global__ void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }
-__global__ void hare_kdtree_shoot_count(KdArgs g, ShootIO io) { kdtree_shoot_body<true>(g, io); }
+__global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }
+__global__ __launch_bounds__(256) void hare_kdtree_shoot_count(KdArgs g, ShootIO io) { kdtree_shoot_body<true>(g, io); }
 
 // Batch counters of the persistent kernels: sum the per-wave {rays, hits} partials into ctr (one launch
 // of one workgroup after the shoot kernel, same stream).

@@ -44,6 +44,9 @@
 #ifndef HARE_K1Q_TAIL_STEPS
 #define HARE_K1Q_TAIL_STEPS 32    // DDA steps per walk task in that regime
 #endif
+#ifndef HARE_K1Q_MAILBOX
+#define HARE_K1Q_MAILBOX 1        // skip the polygon this ray tested last
+#endif
 #ifndef HARE_K1Q_REFILL_MIN
 #define HARE_K1Q_REFILL_MIN 64    // set up new rays when this many slots are free (a full wave of set-ups)
 #endif
@@ -396,12 +399,12 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                                               dfx, dfy, dfz, dm, be1, be2);
                     // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the one this ray
                     // tested last is exact (Voxel_Grid.cs:477 + K1p's register mailbox)
-                    const bool sk0 = idx == e1 || idx == e2 || idx == done1;
+                    const bool sk0 = idx == e1 || idx == e2 || (HARE_K1Q_MAILBOX && idx == done1);
                     const bool keep0 = culling && !sk0 && !ca;              // candidate 0 survives: it goes to the exact phase
                     const bool step0 = culling && !keep0;                   // candidate 0 consumed
                     const int dn0 = (step0 && !sk0) ? idx : done1;          // a certain miss counts as tested
                     const bool go1 = step0 && has1;
-                    const bool sk1 = nexti == e1 || nexti == e2 || nexti == dn0;
+                    const bool sk1 = nexti == e1 || nexti == e2 || (HARE_K1Q_MAILBOX && nexti == dn0);
                     const bool keep1 = go1 && !sk1 && !cb;
                     const bool step1 = go1 && !keep1;
                     done1 = (step1 && !sk1) ? nexti : dn0;
