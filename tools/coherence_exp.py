@@ -26,9 +26,9 @@ def octa_key(d, bits):
 def main():
     import torch
     import hare_amd as H
-    D = 64; N = int(os.environ.get("RAYS", 1 << 20))
-    mesh = H.scenes.hall(); g = H.Voxel_Grid([H.Topology(mesh.verts, mesh.nverts)], D)
-    rays = H.scenes.burst_rays(N, mesh.size)
+    D = int(os.environ.get("DOMAIN", 64)); N = int(os.environ.get("RAYS", 1 << 20))
+    mesh = H.scenes.SCENES[os.environ.get("SCENE", "hall")](); g = H.Voxel_Grid([H.Topology(mesh.verts, mesh.nverts)], D)
+    rays = H.scenes.burst_rays(int(os.environ.get("BURST", N)), mesh.size, start=int(os.environ.get("START", 0)), count=N)
 
     def run(r, K=20):
         dr = torch.from_numpy(np.ascontiguousarray(r)).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
