@@ -221,16 +221,30 @@ int upload_polys(Scene& s, const HipApi* H)
     if (s.d_polys.size() == s.topos.size()) return HARE_OK;
     s.d_polys.assign(s.topos.size(), nullptr);
     s.d_quads.assign(s.topos.size(), nullptr);
+    s.d_cull.assign(s.topos.size(), nullptr);
+    // all or nothing: a scene whose record arrays are only partly on the device must not look uploaded to the next call
+    auto fail = [&](int rc) {
+        for (auto* v : {&s.d_polys, &s.d_quads, &s.d_cull}) {
+            for (void*& p : *v) dev_free(H, p);
+            v->clear();
+        }
+        return rc;
+    };
+    static_assert(offsetof(PolyRec, ee) == kCullStride, "the pre-cull reads exactly the bytes in front of PolyRec::ee");
     for (size_t m = 0; m < s.topos.size(); ++m) {
         const Topo& T = s.topos[m];
         std::vector<PolyRec> rec;
         std::vector<QuadRec> quads;
         make_poly_records(T, rec, quads);
         int rc = upload(H, &s.d_polys[m], rec.data(), rec.size() * sizeof(PolyRec));
-        if (rc) return rc;
+        if (rc) return fail(rc);
+        std::vector<unsigned char> dense(rec.size() * (size_t)kCullStride);
+        for (size_t p = 0; p < rec.size(); ++p) memcpy(&dense[p * (size_t)kCullStride], &rec[p], (size_t)kCullStride);
+        rc = upload(H, &s.d_cull[m], dense.data(), dense.size());
+        if (rc) return fail(rc);
         if (T.has_quads) {
             rc = upload(H, &s.d_quads[m], quads.data(), quads.size() * sizeof(QuadRec));
-            if (rc) return rc;
+            if (rc) return fail(rc);
         }
     }
     return HARE_OK;
@@ -414,6 +428,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         VoxelArgs g;
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
+        g.cull = (const unsigned char*)s.d_cull[top];
         g.quads = (const QuadRec*)s.d_quads[top];
         g.cells = (const CellRec*)s.d_cells[top];
         g.items = (const int32_t*)s.d_items[top];
@@ -514,6 +529,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         OctreeArgs g;
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
+        g.cull = (const unsigned char*)s.d_cull[top];
         g.quads = (const QuadRec*)s.d_quads[top];
         g.nodes = (const OctNode*)s.d_oct_nodes;
         g.items = (const int32_t*)s.d_oct_items;
@@ -779,7 +795,7 @@ void hare_scene_destroy(hare_scene* s)
     if (H && (s->module || s->stream)) {
         DeviceGuard dev_guard(H, s->device);   // act on the scene's device, leave the caller's current device as it was
         if (s->stream) (void)H->StreamSynchronize(s->stream);
-        for (auto* v : {&s->d_polys, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
+        for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_part})
             dev_free(H, *p);

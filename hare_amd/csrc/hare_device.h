@@ -35,6 +35,16 @@ enum : uint32_t {
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)
 enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_WORDS = 8 };
 
+// The FP32 pre-cull reads bytes 0..47 of a PolyRec (v0, e1f, e2f).  Cell and leaf lists hold runs of consecutive polygon
+// ids (82 % of neighbouring entries differ by one in the bench scenes, tools/list_locality.py), so a copy of just those bytes
+// at a 48-byte stride puts the candidates a ray scans next to each other: 2.7 records per 128-byte line instead of one.
+// Measured: -4 % kernel time at C2 and C3, +12 % casts/s in the bounce loop.  The exact test still
+// reads the 128-byte record.  -DHARE_CULL_DENSE=0 builds the kernels that gather from the record heads (the A/B baseline).
+constexpr int kCullStride = 48;
+#ifndef HARE_CULL_DENSE
+#define HARE_CULL_DENSE 1
+#endif
+
 struct VoxelArgs {
     const PolyRec* polys;
     const QuadRec* quads;      // null when the topology is all triangles
@@ -48,6 +58,7 @@ struct VoxelArgs {
     int32_t occ_cd;
     double omin[3], omax[3];   // OBox
     double vd[3];              // VoxelDims
+    const unsigned char* cull; // dense copy of every record's first kCullStride bytes (what the FP32 pre-cull reads)
 };
 
 struct OctNode {               // 64 bytes
@@ -66,7 +77,19 @@ struct OctreeArgs {
     const int32_t* items;
     int32_t n_nodes;
     int32_t max_depth;
+    const unsigned char* cull; // as in VoxelArgs
 };
+
+// Where the pre-cull's 48 bytes of polygon i live: the dense copy, or the head of the 128-byte record itself
+template <class Args>
+HARE_HD const unsigned char* cull_record(const Args& g, int i)
+{
+#if HARE_CULL_DENSE
+    return g.cull + (size_t)(unsigned)i * (size_t)kCullStride;
+#else
+    return reinterpret_cast<const unsigned char*>(g.polys + i);
+#endif
+}
 
 struct KdNodeRec {             // 80 bytes
     double bmin[3], bmax[3];

@@ -432,7 +432,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                 next_candidate();
             } else {
                 // first 48 bytes of the record: v0 (FP64) + e1f e2f (FP32)
-                const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + idx);
+                const unsigned char* rec = cull_record(g, idx);
                 const double2 c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
                 const uint4 r1 = *reinterpret_cast<const uint4*>(rec + 16);          // v0.z | e1f.x e1f.y
                 const float4 fb = *reinterpret_cast<const float4*>(rec + 32);        // e1f.z e2f.x e2f.y e2f.z
@@ -842,7 +842,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         // per CU by its LDS frames, so the second record in flight costs no occupancy; the voxel kernel has no such room.)
         struct CullRec { double2 c0; uint4 r1; float4 fb; };
         auto load_rec = [&](int i) {
-            const unsigned char* rec = reinterpret_cast<const unsigned char*>(g.polys + i);
+            const unsigned char* rec = cull_record(g, i);
             CullRec r;
             r.c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
             r.r1 = *reinterpret_cast<const uint4*>(rec + 16);       // v0.z | e1f.x e1f.y

@@ -363,8 +363,8 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
                     const unsigned qa = q + 2 < qe ? q + 2 : qe - 1, qb = q + 3 < qe ? q + 3 : qe - 1;
                     const int i2 = g.items[qa], i3 = g.items[qb];
                     const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;
-                    const unsigned char* reca = reinterpret_cast<const unsigned char*>(g.polys + ia);
-                    const unsigned char* recb = reinterpret_cast<const unsigned char*>(g.polys + ib);
+                    const unsigned char* reca = cull_record(g, ia);
+                    const unsigned char* recb = cull_record(g, ib);
                     const double2 a0 = *reinterpret_cast<const double2*>(reca);
                     const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);
                     const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);

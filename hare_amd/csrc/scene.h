@@ -118,6 +118,7 @@ struct Scene {
 
     // device residents (all on `device`)
     std::vector<void*> d_polys;                  // per topo: PolyRec[P]
+    std::vector<void*> d_cull;                   // per topo: first kCullStride bytes of each PolyRec, dense (hare_device.h)
     std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
     int32_t occ_words = 0;                       // words of the occupancy bitmap the persistent kernel stages in LDS

@@ -383,8 +383,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         i2 = g.items[qa]; i3 = i2;                           // q + 3 >= qe: i3 is never a candidate
                     }
                     const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;   // a finished lane may hold -1: stay inside the array
-                    const unsigned char* reca = reinterpret_cast<const unsigned char*>(g.polys + ia);
-                    const unsigned char* recb = reinterpret_cast<const unsigned char*>(g.polys + ib);
+                    const unsigned char* reca = cull_record(g, ia);
+                    const unsigned char* recb = cull_record(g, ib);
                     const double2 a0 = *reinterpret_cast<const double2*>(reca);          // v0.x v0.y
                     const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);         // v0.z | e1f.x e1f.y
                     const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);       // e1f.z e2f.x e2f.y e2f.z
