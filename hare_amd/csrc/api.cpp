@@ -526,6 +526,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             set_error("hare_shoot: octree not built");
             return HARE_E_STATE;
         }
+        if (s.oct.id_count > s.topos[(size_t)top].P) {   // the reference would index Model[top_index] out of range ("Octree - alt.cs":216)
+            set_error("hare_shoot: the octree holds polygon ids of the last topology that topology " + std::to_string(top) + " does not have");
+            return HARE_E_INVALID;
+        }
         OctreeArgs g;
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
@@ -633,6 +637,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         if (!s.kd.built || !s.d_kd_nodes) {
             set_error("hare_shoot: kd-tree not built");
             return HARE_E_STATE;
+        }
+        if (s.kd.id_count > s.topos[(size_t)top].P) {
+            set_error("hare_shoot: the kd-tree holds polygon ids of the last topology that topology " + std::to_string(top) + " does not have");
+            return HARE_E_INVALID;
         }
         KdArgs g;
         memset(&g, 0, sizeof g);

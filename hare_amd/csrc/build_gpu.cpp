@@ -343,6 +343,7 @@ int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_p
     *used = false;
     const DeviceModule& M = *s.module;
     if (!M.ob_count || !M.ob_fill) return HARE_OK;
+    if (s.topos.size() != 1) return HARE_OK;   // several topologies (root of the last, membership by the first): host builder
     const Topo& T = s.topos[0];
     DevMem mem(H);
     BuildArgs b;
@@ -522,6 +523,7 @@ int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_p
         }
         o.nodes[k] = r;
     }
+    o.id_count = T.P;
     o.built = true;
     o.built_on_device = true;
     s.oct = std::move(o);

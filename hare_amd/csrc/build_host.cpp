@@ -359,21 +359,28 @@ int octree_check_args(const Scene& s, int32_t max_depth, int32_t max_polys)
         set_error("hare_octree_build: max_depth must be in [0, 24], max_polys >= 0");
         return HARE_E_INVALID;
     }
-    if (s.topos.size() != 1) {
-        // the reference rebuilds the root per topology and tests membership against Model[0] only
-        // ("Octree - alt.cs":63-88,123): with several topologies its result is not meaningful.
-        set_error("hare_octree_build: exactly one topology is supported (reference uses Model[0] for membership)");
-        return HARE_E_UNSUPPORTED;
+    if (s.topos.empty()) {
+        set_error("hare_octree_build: no topology");
+        return HARE_E_INVALID;
     }
+    // Several topologies, as the reference has it ("Octree - alt.cs":63-88): a fresh root per topology, the LAST one's
+    // stays; its polygon ids 0..P-1 are binned by the vertices of Model[0] (:123).  A topology that is split and has
+    // more polygons than Model[0] makes the reference index Model[0] out of range.
+    for (size_t m = 1; m < s.topos.size(); ++m)
+        if (s.topos[m].P > s.topos[0].P && max_depth > 0 && s.topos[m].P > max_polys) {
+            set_error("hare_octree_build: topology " + std::to_string(m) + " has more polygons than topology 0, whose vertices the "
+                      "reference bins every topology's polygon ids by (\"Octree - alt.cs\":123): IndexOutOfRangeException there");
+            return HARE_E_INVALID;
+        }
     return HARE_OK;
 }
 
 int build_octree(Scene& s, int32_t max_depth, int32_t max_polys)
 {
     if (int rc = octree_check_args(s, max_depth, max_polys)) return rc;
-    const Topo& T = s.topos[0];
+    const Topo& T = s.topos.back();      // root cube and id range: the last topology's (:63-88)
     OBuild b;
-    b.T0 = &T;
+    b.T0 = &s.topos[0];                  // membership: Model[0]'s vertices (:123)
     b.max_depth = max_depth;
     b.max_polys = max_polys;
     OctNode root;
@@ -402,6 +409,7 @@ int build_octree(Scene& s, int32_t max_depth, int32_t max_polys)
         o.nodes[i].item_count = (int32_t)b.lists[i].size();
         o.items.insert(o.items.end(), b.lists[i].begin(), b.lists[i].end());
     }
+    o.id_count = T.P;
     o.built = true;
     s.oct = std::move(o);
     return HARE_OK;
@@ -480,11 +488,20 @@ int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys)
         set_error("hare_kdtree_build: max_depth must be in [0, 60], max_polys >= 0");
         return HARE_E_INVALID;
     }
-    if (s.topos.size() != 1) {
-        set_error("hare_kdtree_build: exactly one topology is supported (reference uses Model[0] for membership)");
-        return HARE_E_UNSUPPORTED;
+    if (s.topos.empty()) {
+        set_error("hare_kdtree_build: no topology");
+        return HARE_E_INVALID;
     }
-    const Topo& T = s.topos[0];
+    // Several topologies, as the reference has it (KDTree.cs:67-87): the bounding box grows over the topologies, a fresh
+    // root per topology, the LAST one's stays; its polygon ids are split by the centroids and vertices of Model[0] (:98-133).
+    for (size_t m = 1; m < s.topos.size(); ++m)
+        if (s.topos[m].P > s.topos[0].P && max_depth > 0 && s.topos[m].P > max_polys) {
+            set_error("hare_kdtree_build: topology " + std::to_string(m) + " has more polygons than topology 0, whose centroids the "
+                      "reference splits every topology's polygon ids by (KDTree.cs:98-105): IndexOutOfRangeException there");
+            return HARE_E_INVALID;
+        }
+    const Topo& T = s.topos[0];          // centroids and membership: Model[0]
+    const Topo& TL = s.topos.back();     // id range: the last topology's
     KBuild b;
     b.T0 = &T;
     b.max_depth = max_depth;
@@ -503,16 +520,17 @@ int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys)
         b.cent[3 * (size_t)p + 2] = sz / T.nverts[p];
     }
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int32_t p = 0; p < T.P; ++p)
-        for (int c = 0; c < T.nverts[p]; ++c)
-            for (int a = 0; a < 3; ++a) {
-                const double v = T.verts[(size_t)p * 12 + 3 * c + a];
-                if (v < mn[a]) mn[a] = v;
-                if (v > mx[a]) mx[a] = v;
-            }
+    for (const Topo& Tm : s.topos)       // min / max are not reset between topologies (:67-82)
+        for (int32_t p = 0; p < Tm.P; ++p)
+            for (int c = 0; c < Tm.nverts[p]; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    const double v = Tm.verts[(size_t)p * 12 + 3 * c + a];
+                    if (v < mn[a]) mn[a] = v;
+                    if (v > mx[a]) mx[a] = v;
+                }
     const int32_t root = kd_new(b, mn, mx);
-    b.lists[root].resize(T.P);
-    for (int32_t i = 0; i < T.P; ++i) b.lists[root][i] = i;
+    b.lists[root].resize(TL.P);
+    for (int32_t i = 0; i < TL.P; ++i) b.lists[root][i] = i;
     kd_split(b, root, 0, mn, mx);
 
     KdHost k;
@@ -532,6 +550,7 @@ int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys)
         k.nodes[i].item_count = (int32_t)b.lists[i].size();
         k.items.insert(k.items.end(), b.lists[i].begin(), b.lists[i].end());
     }
+    k.id_count = TL.P;
     k.built = true;
     s.kd = std::move(k);
     return HARE_OK;

@@ -93,8 +93,12 @@ extern "C" int hare_shoot_one(hare_scene* s, int32_t kind, int32_t top_index, ha
             set_error("hare_shoot_one: partition not built");
             return HARE_E_STATE;
         }
-        const HostMirror* hm = host_mirror(*s);
         const size_t top = (size_t)top_index;
+        if ((kind == HARE_KIND_OCTREE && s->oct.id_count > s->topos[top].P) || (kind == HARE_KIND_KDTREE && s->kd.id_count > s->topos[top].P)) {
+            set_error("hare_shoot_one: the tree holds polygon ids of the last topology that topology " + std::to_string(top_index) + " does not have");
+            return HARE_E_INVALID;
+        }
+        const HostMirror* hm = host_mirror(*s);
         const PolyRec* polys = hm->polys[top].data();
         const QuadRec* quads = hm->quads[top].empty() ? nullptr : hm->quads[top].data();
         V3 o = {ray->x, ray->y, ray->z};

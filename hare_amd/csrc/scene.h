@@ -52,6 +52,7 @@ struct OctreeHost {
     bool built = false;
     bool built_on_device = false;
     int32_t max_depth = 0, max_polys = 0;
+    int32_t id_count = 0;      // polygon ids in the lists are < id_count (= Polygon_Count of the LAST topology, see build_octree)
     std::vector<OctNode> nodes;
     std::vector<int32_t> items;
 };
@@ -59,6 +60,7 @@ struct OctreeHost {
 struct KdHost {
     bool built = false;
     int32_t max_depth = 0, max_polys = 0;
+    int32_t id_count = 0;      // as OctreeHost::id_count
     int32_t depth_reached = 0;
     std::vector<KdNodeRec> nodes;
     std::vector<int32_t> items;

@@ -142,13 +142,17 @@ HARE_API int hare_scene_create(const hare_topology_desc *topos, int32_t n_topos,
 HARE_API void hare_scene_destroy(hare_scene *s);
 
 /* ---- partition constructors ----
- * The voxel grid is built on the GPU when one is present (environment HARE_BUILD=host forces the host
- * builder); both builders produce identical lists.  Octree / KDTree are built on the host.
+ * The voxel grid and the octree (of a single topology) are built on the GPU when one is present (environment
+ * HARE_BUILD=host forces the host builders); both builders produce identical lists.  The KDTree is built on the host.
  * Voxel_Grid(Topology[] Model_in, int Domain)                      Voxel_Grid.cs:48-121  */
 HARE_API int hare_voxel_build(hare_scene *s, int32_t domain);
 /* Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys)    Voxel_Grid.cs:128-254 */
 HARE_API int hare_voxel_build_adaptive(hare_scene *s, int32_t max_domain, int32_t avg_polys);
-/* Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) "Octree - alt.cs":45-89 */
+/* Octree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) "Octree - alt.cs":45-89
+ * Several topologies: as the reference is written -- the root cube and the ids 0..P-1 of the LAST topology, binned by the
+ * vertices of topology 0 (:63-88,123); the kd-tree's box grows over all topologies (KDTree.cs:67-87).  HARE_E_INVALID where
+ * the reference would index out of range: a topology that gets split and has more polygons than topology 0 (at build), a
+ * top_index whose topology has fewer polygons than the last one (at shoot). */
 HARE_API int hare_octree_build(hare_scene *s, int32_t max_depth, int32_t max_polys);
 /* KDTree(Topology[] Model_In, int maxDepth, int maxPolygonsPerNode) KDTree.cs:51-88 */
 HARE_API int hare_kdtree_build(hare_scene *s, int32_t max_depth, int32_t max_polys);
