@@ -30,10 +30,10 @@
 #define HARE_K1Q_WALK_MIN 20      // a walk task ends early when fewer lanes than this are still walking
 #endif
 #ifndef HARE_K1Q_CULL_PAIRS
-#define HARE_K1Q_CULL_PAIRS 2     // pairs of candidates per cull task
+#define HARE_K1Q_CULL_PAIRS 4     // pairs of candidates per cull task (swept 1..8: DESIGN.md section 9)
 #endif
 #ifndef HARE_K1Q_EXACT_MIN
-#define HARE_K1Q_EXACT_MIN 40     // run the exact phase when this many rays wait for it (or nothing else can run)
+#define HARE_K1Q_EXACT_MIN 24     // run the exact phase when this many rays wait for it (or nothing else can run); swept 8..56
 #endif
 #ifndef HARE_K1Q_PEND_MIN
 #define HARE_K1Q_PEND_MIN 16      // the same for the pending-hit walk
