@@ -317,17 +317,28 @@ int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, u
 // Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass when the process
 // opted in with HARE_DEV=1 (tools/, the cull-audit test), so a stray bit from a caller can never reach a kernel.
-// Which production voxel kernel serves a batch (measured on MI355X): K1q (hare_voxel_pool_*, rays outnumber
-// lanes) wins once a launch is long enough for its steady state to outweigh its longer ramp and drain -- from ~1.5M
-// rays on a fine grid, and from 1M rays on the coarse-bitmap grids (D > 80), whose rays are several times longer; K1p
-// (hare_voxel_persist_*) below that.  HARE_VOXEL_KERNEL=pool|persist overrides (developer A/B).
-bool voxel_pool_wanted(int64_t n, bool coarse)
+// Which production voxel kernel serves a batch (measured on MI355X over 9 scene / grid combinations):
+//  * a scene whose records are far beyond the L2 (the 986k-triangle cathedral, ~200 MB): K1q (hare_voxel_pool_*) at every
+//    batch size -- it keeps 1.5x the rays in flight per CU and requests eight candidates' records per task, which is what
+//    covers miss latency (-7 ... -31 % against K1p from 16k to 2M rays);
+//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 23 - 52 MB): K1p (hare_voxel_persist_*) between ~200k
+//    and ~1.18M rays (K1q +2 ... +33 % there), K1q below (one short launch is all latency: -5 ... -21 % from 64 to 131k
+//    rays) and above (its steady state outweighs its longer ramp and drain: -2 % at 1.18M, -9 % at 1.5M, -20 % at 16M).
+// HARE_VOXEL_KERNEL=pool|persist overrides (developer A/B).
+size_t voxel_scene_bytes(const Scene& s, size_t top)
+{
+    const size_t ncell = (size_t)s.vox.ct * s.vox.ct * s.vox.ct;
+    const size_t items = top < s.vox.items.size() ? s.vox.items[top].size() : 0;
+    return (size_t)s.topos[top].P * (sizeof(PolyRec) + (size_t)kCullStride) + ncell * sizeof(CellRec) + items * sizeof(int32_t);
+}
+bool voxel_pool_wanted(const Scene& s, size_t top, int64_t n)
 {
     if (const char* vk = getenv("HARE_VOXEL_KERNEL")) {
         if (strcmp(vk, "pool") == 0) return true;
         if (strcmp(vk, "persist") == 0) return false;
     }
-    return n >= (coarse ? (1ll << 20) : 1572864ll);
+    if (voxel_scene_bytes(s, top) > (96ull << 20)) return true;
+    return n <= 196608ll || n >= 1179648ll;
 }
 constexpr bool kOctreePoolDefault = false;
 // The octree's production kernels: K2q (hare_octree_pool) / K2p (hare_octree_persist); HARE_OCTREE_KERNEL=pool|persist overrides.
@@ -467,7 +478,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         {
             const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
             hipFunction_t pf = !coarse ? (quads ? M.voxel_pool_quad : M.voxel_pool_tri) : (quads ? M.voxel_pool_quad_g : M.voxel_pool_tri_g);
-            if (pf && voxel_pool_wanted(n, coarse) && voxel_pool_usable(s, flags)) {
+            if (pf && voxel_pool_wanted(s, (size_t)top, n) && voxel_pool_usable(s, flags)) {
                 if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
                 unsigned pgrid = (unsigned)std::max(1, M.cu_count);
                 pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
@@ -1353,7 +1364,7 @@ const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t to
         if (count) return "hare_voxel_shoot_count";
         if (simple || n >= 0x7FFFFF00ll) return quads ? "hare_voxel_shoot_quad" : "hare_voxel_shoot_tri";
         const bool coarse = s->occ_shift > 0;
-        if (voxel_pool_wanted(n, coarse) && voxel_pool_usable(*s, flags))
+        if (voxel_pool_wanted(*s, (size_t)top_index, n) && voxel_pool_usable(*s, flags))
             return !coarse ? (quads ? "hare_voxel_pool_quad" : "hare_voxel_pool_tri") : (quads ? "hare_voxel_pool_quad_g" : "hare_voxel_pool_tri_g");
         return !coarse ? (quads ? "hare_voxel_persist_quad" : "hare_voxel_persist_tri") : (quads ? "hare_voxel_persist_quad_g" : "hare_voxel_persist_tri_g");
     }

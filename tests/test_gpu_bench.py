@@ -41,19 +41,21 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert j["x_event_parity_vs_oracle"] is True                # rank 0's shard, bit for bit
     assert j["ms_per_step_per_rank"]["max"] >= j["ms_per_step_per_rank"]["min"] > 0
     assert j["cpu_baseline"] is None                            # reported at N = 1 only
-    assert j["roofline"]["kernel"] == "hare_voxel_persist_tri" and j["roofline"]["frac"] > 0
+    # 65 536 rays per rank on the cache-resident hall: the short-launch side of the picker (api.cpp: voxel_pool_wanted)
+    assert j["roofline"]["kernel"] == "hare_voxel_pool_tri" and j["roofline"]["frac"] > 0
 
 
 @pytest.mark.parametrize("extra,kernel", [
-    ((), "hare_voxel_persist_tri"),
+    ((), "hare_voxel_pool_tri"),                          # 32 768 rays: a short launch (voxel_pool_wanted)
     (("--kind", "octree"), "hare_octree_persist"),
-    (("--bounces", "3"), "hare_voxel_persist_tri"),
+    (("--bounces", "3"), "hare_voxel_pool_tri"),
+    (("--rays", "524288"), "hare_voxel_persist_tri"),     # mid-size batch on a cache-resident scene
 ])
 def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
-    j = _bench("--rays", "32768", "--steps", "2", "--warmup", "1", *extra)
+    j = _bench(*(("--rays", "32768") if "--rays" not in extra else ()), "--steps", "2", "--warmup", "1", *extra)
     assert j["n_gpus"] == 1 and j["x_event_parity_vs_oracle"] is True
     rf, cpu = j["roofline"], j["cpu_baseline"]
     assert rf["kernel"] == kernel and rf["bound"] == "hbm" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["algorithmic_bytes_per_launch"] > 104 * 32768 * 0.5
+    assert rf["algorithmic_bytes_per_launch"] > 104 * j["config"]["rays_per_gpu"] * 0.5
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
