@@ -317,14 +317,26 @@ int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, u
 // Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass when the process
 // opted in with HARE_DEV=1 (tools/, the cull-audit test), so a stray bit from a caller can never reach a kernel.
-// Which production voxel kernel serves a batch (measured on MI355X over 9 scene / grid combinations):
-//  * a scene whose records are far beyond the L2 (the 986k-triangle cathedral, ~200 MB): K1q (hare_voxel_pool_*) at every
-//    batch size -- it keeps 1.5x the rays in flight per CU and requests eight candidates' records per task, which is what
-//    covers miss latency (-7 ... -31 % against K1p from 16k to 2M rays);
-//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 23 - 52 MB): K1p (hare_voxel_persist_*) between ~200k
-//    and ~1.18M rays (K1q +2 ... +33 % there), K1q below (one short launch is all latency: -5 ... -21 % from 64 to 131k
-//    rays) and above (its steady state outweighs its longer ramp and drain: -2 % at 1.18M, -9 % at 1.5M, -20 % at 16M).
+// Which production voxel kernel serves a batch (measured on MI355X over 9 scene / grid combinations): K1q
+// (hare_voxel_pool_*) once a launch is long enough for its steady state to outweigh its longer ramp and drain, K1p
+// (hare_voxel_persist_*) below.  Where that is depends on whether the scene's records stay in the L2: K1q keeps 1.5x the rays
+// in flight per CU and requests eight candidates' records per task, which is what covers miss latency --
+//  * a scene far beyond the L2 (the 986k-triangle cathedral, ~200 MB): K1q from ~400k rays (524k: -18 ... -28 %; 262k: +12 ... +33 %);
+//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): K1q from ~1.18M rays (-2 % there, -9 % at
+//    1.5M, -20 % at 16M; +7 % at the 1M-ray headline, +17 ... +68 % from 65k to 524k).
 // HARE_VOXEL_KERNEL=pool|persist overrides (developer A/B).
+// The persistent kernels (K1p, K2p) give every wave of the grid a static first chunk of rays and hand out the rest by tickets:
+// 128 rays per wave when the batch has plenty, less for a batch that does not (a fixed 128 left half of the grid's waves
+// without any work at 262k rays), in steps of 32 and at least 64.  How much less differs (measured): a voxel ray
+// is cheap against the ~30 ns of a ticket draw, so K1p takes the whole per-wave share statically (393k rays: 0.286 ms, with a
+// quarter kept for tickets 0.335); an octree ray costs ten times as much and the end of the batch matters more than the
+// tickets, so K2p keeps a quarter of the share for them (524k rays: 2.34 ms against 2.61 all static).
+int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tickets)
+{
+    int64_t per_wave = n / ((int64_t)std::max(1u, pgrid) * 4);
+    if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
+    return (int32_t)std::max<int64_t>(64, std::min<int64_t>(128, per_wave / 32 * 32));
+}
 size_t voxel_scene_bytes(const Scene& s, size_t top)
 {
     const size_t ncell = (size_t)s.vox.ct * s.vox.ct * s.vox.ct;
@@ -337,8 +349,7 @@ bool voxel_pool_wanted(const Scene& s, size_t top, int64_t n)
         if (strcmp(vk, "pool") == 0) return true;
         if (strcmp(vk, "persist") == 0) return false;
     }
-    if (voxel_scene_bytes(s, top) > (96ull << 20)) return true;
-    return n <= 196608ll || n >= 1179648ll;
+    return n >= (voxel_scene_bytes(s, top) > (96ull << 20) ? 393216ll : 1179648ll);
 }
 constexpr bool kOctreePoolDefault = false;
 // The octree's production kernels: K2q (hare_octree_pool) / K2p (hare_octree_persist); HARE_OCTREE_KERNEL=pool|persist overrides.
@@ -518,6 +529,9 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
         io.work = (unsigned int*)s.d_work + slot;
         HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+        // static first chunk per wave (static_chunk_rays): at 262k rays, where 128 left half the grid's waves without work, 0.348 -> 0.239 ms
+        io.static_rays = static_chunk_rays(n, pgrid, false);
+        if (getenv("HARE_K1P_STATIC_RAYS")) io.static_rays = std::max(32, std::min(256, atoi(getenv("HARE_K1P_STATIC_RAYS")) / 32 * 32));   // developer sweeps
         void* args[] = {&g, &io};
         hipFunction_t pf = !coarse ? (quads ? M.voxel_persist_quad : M.voxel_persist_tri)
                                    : (quads ? M.voxel_persist_quad_g : M.voxel_persist_tri_g);
@@ -628,6 +642,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             const unsigned slot = s.work_slot.fetch_add(1) % 64u;
             if (int rc = prepare_partials(s, M, io, pgrid, slot)) return rc;
             io.ticket_rays = 32;                  // an octree ray costs ~10x a voxel ray: ticket atomics never bind
+            io.static_rays = static_chunk_rays(n, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
+            if (getenv("HARE_K2P_STATIC_RAYS")) io.static_rays = std::max(32, std::min(256, atoi(getenv("HARE_K2P_STATIC_RAYS")) / 32 * 32));   // developer sweeps
             if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
             io.work = (unsigned int*)s.d_work + slot;
             HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));

@@ -181,6 +181,9 @@ struct ShootIO {
     // persistent voxel kernel: rays per ticket after each wave's static first chunk.  Small tickets even
     // out the end of a small batch; large ones keep the (chip-wide serialised) ticket atomics rare.
     int32_t ticket_rays;
+    // persistent voxel kernel: rays in every wave's static first chunk (a multiple of 32, <= 128): the host shrinks it for
+    // batches too small to give every wave of the grid 128 rays -- idle waves cost more than a shorter static share
+    int32_t static_rays;
 };
 
 }  // namespace hare

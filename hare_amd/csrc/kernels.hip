@@ -198,7 +198,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 #ifndef HARE_K1P_STATIC
 #define HARE_K1P_STATIC 128
 #endif
-    const int RAY_CHUNK = HARE_K1P_STATIC;
+    const int RAY_CHUNK = io.static_rays > 0 ? io.static_rays : HARE_K1P_STATIC;
     const int EXACT_MIN_PARKED = HARE_K1P_EXACT;
 
     // wave-uniform work chunk [cn, ce).  The first chunk of every wave is static (wave w owns rays
@@ -626,7 +626,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 #define HARE_K2P_REFILL 8
 #define HARE_K2P_EXACT 1
 #endif
-    const int STEPS = HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS, REFILL_MIN_IDLE = HARE_K2P_REFILL, RAY_CHUNK = 128, EXACT_MIN_PARKED = HARE_K2P_EXACT;
+    const int STEPS = HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS, REFILL_MIN_IDLE = HARE_K2P_REFILL, EXACT_MIN_PARKED = HARE_K2P_EXACT;
+    const int RAY_CHUNK = io.static_rays > 0 ? io.static_rays : 128;      // the host sizes it by the batch (ShootIO::static_rays)
     const unsigned int n32 = (unsigned int)io.n;
     // static first chunk per wave, tickets of io.ticket_rays after those (as in the voxel kernel)
     const unsigned int n_static = gridDim.x * 4u * (unsigned int)RAY_CHUNK;

@@ -41,15 +41,14 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert j["x_event_parity_vs_oracle"] is True                # rank 0's shard, bit for bit
     assert j["ms_per_step_per_rank"]["max"] >= j["ms_per_step_per_rank"]["min"] > 0
     assert j["cpu_baseline"] is None                            # reported at N = 1 only
-    # 65 536 rays per rank on the cache-resident hall: the short-launch side of the picker (api.cpp: voxel_pool_wanted)
-    assert j["roofline"]["kernel"] == "hare_voxel_pool_tri" and j["roofline"]["frac"] > 0
+    assert j["roofline"]["kernel"] == "hare_voxel_persist_tri" and j["roofline"]["frac"] > 0
 
 
 @pytest.mark.parametrize("extra,kernel", [
-    ((), "hare_voxel_pool_tri"),                          # 32 768 rays: a short launch (voxel_pool_wanted)
+    ((), "hare_voxel_persist_tri"),
     (("--kind", "octree"), "hare_octree_persist"),
-    (("--bounces", "3"), "hare_voxel_pool_tri"),
-    (("--rays", "524288"), "hare_voxel_persist_tri"),     # mid-size batch on a cache-resident scene
+    (("--bounces", "3"), "hare_voxel_persist_tri"),
+    (("--rays", "1310720"), "hare_voxel_pool_tri"),       # a launch long enough for the pool kernel (api.cpp: voxel_pool_wanted)
 ])
 def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     j = _bench(*(("--rays", "32768") if "--rays" not in extra else ()), "--steps", "2", "--warmup", "1", *extra)

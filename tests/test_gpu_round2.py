@@ -428,10 +428,10 @@ def test_concurrent_batch_callers_on_one_scene(hall):
 
 
 def test_the_picker_follows_its_rule(hall):
-    """api.cpp voxel_pool_wanted: a cache-resident scene takes K1p between ~200k and ~1.18M rays and K1q outside; the
-    environment override is for A/B runs only (the tests above use it)."""
+    """api.cpp voxel_pool_wanted: a cache-resident scene takes K1p below ~1.18M rays and K1q from there; the environment
+    override is for A/B runs only (the tests above use it)."""
     _, T, _ = hall
     g = H.Voxel_Grid([T], 64)
-    want = {64: "pool", 65536: "pool", 196608: "pool", 196609: "persist", 1 << 20: "persist", 1179647: "persist", 1179648: "pool", 1 << 24: "pool"}
+    want = {64: "persist", 65536: "persist", 393216: "persist", 1 << 20: "persist", 1179647: "persist", 1179648: "pool", 1 << 24: "pool"}
     for n, k in want.items():
         assert g.kernel_name(n) == f"hare_voxel_{k}_tri", (n, g.kernel_name(n))
