@@ -647,6 +647,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
             io.work = (unsigned int*)s.d_work + slot;
             HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+            if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
             void* pargs[] = {&g, &io};
             int rc = launch(H, M.octree_persist, pgrid, 256, plds, st, pargs);
             if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * 4u, st);

@@ -619,6 +619,13 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 
     const int lane = tid & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // developer timeline (flag 0x2000, tools/timeline_oct.py): per wave {start, tickets dry, end} on the 100 MHz wall clock
+    auto timeline = [&](int slot) {
+        if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
+            if (lane == 0) io.prof[32 + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6)) + slot] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    timeline(0);
     // tuned on C3 (tools/sweep_oct.py): parking survivors does not pay here, several culls per round do
 #ifndef HARE_K2P_STEPS
 #define HARE_K2P_STEPS 4
@@ -743,7 +750,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     if (lane == 0) base = atomicAdd(io.work, dyn);
                     base = __shfl(base, 0, 64);
                     cn = base + n_static;
-                    if (cn >= n32) { drained = true; break; }
+                    if (cn >= n32) { drained = true; timeline(1); break; }
                     ce = (n32 - cn > dyn) ? cn + dyn : n32;
                 }
                 const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
@@ -919,6 +926,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         }
     }
 
+    timeline(2);
     if (io.ctr) {
         const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
         if (lane == 0) {

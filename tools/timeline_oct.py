@@ -1,0 +1,30 @@
+"""Developer tool: per-wave timeline of the production octree kernel K2p (flag 0x2000): start, tickets dry, end -- how much of a
+launch is its tail (a few rays scan thousands of leaf entries: tools prints their share)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["HARE_DEV"] = "1"
+import numpy as np, torch
+import hare_amd as H
+mesh = H.scenes.hall(); g = H.Octree([H.Topology(mesh.verts, mesh.nverts)], 8, 16)
+W = 4096
+st = torch.cuda.current_stream().cuda_stream
+for N in [int(x) for x in os.environ.get("RAYS", "1048576").split(",")]:
+    rays = H.scenes.burst_rays(N, mesh.size)
+    dr = torch.from_numpy(rays).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
+    buf = torch.zeros(8 + 32 + 4 * W, dtype=torch.int64, device="cuda")
+    for rep in range(2):
+        buf.zero_()
+        g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x2000)
+        torch.cuda.synchronize()
+    tl = buf.cpu().numpy()[8 + 32:].reshape(W, 4).astype(np.float64)
+    live = tl[:, 0] > 0
+    t0 = tl[live, 0].min()
+    dry = (tl[:, 1] - t0) / 100.0; end = (tl[:, 2] - t0) / 100.0
+    span = end[live].max()
+    has_dry = live & (tl[:, 1] > 0)
+    e = np.sort(end[live])
+    print("n=%d: %d waves, span %.0f us | tickets dry p10/50/90 %.0f/%.0f/%.0f | wave end p10/50/90/99/max %.0f/%.0f/%.0f/%.0f/%.0f"
+          % (N, live.sum(), span, *np.percentile(dry[has_dry], [10, 50, 90]), *np.percentile(end[live], [10, 50, 90, 99]), span))
+    print("   waves still running at 50/60/70/80/90/95 %% of the span: %s of %d; wave-time after the median wave's end: %.1f %% of all wave-time"
+          % ([int((e > span * f).sum()) for f in (0.5, 0.6, 0.7, 0.8, 0.9, 0.95)], live.sum(),
+             100 * np.clip(e - np.median(e), 0, None).sum() / e.sum()))
