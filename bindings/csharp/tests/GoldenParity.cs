@@ -1,6 +1,7 @@
 // GoldenParity.cs -- pins this repo's oracle (and, when libhare_hip.so + a GPU are present, the HIP kernels) to the
 // REFERENCE implementation: runs PachydermAcoustic/Hare's own Voxel_Grid / Octree / KDTree .Shoot on the committed
-// config-1 inputs and compares every X_Event with the committed expected records, bit for bit.
+// config-1 inputs (and on case 2: exact ties, trees over two topologies) and compares every X_Event with the committed
+// expected records, bit for bit.
 //
 // It cannot run where this repo is built (no .NET toolchain there; DESIGN.md section 1) -- it is the recipe for
 // whoever has `dotnet`:
@@ -77,7 +78,9 @@ public static class GoldenParity
         return bad;
     }
 
-    static int Run(string what, Spatial_Partition part, double[] rays, int[] excl, Rec[] want, int pass)
+    static int Run(string what, Spatial_Partition part, double[] rays, int[] excl, Rec[] want, int pass) { return Run(what, part, rays, excl, want, pass, 0); }
+
+    static int Run(string what, Spatial_Partition part, double[] rays, int[] excl, Rec[] want, int pass, int top)
     {
         int n = want.Length, threw = 0;
         var got = new Rec[n];
@@ -87,13 +90,61 @@ public static class GoldenParity
             X_Event e = null;
             try
             {
-                if (excl == null) part.Shoot(R, 0, out e);
-                else part.Shoot(R, 0, out e, excl[i]);
+                if (excl == null) part.Shoot(R, top, out e);
+                else part.Shoot(R, top, out e, excl[i]);
             }
             catch (Exception) { e = null; threw++; }
             got[i] = FromEvent(e);
         }
         return Compare(what, got, want, threw);
+    }
+
+    static Topology MakeTopology(double[] tris, int P)
+    {
+        var polys = new Point[P][];
+        for (int k = 0; k < P; k++)
+        {
+            polys[k] = new Point[3];
+            for (int c = 0; c < 3; c++) polys[k][c] = new Point(tris[9 * k + 3 * c], tris[9 * k + 3 * c + 1], tris[9 * k + 3 * c + 2]);
+        }
+        var T = new Topology(polys);
+        T.Finish_Topology();
+        if (T.Polygon_Count != P) throw new InvalidDataException("Topology kept " + T.Polygon_Count + " of " + P + " polygons");
+        return T;
+    }
+
+    // Case 2 (tests/golden/c2_ties.npz, written to <dir>/c2 by export_raw.py): rays aimed exactly at corners and edges, coincident
+    // and coplanar overlapping triangles (strict `<`, list order), and Octree / KDTree built over TWO topologies, shot at
+    // top_index 0 and 1 ("Octree - alt.cs":63-88,123; KDTree.cs:67-87).
+    static int Case2(string dir)
+    {
+        if (!File.Exists(Path.Combine(dir, "params.txt"))) { Console.WriteLine("case 2 not exported (" + dir + "): skipped"); return 0; }
+        string[] p = File.ReadAllText(Path.Combine(dir, "params.txt")).Split(new[] { ' ', '\n', '\r' }, StringSplitOptions.RemoveEmptyEntries);
+        int D = int.Parse(p[0]), OD = int.Parse(p[1]), OP = int.Parse(p[2]), KDD = int.Parse(p[3]), KDP = int.Parse(p[4]);
+        int P0 = int.Parse(p[5]), P1 = int.Parse(p[6]), N = int.Parse(p[7]);
+        double[] rays = ReadF64(Path.Combine(dir, "rays.f64"));
+        int[] excl1 = ReadI32(Path.Combine(dir, "excl1.i32")), excl2 = ReadI32(Path.Combine(dir, "excl1_two.i32"));
+        Topology T0 = MakeTopology(ReadF64(Path.Combine(dir, "tris0.f64")), P0), T1 = MakeTopology(ReadF64(Path.Combine(dir, "tris1.f64")), P1);
+        var one = new Topology[] { T0 };
+        var two = new Topology[] { T0, T1 };
+        Func<string, Rec[]> ev = name => ReadEvents(Path.Combine(dir, name + ".xev"), N);
+        int bad = 0;
+        var vox = new Voxel_Grid(one, D);
+        bad += Run("c2 voxel", vox, rays, null, ev("voxel"), 11);
+        bad += Run("c2 voxel_excl", vox, rays, excl1, ev("voxel_excl"), 12);
+        var oct = new Octree(one, OD, OP);
+        bad += Run("c2 octree", oct, rays, null, ev("octree"), 13);
+        bad += Run("c2 octree_excl", oct, rays, excl1, ev("octree_excl"), 14);
+        bad += Run("c2 kdtree", new KDTree(one, KDD, KDP), rays, null, ev("kdtree"), 15);
+        var oct2 = new Octree(two, OD, OP);
+        var kd2 = new KDTree(two, KDD, KDP);
+        for (int top = 0; top < 2; top++)
+        {
+            bad += Run("c2 octree2 top" + top, oct2, rays, null, ev("octree2_top" + top), 16 + 3 * top, top);
+            bad += Run("c2 octree2x top" + top, oct2, rays, excl2, ev("octree2_top" + top + "_excl"), 17 + 3 * top, top);
+            bad += Run("c2 kdtree2 top" + top, kd2, rays, null, ev("kdtree2_top" + top), 18 + 3 * top, top);
+        }
+        return bad;
     }
 
     public static int Main(string[] args)
@@ -150,6 +201,7 @@ public static class GoldenParity
 #else
         if (gpu) Console.WriteLine("--gpu: rebuild with -p:DefineConstants=HARE_GPU and the shim sources (HareHip.cs, Gpu_Spatial_Partition.cs)");
 #endif
+        bad += Case2(Path.Combine(dir, "c2"));
         Console.WriteLine(bad == 0 ? "PINNED: the reference reproduces every committed X_Event bit for bit" : "MISMATCH: " + bad + " records differ");
         return bad == 0 ? 0 : 1;
     }

@@ -43,7 +43,31 @@ def main(out_dir=None):
     with open(os.path.join(out_dir, "params.txt"), "w") as f:
         f.write(" ".join(str(int(x)) for x in G["params"]) + f" {tris.shape[0]} {n}\n")
     print(f"wrote {out_dir}: {tris.shape[0]} triangles, {n} rays, 5 event files")
+    export_c2(os.path.join(out_dir, "c2"))
     return out_dir
+
+
+def export_c2(out_dir):
+    """Case 2 (tests/golden/c2_ties.npz): exact ties + trees over two topologies.  Files as above, plus
+    tris0.f64 / tris1.f64 (Model[0], Model[1]), excl1_two.i32, and the events octree2_top{0,1}[_excl].xev, kdtree2_top{0,1}.xev
+    of Octree / KDTree built over BOTH topologies and shot at top_index 0 / 1.  params.txt: D OD OP KDD KDP P0 P1 N."""
+    os.makedirs(out_dir, exist_ok=True)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "c2_ties.npz"))
+    n = G["rays"].shape[0]
+    np.ascontiguousarray(G["verts0"], "<f8").tofile(os.path.join(out_dir, "tris0.f64"))
+    np.ascontiguousarray(G["verts1"], "<f8").tofile(os.path.join(out_dir, "tris1.f64"))
+    np.ascontiguousarray(G["rays"], "<f8").tofile(os.path.join(out_dir, "rays.f64"))
+    np.ascontiguousarray(G["excl1"], "<i4").tofile(os.path.join(out_dir, "excl1.i32"))
+    np.ascontiguousarray(G["excl1_two"], "<i4").tofile(os.path.join(out_dir, "excl1_two.i32"))
+    names = ["voxel", "voxel_excl", "octree", "octree_excl", "kdtree"] + [f"{k}2_top{t}{x}" for t in (0, 1) for k, x in
+                                                                         (("octree", ""), ("octree", "_excl"), ("kdtree", ""))]
+    for name in names:
+        ev = np.ascontiguousarray(G[name])
+        assert ev.dtype.itemsize == 56 and len(ev) == n
+        ev.tofile(os.path.join(out_dir, name + ".xev"))
+    with open(os.path.join(out_dir, "params.txt"), "w") as f:
+        f.write(" ".join(str(int(x)) for x in G["params"]) + f" {G['verts0'].shape[0]} {G['verts1'].shape[0]} {n}\n")
+    print(f"wrote {out_dir}: {G['verts0'].shape[0]} + {G['verts1'].shape[0]} triangles, {n} rays, {len(names)} event files")
 
 
 if __name__ == "__main__":
