@@ -1,0 +1,76 @@
+"""Developer tool: a long randomized differential run of the HIP paths against the oracle -- many more seeds than the test
+suite carries, random grid sizes (incl. the coarse-bitmap range and the 65..80 range the pool kernel cannot take), random tree
+shapes, random batch sizes (ragged waves), both voxel kernels and both octree kernels forced in turn, exclusions, origin
+write-back.  Stops at the first difference and prints the configuration that reproduces it.
+
+    SEEDS=0:300 python tools/fuzz_parity.py
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import hare_amd as H
+from oracle import pyoracle as po
+from tests.test_gpu_parity import _random_scene
+
+F = ("hit", "poly_id", "t", "u", "v", "x", "y", "z")
+
+
+def same(a, b):
+    for f in F:
+        x, y = np.ascontiguousarray(a[f]), np.ascontiguousarray(b[f])
+        if x.dtype.kind == "f": x, y = x.view(np.int64), y.view(np.int64)
+        bad = np.nonzero(x != y)[0]
+        if bad.size: return "X_Event.%s differs on rays %s" % (f, bad[:6])
+    return None
+
+
+def main():
+    lo, hi = (int(x) for x in os.environ.get("SEEDS", "0:200").split(":"))
+    t0 = time.time(); checks = 0
+    for seed in range(lo, hi):
+        verts, nverts, rays = _random_scene(seed)
+        rng = np.random.default_rng(10_000 + seed)
+        n = int(rng.choice([1, 63, 64, 65, 1000, 4000]))
+        rays = np.ascontiguousarray(rays[:n])
+        T, To = H.Topology(verts, nverts), po.Topology(verts, nverts)
+        D = int(rng.choice([1, 2, 5, 13, 31, 64, 70, 80, 81, 97, 128, 161, 200]))
+        e1 = rng.integers(-1, len(nverts), n).astype(np.int32); e2 = rng.integers(-1, len(nverts), n).astype(np.int32)
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        ref, _ = o.shoot(rays); refx, _ = o.shoot(rays, excl1=e1, excl2=e2)
+        moved = rays.copy(); refm, _, movedref = o.shoot(rays, mutate=True)
+        for kern in ("persist", "pool"):
+            os.environ["HARE_VOXEL_KERNEL"] = kern
+            cfg = "seed %d voxel D=%d n=%d kernel=%s (%s)" % (seed, D, n, kern, g.kernel_name(n))
+            for what, got, want in (("plain", g.Shoot_batch(rays)[0], ref), ("excl", g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], refx)):
+                bad = same(got, want); checks += 1
+                if bad: print("MISMATCH", cfg, what, bad); return 1
+            r = rays.copy(); got, _ = g.Shoot_batch(r, writeback_origin=True); checks += 1
+            bad = same(got, refm) or (None if np.array_equal(r.view(np.int64), movedref.view(np.int64)) else "moved origins differ")
+            if bad: print("MISMATCH", cfg, "writeback", bad); return 1
+        os.environ.pop("HARE_VOXEL_KERNEL", None)
+        depth, maxp = int(rng.integers(0, 9)), int(rng.integers(1, 40))
+        # the reference pads child boxes by an ABSOLUTE 0.1 m ("Octree - alt.cs":99-111): below ~0.4 m a node's
+        # polygons land in all eight children and the tree grows 8x per level in ANY implementation -- keep nodes above 1 m
+        ext = float((verts[:, :3].reshape(-1, 3).max(0) - verts[:, :3].reshape(-1, 3).min(0)).max())
+        depth = min(depth, max(0, int(np.floor(np.log2(max(ext, 1e-9))))))
+        oc, oo = H.Octree([T], depth, maxp), po.Octree([To], depth, maxp)
+        oref, _ = oo.shoot(rays); orefx, _ = oo.shoot(rays, excl1=e1, excl2=e2)
+        for kern in ("persist", "pool"):
+            os.environ["HARE_OCTREE_KERNEL"] = kern
+            cfg = "seed %d octree %d/%d n=%d kernel=%s" % (seed, depth, maxp, n, kern)
+            for what, got, want in (("plain", oc.Shoot_batch(rays)[0], oref), ("excl", oc.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], orefx)):
+                bad = same(got, want); checks += 1
+                if bad: print("MISMATCH", cfg, what, bad); return 1
+        os.environ.pop("HARE_OCTREE_KERNEL", None)
+        if seed % 4 == 0:
+            kd, ko = H.KDTree([T], depth + 2, maxp), po.KDTree([To], depth + 2, maxp)
+            m = min(n, 800)
+            bad = same(kd.Shoot_batch(rays[:m])[0], ko.shoot(rays[:m])[0]); checks += 1
+            if bad: print("MISMATCH seed %d kd %d/%d" % (seed, depth + 2, maxp), bad); return 1
+        print("seed %d clean (D=%d n=%d octree %d/%d), %d comparisons so far, %.0f s" % (seed, D, n, depth, maxp, checks, time.time() - t0), flush=True)
+    print("CLEAN: seeds %d..%d, %d comparisons of full X_Event arrays, %.0f s" % (lo, hi - 1, checks, time.time() - t0))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
