@@ -62,6 +62,36 @@ def main():
                 bad = same(got, want); checks += 1
                 if bad: print("MISMATCH", cfg, what, bad); return 1
         os.environ.pop("HARE_OCTREE_KERNEL", None)
+        if seed % 5 == 0 and n >= 1000:
+            # the device-resident bounce loop on this scene (open soups: many rays leave and are retired), both voxel kernels,
+            # and the occlusion predicate on the first cast
+            import torch
+            from hare_amd import capi
+            st = torch.cuda.current_stream().cuda_stream
+            for kern in ("persist", "pool"):
+                os.environ["HARE_VOXEL_KERNEL"] = kern
+                d_rays = torch.from_numpy(rays.copy()).cuda(); d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+                d_ex = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+                cur, excl, dead = rays.copy(), np.full(n, -1, np.int32), np.zeros(n, bool)
+                for b in range(4):
+                    g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), stream=st, flags=capi.SHOOT_RETIRED_RAYS)
+                    g.reflect_device(n, d_rays.data_ptr(), d_ev.data_ptr(), d_ex.data_ptr(), stream=st)
+                    torch.cuda.synchronize()
+                    ev = np.frombuffer(d_ev.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE)
+                    live = ~dead
+                    want = np.zeros(n, po.XEVENT_DTYPE); want["poly_id"] = -1
+                    if live.any(): want[live] = o.shoot(cur[live], excl1=excl[live])[0]
+                    bad = same(ev, want); checks += 1
+                    if bad: print("MISMATCH seed %d voxel D=%d n=%d kernel=%s bounce %d" % (seed, D, n, kern, b), bad); return 1
+                    alive_ = (want["hit"] == 1) & live
+                    cur = po.reflect_batch(To, cur, want)
+                    excl = np.where(alive_, want["poly_id"], -2).astype(np.int32)
+                    dead |= ~alive_
+            os.environ.pop("HARE_VOXEL_KERNEL", None)
+            tmax = np.abs(rng.normal(0, 1, n)) * float(np.nanmedian(ref["t"][ref["hit"] == 1])) if (ref["hit"] == 1).any() else np.ones(n)
+            occ = g.Occluded_batch(rays, t_max=tmax)[0]
+            want_occ = (ref["hit"] == 1) & (ref["t"] < tmax); checks += 1
+            if not np.array_equal(np.asarray(occ, bool), want_occ): print("MISMATCH seed %d occlusion D=%d n=%d" % (seed, D, n)); return 1
         if seed % 4 == 0:
             kd, ko = H.KDTree([T], depth + 2, maxp), po.KDTree([To], depth + 2, maxp)
             m = min(n, 800)
