@@ -12,6 +12,11 @@ collective); the only exchange is the RCCL all-reduce of the hit counter after e
 
 Other configs: --kind octree (config 3), --scene cathedral --domain 128 --rays 2097152 (config 4 shard),
 --scene cathedral --domain 128 --bounces 8 (config 5: device-resident specular bounce loop, value = casts/s).
+The default N = 1 run (the driver's command) measures the headline workload first and then, in the same process, configs
+3, 4 (one GPU's 2M-ray shard) and 5 (one GPU's 1M rays x 8 bounces) at fewer steps; they are attached to the ONE JSON line
+as "configs": {"c3": ..., "c4_shard": ..., "c5": ...}, each with its own value, roofline, cpu_baseline and parity flag
+(--no-extra-configs skips them).  --force-dist runs the torch.distributed code path (init, per-step async all-reduce of
+the counters, all-gather of the timings) even at N = 1, so that the RCCL branch can be exercised on a one-GPU box.
 
 Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch (SURVEY.md 8(d):
 104 + 8*C + 4*L + 96*T per ray for the grid, 64*C for the octree, + 28 B per bounce; C/L/T counted exactly
@@ -55,6 +60,15 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg: profiling runs want only full-size launches")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo: rehearsal with ranks sharing one GPU)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N = 1, default workload: do not append configs 3, 4 (shard) and 5 to the line")
+    ap.add_argument("--extra-configs", action="store_true", help="append configs 3, 4 (shard), 5 whatever the headline workload is")
+    ap.add_argument("--extra-rays", type=int, default=0, help="cap the rays of the appended configs (tests; 0 = their real sizes)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and run its code path even with one rank (tests the RCCL branch on one GPU)")
+    ap.add_argument("--bounce-api", default="device", choices=["device", "batch"],
+                    help="--bounces > 1: 'device' = hare_shoot_device + hare_reflect_device on resident buffers (the timed loop); "
+                         "'batch' additionally times hare_bounce_batch from host buffers (PCIe-inclusive, reported beside it)")
     return ap.parse_args(argv)
 
 
@@ -138,81 +152,96 @@ def kernel_source_sha() -> str:
 
 
 def load_traffic(workload_key: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json).  An entry is only
-    reported when it was measured on THIS kernel source (its `kernel_sha16`), else None: counters of an older
-    kernel say nothing about the one that just ran."""
+    """The committed rocprofv3 PMC passes for this workload (profiles/traffic.json): HBM bytes per launch and the issue-side
+    counters.  An entry is only reported when it was measured on THIS kernel source (its `kernel_sha16`), else None:
+    counters of an older kernel say nothing about the one that just ran."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(p) as f:
             t = json.load(f)
         e = t.get(workload_key)
-        if e is None:
-            return None, None
-        if e.get("kernel_sha16") != kernel_source_sha():
-            return None, None
-        return e.get("hbm_bytes_per_launch"), e.get("SQ_INSTS_VALU")
+        if e is None or e.get("kernel_sha16") != kernel_source_sha():
+            return None
+        return e
     except Exception:
-        return None, None
+        return None
 
 
-def main() -> None:
-    args = parse_args()
-    if args.gpus < 1:
-        raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # the driver's command line: start the ranks ourselves, BEFORE anything initialises the GPU in this process
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+GPU_CLOCK_HZ = 2.4e9      # MI355X peak shader clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
+N_SIMDS = 1024
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, the two must agree")
 
+class Env:
+    """What every workload of one bench process shares: the rank, the (optional) process group, the device."""
+
+    def __init__(self, args, rank, local_rank, world, dist, device):
+        self.args, self.rank, self.local_rank, self.world, self.dist, self.device = args, rank, local_rank, world, dist, device
+        self.backend = args.backend
+        self.meshes = {}       # scene name -> (mesh, H.Topology)
+        self.parts = {}        # (scene, kind, domain) -> (partition, description, build seconds)
+        self.oracles = {}      # (scene, kind, domain) -> (oracle topology, oracle partition, reference name)
+
+    def mesh(self, H, scene):
+        if scene not in self.meshes:
+            m = H.scenes.SCENES[scene]()
+            self.meshes[scene] = (m, H.Topology(m.verts, m.nverts))
+        return self.meshes[scene]
+
+    def partition(self, H, scene, kind, domain):
+        key = (scene, kind, domain if kind == "voxel" else 0)
+        if key not in self.parts:
+            _, topo = self.mesh(H, scene)
+            t0 = time.time()
+            if kind == "voxel":
+                part, kdesc = H.Voxel_Grid([topo], domain, device=self.device), f"Voxel_Grid Domain={domain}"
+            elif kind == "octree":
+                part, kdesc = H.Octree([topo], 8, 16, device=self.device), "Octree maxDepth=8 maxPolys=16"
+            else:
+                part, kdesc = H.KDTree([topo], 12, 16, device=self.device), "KDTree maxDepth=12 maxPolys=16"
+            self.parts[key] = (part, kdesc, time.time() - t0)
+        return self.parts[key]
+
+    def oracle(self, H, scene, kind, domain):
+        """The checker (oracle/): only ever called after the timed region, on rank 0."""
+        from oracle import pyoracle as po
+        key = (scene, kind, domain if kind == "voxel" else 0)
+        if key not in self.oracles:
+            m, _ = self.mesh(H, scene)
+            ot = po.Topology(m.verts, m.nverts)
+            if kind == "voxel":
+                og, ref_name = po.VoxelGrid([ot], domain=domain), "Voxel_Grid.Shoot"
+            elif kind == "octree":
+                og, ref_name = po.Octree([ot], 8, 16), "Octree.Shoot"
+            else:
+                og, ref_name = po.KDTree([ot], 12, 16), "KDTree.Shoot"
+            self.oracles[key] = (ot, og, ref_name)
+        return self.oracles[key]
+
+    def drop(self, scene=None):
+        """Free partitions (device memory) of `scene`, or all."""
+        for key in [k for k in self.parts if scene is None or k[0] == scene]:
+            self.parts.pop(key)[0].close()
+        for key in [k for k in self.oracles if scene is None or k[0] == scene]:
+            self.oracles.pop(key)
+
+
+def measure(w, env):
+    """One workload (scene, partition, rays per GPU, bounces) measured per the bench contract: `warmup` untimed steps, then
+    exactly `steps` steps between barrier + synchronize fences, MAX over ranks.  Returns the JSON line (rank 0) or None."""
     import numpy as np
     import torch
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the ray-cast path has no CPU fallback")
-    ndev = torch.cuda.device_count()
-    if world > ndev and args.backend == "nccl":
-        raise SystemExit(f"--gpus {world} with backend nccl needs {world} GPUs, {ndev} visible "
-                         f"(--backend gloo rehearses the multi-rank path with ranks sharing a GPU)")
-    device = local_rank % ndev
-    torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # noqa: F811
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
-            # RCCL builds its communicator on the first collective: do that here, never inside the timed region
-            _t = torch.zeros(8, dtype=torch.int64, device="cuda")
-            dist.all_reduce(_t)
-            torch.cuda.synchronize()
-        else:
-            dist.init_process_group(backend="gloo")
-            dist.all_reduce(torch.zeros(8, dtype=torch.int64))
 
     import hare_amd as H
     from hare_amd.sharding import shard_range
 
-    mesh = H.scenes.SCENES[args.scene]()
-    topo = H.Topology(mesh.verts, mesh.nverts)
-    t0 = time.time()
-    if args.kind == "voxel":
-        part = H.Voxel_Grid([topo], args.domain, device=device)
-        kdesc = f"Voxel_Grid Domain={args.domain}"
-    elif args.kind == "octree":
-        part = H.Octree([topo], 8, 16, device=device)
-        kdesc = "Octree maxDepth=8 maxPolys=16"
-    else:
-        part = H.KDTree([topo], 12, 16, device=device)
-        kdesc = "KDTree maxDepth=12 maxPolys=16"
-    build_s = time.time() - t0
+    rank, world, dist, backend = env.rank, env.world, env.dist, env.backend
+    scene, kind, domain = w["scene"], w["kind"], w["domain"]
+    steps, warmup = w["steps"], w["warmup"]
+    mesh, _ = env.mesh(H, scene)
+    part, kdesc, build_s = env.partition(H, scene, kind, domain)
 
-    n = args.rays
-    B = args.bounces
+    n = w["rays"]
+    B = w["bounces"]
     kernel_name = part.kernel_name(n)
     n_total = n * world
     lo, hi = shard_range(n_total, rank, world)
@@ -225,7 +254,7 @@ def main() -> None:
     # 256 MiB Infinity Cache from step to step; the timed steps therefore rotate through enough copies (same rays) that a
     # buffer's lines have been evicted by the time it comes round again: rays are read from HBM, events written to HBM.
     per_set = n * (48 + 56)
-    n_sets = 1 if args.bounces > 1 else max(2, min(8, -(-640 * 1024 * 1024 // per_set)))
+    n_sets = 1 if B > 1 else max(2, min(8, -(-640 * 1024 * 1024 // per_set)))
     ray_sets = [d_rays] + [d_rays.clone() for _ in range(n_sets - 1)]
     out_sets = [d_out] + [torch.empty_like(d_out) for _ in range(n_sets - 1)]
 
@@ -270,7 +299,7 @@ def main() -> None:
         c.zero_()
         cast_pass(c.data_ptr())
         if dist is not None:
-            if args.backend == "nccl":
+            if backend == "nccl":
                 pending[k & 1] = dist.all_reduce(c, async_op=True)   # RCCL: the final hit-count reduce (64 B)
                 reduced[k & 1] = c
             else:                                                    # gloo rehearsal: through the host
@@ -295,14 +324,14 @@ def main() -> None:
 
     # set-up, not a step: the first launch loads the code object and sizes the scene's scratch
     part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), stream=sp)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     ev1.record(stream)
     fence()
@@ -311,7 +340,7 @@ def main() -> None:
     walls = [wall]
     if dist is not None:
         tw = torch.tensor([wall, dev_ms], dtype=torch.float64)
-        if args.backend == "nccl":
+        if backend == "nccl":
             tw = tw.cuda()
         gathered = [torch.zeros_like(tw) for _ in range(world)]
         dist.all_gather(gathered, tw)
@@ -323,7 +352,7 @@ def main() -> None:
     rays_total = int(last[0])
 
     # shoot-kernel duration: HIP events around each shoot launch on the launch stream (the stream the kernel runs on)
-    nrep = max(1, min(args.steps, 30))
+    nrep = max(1, min(steps, 30))
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2 * B)] for _ in range(nrep)]
     cast_pass(0)
     torch.cuda.synchronize()
@@ -337,21 +366,24 @@ def main() -> None:
     # measured device-copy bandwidth (what "HBM peak" means in practice on this box) and the host-buffer (PCIe-inclusive) rate
     copy_gbs = None
     e2e = None
+    e2e_slim = None
+    bounce_batch = None
     if rank == 0:
-        a = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
-        b_ = torch.empty_like(a)
-        b_.copy_(a)
-        torch.cuda.synchronize()
-        c0 = torch.cuda.Event(enable_timing=True)
-        c1 = torch.cuda.Event(enable_timing=True)
-        c0.record(stream)
-        for _ in range(10):
+        if w.get("copy_bw", True):
+            a = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+            b_ = torch.empty_like(a)
             b_.copy_(a)
-        c1.record(stream)
-        torch.cuda.synchronize()
-        copy_gbs = 2 * a.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
-        del a, b_
-        if B == 1 and not args.no_e2e:
+            torch.cuda.synchronize()
+            c0 = torch.cuda.Event(enable_timing=True)
+            c1 = torch.cuda.Event(enable_timing=True)
+            c0.record(stream)
+            for _ in range(10):
+                b_.copy_(a)
+            c1.record(stream)
+            torch.cuda.synchronize()
+            copy_gbs = 2 * a.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del a, b_
+        if B == 1 and w["e2e"]:
             # host buffers in, host buffers out (H2D + kernel + D2H inside one hare_shoot_batch): the PCIe-inclusive rate
             import ctypes as C
             ev_h = np.zeros(n, H.capi.XEVENT_DTYPE)
@@ -369,30 +401,30 @@ def main() -> None:
                 dt = time.perf_counter() - t1
                 best = dt if best is None else min(best, dt)
             e2e = n / best / 1e6
+        if B > 1 and w.get("bounce_api") == "batch" and hasattr(part, "Bounce_batch"):
+            # the same loop through ONE C-ABI call from host buffers (hare_bounce_batch): H2D once, B casts and B-1 reflections on
+            # the device, the final events D2H -- what a C# / Pachyderm caller without device pointers gets
+            part.Bounce_batch(rays_h, B)        # sizes the staging buffers
+            best = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                bb_ev, bb_ctr = part.Bounce_batch(rays_h, B)
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            bounce_batch = {"mcasts_s": round(bb_ctr["rays"] / best / 1e6, 1), "ms": round(best * 1e3, 3), "casts": bb_ctr["rays"],
+                            "events": bb_ev}
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return None
 
     # ---- rank 0: oracle pass over THIS rank's rays = exact C/L/T for the roofline, the CPU baseline, a parity check
     roofline = None
     cpu = None
     parity = None
-    if not args.no_cpu_baseline:
+    if w["cpu_baseline"]:
         from oracle import pyoracle as po
         cores = int(os.environ.get("HARE_CPU_THREADS", "0")) or min(len(os.sched_getaffinity(0)), 32)
-        ot = po.Topology(mesh.verts, mesh.nverts)
-        if args.kind == "voxel":
-            og = po.VoxelGrid([ot], domain=args.domain)
-            ref_name = "Voxel_Grid.Shoot"
-        elif args.kind == "octree":
-            og = po.Octree([ot], 8, 16)
-            ref_name = "Octree.Shoot"
-        else:
-            og = po.KDTree([ot], 12, 16)
-            ref_name = "KDTree.Shoot"
+        ot, og, ref_name = env.oracle(H, scene, kind, domain)
 
         def oracle_pass(rays, nthreads):
             """The same pass on the CPU: returns (events of the last cast, summed counters, casts with a live ray)."""
@@ -423,9 +455,9 @@ def main() -> None:
 
         # full pass: exact counters for the roofline + the reference result for the parity check; timed as the CPU baseline
         best = None
-        budget = time.time() + 20.0
+        budget = time.time() + w.get("cpu_budget_s", 20.0)
         reps = 0
-        max_reps = 5 if world == 1 else 1   # the CPU baseline is reported at N = 1 only
+        max_reps = w.get("cpu_reps", 5) if world == 1 else 1   # the CPU baseline is reported at N = 1 only
         ref = ctr = links = None
         while reps < max_reps and (reps < 1 or time.time() < budget):
             c0 = time.perf_counter()
@@ -436,7 +468,7 @@ def main() -> None:
         casts = ctr["rays"]
         unit = "Mrays/s" if B == 1 else "Mcasts/s"
         if world == 1:
-            n1 = min(n, 100000 if args.kind == "voxel" else 20000)
+            n1 = min(n, (100000 if kind == "voxel" else 20000) // B)
             c0 = time.perf_counter()
             _, c1ctr, _ = oracle_pass(rays_h[:n1], 1)
             dt1 = time.perf_counter() - c0
@@ -445,10 +477,20 @@ def main() -> None:
                              + f", best of {reps} passes on {cores} threads; 1 thread: {c1ctr['rays'] / dt1 / 1e6:.3f} {unit} on {n1} rays. "
                              f"C restatement of Hare {ref_name} (oracle/, per-thread mailbox, no per-candidate allocation): an upper "
                              f"bound on the C# reference, which cannot be run here"}
-        bytes_pass = algorithmic_bytes(ctr, args.kind, links)
+        bytes_pass = algorithmic_bytes(ctr, kind, links)
         achieved = bytes_pass / (sum(per_cast_ms) * 1e-3) / 1e9
-        wkey = f"{args.scene}-{args.kind}-" + (f"D{args.domain}-" if args.kind == "voxel" else "") + f"n{n}" + (f"-b{B}" if B > 1 else "")
-        traffic, insts = load_traffic(wkey)
+        wkey = f"{scene}-{kind}-" + (f"D{domain}-" if kind == "voxel" else "") + f"n{n}" + (f"-b{B}" if B > 1 else "")
+        prof = load_traffic(wkey)
+        traffic = None if prof is None else prof.get("hbm_bytes_per_launch")
+        issue = None
+        if prof is not None and prof.get("SQ_INSTS_VALU"):
+            # issue side, as a number: wave-level VALU instructions x 4 cycles (one wave64 FP32/integer instruction on a SIMD-32;
+            # FP64 ones take 8) over every SIMD's cycles in the kernel's duration -- a LOWER bound on how busy the vector issue is
+            issue = {"valu_insts_per_launch": int(prof["SQ_INSTS_VALU"]),
+                     "valu_issue_frac": round(prof["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * GPU_CLOCK_HZ * kern_ms * 1e-3), 4),
+                     "sq_active_inst_any_frac": prof.get("sq_active_inst_any_frac"), "sq_wait_any_frac": prof.get("sq_wait_any_frac"),
+                     "ta_busy_frac": prof.get("ta_busy_frac"), "l1_accesses_per_ray": prof.get("l1_accesses_per_ray"),
+                     "source": "profiles/traffic.json (rocprofv3 PMC passes on this kernel source)"}
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": kernel_name, "kernel_ms": round(kern_ms, 4),
@@ -456,8 +498,9 @@ def main() -> None:
                     "bytes_per_cast": round(bytes_pass / max(casts, 1), 1),
                     "per_cast": {"C_cells": round(ctr["cells"] / max(casts, 1), 2), "L_entries": round(ctr["entries"] / max(casts, 1), 2),
                                  "T_tests": round(ctr["tests"] / max(casts, 1), 2)},
-                    # what the counters say actually bounds the kernel (DESIGN.md 9): the scene is cache-resident, HBM is a few % busy
+                    # what the counters say actually bounds the kernel (DESIGN.md 5): the scene is cache-resident, HBM is a few % busy
                     "measured_bound": "valu issue + dependent-load latency (not HBM)",
+                    "issue_side": issue,
                     "hbm_busy_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1)}
         if B > 1:
@@ -470,27 +513,119 @@ def main() -> None:
             got = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)   # events of the last cast
         fields = ("hit", "poly_id", "t", "x", "y", "z", "u", "v")
         parity = bool(all(np.array_equal(got[f], ref[f]) for f in fields))
+        if bounce_batch is not None:
+            bb_ev = bounce_batch.pop("events")
+            bounce_batch["parity_vs_oracle"] = bool(all(np.array_equal(bb_ev[f], ref[f]) for f in fields)) and bounce_batch["casts"] == casts
+    if bounce_batch is not None:
+        bounce_batch.pop("events", None)
 
-    ms_per_step = wall * 1e3 / args.steps
-    value = n_total * B * args.steps / wall / 1e6   # casts per second
+    ms_per_step = wall * 1e3 / steps
+    value = n_total * B * steps / wall / 1e6   # casts per second
     line = {
         "metric": "Mrays/s (primary hits) into 100k-tri mesh", "value": round(value, 2), "unit": "Mrays/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{n} spherical-Fibonacci burst rays per GPU -> {mesh.name} "
                                f"({mesh.P} triangles), {kdesc}, closest hit (X_Event)"
                                + (f", x{B} specular bounces device-resident (value = casts/s)" if B > 1 else ""),
                    "rays_per_gpu": n, "triangles": mesh.P, "partition": kdesc, "sharding": f"rays x{world}, scene replicated",
                    "buffer_sets": n_sets,
-                   "backend": ("none" if world == 1 else ("rccl" if args.backend == "nccl" else "gloo (rehearsal)"))},
-        "ms_per_step_per_rank": {"max": round(max(walls) * 1e3 / args.steps, 4), "min": round(min(walls) * 1e3 / args.steps, 4)},
-        "device_ms_per_step": round(dev_ms / args.steps, 4), "kernel_only_mrays_s": round(n / kern_ms / 1e3, 2),
+                   "backend": ("none" if dist is None else ("rccl" if backend == "nccl" else "gloo (rehearsal)"))},
+        "ms_per_step_per_rank": {"max": round(max(walls) * 1e3 / steps, 4), "min": round(min(walls) * 1e3 / steps, 4)},
+        "device_ms_per_step": round(dev_ms / steps, 4), "kernel_only_mrays_s": round(n / kern_ms / 1e3, 2),
         "end_to_end_mrays_s": None if e2e is None else round(e2e, 1),
         "hits": hits_total, "rays": rays_total, "build_s": round(build_s, 3),
         "x_event_parity_vs_oracle": parity,
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(line), flush=True)
+    if e2e_slim is not None:
+        line["end_to_end_slim_mrays_s"] = round(e2e_slim, 1)
+    if bounce_batch is not None:
+        line["bounce_batch"] = bounce_batch
+    del ray_sets, out_sets, d_rays, d_out, d_rays0, d_excl
+    torch.cuda.empty_cache()
+    return line
+
+
+# What the default N = 1 run appends to the headline line (BASELINE.json configs 3, 4, 5 at one GPU's share)
+EXTRA_CONFIGS = (
+    ("c3", {"scene": "hall", "kind": "octree", "domain": 64, "rays": 1 << 20, "bounces": 1, "steps": 5, "warmup": 1}),
+    ("c4_shard", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 21, "bounces": 1, "steps": 8, "warmup": 2}),
+    ("c5", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 20, "bounces": 8, "steps": 3, "warmup": 1}),
+)
+EXTRA_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernel_only_mrays_s", "hits", "rays", "build_s",
+              "x_event_parity_vs_oracle", "roofline", "cpu_baseline", "bounce_batch")
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the driver's command line: start the ranks ourselves, BEFORE anything initialises the GPU in this process
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, the two must agree")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-cast path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit(f"--gpus {world} with backend nccl needs {world} GPUs, {ndev} visible "
+                         f"(--backend gloo rehearses the multi-rank path with ranks sharing a GPU)")
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1 or args.force_dist:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                    # --force-dist on one rank: a process group of one
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            # RCCL builds its communicator on the first collective: do that here, never inside the timed region
+            _t = torch.zeros(8, dtype=torch.int64, device="cuda")
+            dist.all_reduce(_t)
+            torch.cuda.synchronize()
+        else:
+            dist.init_process_group(backend="gloo")
+            dist.all_reduce(torch.zeros(8, dtype=torch.int64))
+
+    env = Env(args, rank, local_rank, world, dist, device)
+    head = {"scene": args.scene, "kind": args.kind, "domain": args.domain, "rays": args.rays, "bounces": args.bounces,
+            "steps": args.steps, "warmup": args.warmup, "cpu_baseline": not args.no_cpu_baseline, "e2e": not args.no_e2e,
+            "bounce_api": args.bounce_api}
+    line = measure(head, env)
+
+    default_workload = (args.scene == "hall" and args.kind == "voxel" and args.domain == 64 and args.rays == 1 << 20 and args.bounces == 1)
+    extras = (default_workload and not args.no_extra_configs) or args.extra_configs
+    if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
+        # configs 3, 4 (one GPU's shard) and 5 in the same process, driver-observed like the headline; fewer steps, one oracle pass
+        line["configs"] = {}
+        prev_scene = args.scene
+        for name, cfg in EXTRA_CONFIGS:
+            if cfg["scene"] != prev_scene:
+                env.drop(prev_scene)
+                prev_scene = cfg["scene"]
+            if args.extra_rays > 0:
+                cfg = dict(cfg, rays=min(cfg["rays"], args.extra_rays))
+            w = dict(cfg, cpu_baseline=True, e2e=False, copy_bw=False, cpu_reps=2, cpu_budget_s=6.0,
+                     bounce_api=("batch" if cfg["bounces"] > 1 else "device"))
+            t0 = time.time()
+            sub = measure(w, env)
+            sub = {k: sub[k] for k in EXTRA_KEYS if k in sub}
+            sub["wall_s"] = round(time.time() - t0, 1)
+            line["configs"][name] = sub
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

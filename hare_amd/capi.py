@@ -68,6 +68,7 @@ SYMBOLS = {
     "hare_topology_ingest": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "hare_scene_create": (C.c_int, [_vp, _i32, _i32, _vp]),
     "hare_scene_destroy": (None, [_vp]),
+    "hare_scene_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
     "hare_voxel_build": (C.c_int, [_vp, _i32]),
     "hare_voxel_build_adaptive": (C.c_int, [_vp, _i32, _i32]),
     "hare_octree_build": (C.c_int, [_vp, _i32, _i32]),

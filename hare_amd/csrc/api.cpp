@@ -89,7 +89,6 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
-        {"hare_ctr_reduce", &m->ctr_reduce},
         {"hare_occlusion", &m->occlusion},
         {"hare_cull_audit", &m->cull_audit},
         {"hare_voxel_persist_prof", &m->voxel_persist_prof},
@@ -162,10 +161,11 @@ int ensure_device(Scene& s, const HipApi*& H)
     }
     if (!s.stream) HIP_TRY(H->StreamCreate(&s.stream));
     if (!s.d_work) {
-        HIP_TRY(H->Malloc(&s.d_work, 256));
-        HIP_TRY(H->MemsetAsync(s.d_work, 0, 256, nullptr));
+        // the launch-slot ring: zeroed ONCE, here; afterwards every launch leaves its slot zeroed (launch_epilogue, kernels.hip)
+        HIP_TRY(H->Malloc(&s.d_work, (size_t)kLaunchSlots * sizeof(LaunchSlotMem)));
+        HIP_TRY(H->Memset(s.d_work, 0, (size_t)kLaunchSlots * sizeof(LaunchSlotMem)));
+        HIP_TRY(H->DeviceSynchronize());     // launches may come on any stream
     }
-    if (!s.d_part) HIP_TRY(H->Malloc(&s.d_part, (size_t)kPartSlots * kPartWaves * 16));
     return HARE_OK;
 }
 
@@ -290,41 +290,60 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
     return HARE_OK;
 }
 
-// Batch counters of a persistent launch: the waves store {rays, hits} partials (io.part), one small
-// kernel adds them to the caller's counters afterwards.
-int prepare_partials(Scene& s, const DeviceModule& M, ShootIO& io, unsigned& pgrid, unsigned slot)
+// One persistent launch (K1p, K1q, K2p, K2q) on the next slot of the scene's launch-slot ring.  The slot holds the launch's
+// ticket word, done counters and counter shards (LaunchSlotMem); the launch's own last wave leaves it zeroed, so nothing is
+// enqueued in front of the kernel or behind it.  A slot comes round again after kLaunchSlots launches, possibly on another
+// stream: the new launch waits for the event the slot's previous launch recorded behind itself (a no-op when that launch has
+// finished, which is the rule), so a 65th launch in flight waits for the first instead of sharing its ticket word.  The
+// slot's mutex keeps wait + launch + record together when several host threads launch on one scene.
+// args[1] must point to `io`.
+int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, ShootIO& io,
+                   void** args)
 {
-    io.part = nullptr;
-    if (!io.ctr) return HARE_OK;
-    if (!M.ctr_reduce || !s.d_part) {
-        set_error("hare_shoot: counter-reduce kernel missing from code object");
-        return HARE_E_STATE;
-    }
-    pgrid = std::min(pgrid, kPartWaves / 4u);
-    io.part = (unsigned long long*)s.d_part + (size_t)(slot % kPartSlots) * kPartWaves * 2;
+    const unsigned idx = s.work_slot.fetch_add(1) % kLaunchSlots;
+    Scene::LaunchSlot& sl = s.slots[idx];
+    std::lock_guard<std::mutex> lk(sl.mu);
+    io.work = reinterpret_cast<unsigned int*>(static_cast<LaunchSlotMem*>(s.d_work) + idx);
+    if (!sl.ev) HIP_TRY(H->EventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.used) HIP_TRY(H->StreamWaitEvent(st, sl.ev, 0));
+    const int rc = launch(H, f, grid, block, lds, st, args);
+    if (rc) return rc;
+    HIP_TRY(H->EventRecord(sl.ev, st));
+    sl.used = true;
     return HARE_OK;
 }
 
-int reduce_counters(const HipApi* H, const DeviceModule& M, const ShootIO& io, unsigned waves, hipStream_t st)
+// Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
+// counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass on a scene whose
+// `dev` option is set (HARE_DEV=1 when the scene was created, or hare_scene_set_option), so a stray bit from a caller can
+// never reach a kernel.
+constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS;
+uint32_t sanitize_flags(const Scene& s, uint32_t flags)
 {
-    const unsigned long long* part = io.part;
-    int nw = (int)waves;
-    unsigned long long* ctr = io.ctr;
-    void* args[] = {&part, &nw, &ctr};
-    return launch(H, M.ctr_reduce, 1, 256, 0, st, args);
+    return flags & (kPublicFlags | (s.opt.dev ? 0xE000u : 0u));
 }
 
-// Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
-// counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass when the process
-// opted in with HARE_DEV=1 (tools/, the cull-audit test), so a stray bit from a caller can never reach a kernel.
-// Which production voxel kernel serves a batch (measured on MI355X over 9 scene / grid combinations): K1q
-// (hare_voxel_pool_*) once a launch is long enough for its steady state to outweigh its longer ramp and drain, K1p
-// (hare_voxel_persist_*) below.  Where that is depends on whether the scene's records stay in the L2: K1q keeps 1.5x the rays
-// in flight per CU and requests eight candidates' records per task, which is what covers miss latency --
-//  * a scene far beyond the L2 (the 986k-triangle cathedral, ~200 MB): K1q from ~400k rays (524k: -18 ... -28 %; 262k: +12 ... +33 %);
-//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): K1q from ~1.18M rays (-2 % there, -9 % at
-//    1.5M, -20 % at 16M; +7 % at the 1M-ray headline, +17 ... +68 % from 65k to 524k).
-// HARE_VOXEL_KERNEL=pool|persist overrides (developer A/B).
+// The scene's options as the environment gives them; called once per scene, from hare_scene_create (single-caller by contract).
+void read_env_options(SceneOptions& o)
+{
+    auto on = [](const char* e) { return e && *e && *e != '0'; };
+    o = SceneOptions();
+    if (const char* b = getenv("HARE_BUILD")) o.build_host = strcmp(b, "host") == 0;
+    o.dev = on(getenv("HARE_DEV"));
+    if (!o.dev) return;            // everything below is a developer override: ignored unless the process opted in
+    if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
+    if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
+    if (const char* t = getenv("HARE_TICKET")) o.ticket_rays = atoi(t);
+    if (const char* t = getenv("HARE_K1P_STATIC_RAYS")) o.k1p_static_rays = atoi(t);
+    if (const char* t = getenv("HARE_K2P_STATIC_RAYS")) o.k2p_static_rays = atoi(t);
+    if (const char* t = getenv("HARE_BATCH_CHUNKS")) o.batch_chunks = atoi(t);
+    if (const char* t = getenv("HARE_TUNE")) {
+        int v[5] = {0, 0, 0, 0, 0};
+        if (sscanf(t, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) >= 3)
+            for (int k = 0; k < 5; ++k) o.tune[k] = v[k];
+    }
+}
+
 // The persistent kernels (K1p, K2p) give every wave of the grid a static first chunk of rays and hand out the rest by tickets:
 // 128 rays per wave when the batch has plenty, less for a batch that does not (a fixed 128 left half of the grid's waves
 // without any work at 262k rays), in steps of 32 and at least 64.  How much less differs (measured): a voxel ray
@@ -343,35 +362,106 @@ size_t voxel_scene_bytes(const Scene& s, size_t top)
     const size_t items = top < s.vox.items.size() ? s.vox.items[top].size() : 0;
     return (size_t)s.topos[top].P * (sizeof(PolyRec) + (size_t)kCullStride) + ncell * sizeof(CellRec) + items * sizeof(int32_t);
 }
-bool voxel_pool_wanted(const Scene& s, size_t top, int64_t n)
+int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 {
-    if (const char* vk = getenv("HARE_VOXEL_KERNEL")) {
-        if (strcmp(vk, "pool") == 0) return true;
-        if (strcmp(vk, "persist") == 0) return false;
-    }
-    return n >= (voxel_scene_bytes(s, top) > (96ull << 20) ? 393216ll : 1179648ll);
+    if (s.opt.ticket_rays > 0) return std::max(8, std::min(4096, s.opt.ticket_rays));            // developer sweeps
+    // measured optimum on MI355X (tools/sweep_ticket.py): 32 rays up to ~1.5M rays, where the end of the batch dominates,
+    // growing to 128 where the ~11 ns/ticket same-address atomic rate would start to bind
+    if (pool) return n < 1572864 ? 32 : (n < 6291456 ? 64 : 128);
+    return n < 1572864 ? 32 : (n < 6291456 ? 64 : (n < 12582912 ? 96 : 128));
 }
+
+// Which kernel serves a shoot: ONE function, used by the launcher and by hare_shoot_kernel_name, so that the name a profile
+// is read by is the kernel that ran -- including the fall-backs (kernel missing from the code object, LDS that does not fit).
+// `M` may be null (no device yet): the rule alone, for a 256-CU part.
+//
+// The voxel path has two production kernels (measured on MI355X over 9 scene / grid combinations): K1q
+// (hare_voxel_pool_*) once a launch is long enough for its steady state to outweigh its longer ramp and drain, K1p
+// (hare_voxel_persist_*) below.  Where that is depends on whether the scene's records stay in the L2: K1q keeps 1.5x the rays
+// in flight per CU and requests eight candidates' records per task, which is what covers miss latency --
+//  * a scene far beyond the L2 (the 986k-triangle cathedral, ~200 MB): K1q from one pool fill of the whole chip
+//    (CUs x 12 waves x 128 rays = 393 216 rays on the 256-CU MI355X; 524k: -18 ... -28 %; 262k: +12 ... +33 %);
+//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): from three fills (1 179 648 rays: -2 %
+//    there, -9 % at 1.5M, -20 % at 16M; +7 % at the 1M-ray headline, +17 ... +68 % from 65k to 524k).
+// Both thresholds scale with the CU count of the device the scene lives on.
+enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, OctSimple, OctCount, OctPool, OctPersist, KdSimple, KdCount, None };
+struct KernChoice {
+    Kern k = Kern::None;
+    const char* name = "";
+    hipFunction_t f = nullptr;
+};
+constexpr unsigned kLdsMax = 160u * 1024u;
 constexpr bool kOctreePoolDefault = false;
-// The octree's production kernels: K2q (hare_octree_pool) / K2p (hare_octree_persist); HARE_OCTREE_KERNEL=pool|persist overrides.
-bool octree_pool_wanted(int64_t n)
+#ifndef HARE_K2P_WAVES_PER_EU
+#define HARE_K2P_WAVES_PER_EU 4
+#endif
+
+KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, size_t top, int64_t n, uint32_t flags)
 {
-    if (const char* k = getenv("HARE_OCTREE_KERNEL")) {
-        if (strcmp(k, "pool") == 0) return true;
-        if (strcmp(k, "persist") == 0) return false;
+    KernChoice c;
+    const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0, simple = (flags & HARE_SHOOT_SIMPLE_KERNEL) != 0;
+    const bool quads = s.topos[top].has_quads;
+    const bool huge = n >= 0x7FFFFF00ll;                  // the persistent kernels index rays with 32 bits
+    const int cus = (M && M->cu_count > 0) ? M->cu_count : 256;
+    auto pick = [&](Kern k, const char* name, hipFunction_t DeviceModule::*f) {
+        c.k = k;
+        c.name = name;
+        c.f = M ? M->*f : nullptr;
+    };
+    auto have = [&](hipFunction_t DeviceModule::*f) { return !M || (M->*f) != nullptr; };
+    if (kind == HARE_KIND_VOXEL) {
+        if (flags & 0x8000u) { pick(Kern::VoxelAudit, "hare_cull_audit", &DeviceModule::cull_audit); return c; }
+        const bool persist_ok = have(&DeviceModule::voxel_persist_tri) && have(&DeviceModule::voxel_persist_quad) &&
+                                have(&DeviceModule::voxel_persist_tri_g) && have(&DeviceModule::voxel_persist_quad_g);
+        if (count) { pick(Kern::VoxelCount, "hare_voxel_shoot_count", &DeviceModule::voxel_count); return c; }
+        if (simple || huge || !persist_ok) {
+            if (quads) pick(Kern::VoxelSimple, "hare_voxel_shoot_quad", &DeviceModule::voxel_quad);
+            else pick(Kern::VoxelSimple, "hare_voxel_shoot_tri", &DeviceModule::voxel_tri);
+            return c;
+        }
+        const bool coarse = s.occ_shift > 0;
+        const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
+        const bool pool_fits = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= kLdsMax && s.vox.ct <= 512 && !(flags & 0x4000u);
+        const int64_t fill = (int64_t)cus * kPoolWaves * kPoolSlots;          // rays in flight when every pool of the chip is full
+        const bool pool_wanted = s.opt.voxel_kernel == 2 || (s.opt.voxel_kernel == 0 &&
+                                 n >= (voxel_scene_bytes(s, top) > (96ull << 20) ? fill : 3 * fill));
+        hipFunction_t DeviceModule::*pf = !coarse ? (quads ? &DeviceModule::voxel_pool_quad : &DeviceModule::voxel_pool_tri)
+                                                   : (quads ? &DeviceModule::voxel_pool_quad_g : &DeviceModule::voxel_pool_tri_g);
+        if (pool_wanted && pool_fits && have(pf)) {
+            pick(Kern::VoxelPool, !coarse ? (quads ? "hare_voxel_pool_quad" : "hare_voxel_pool_tri")
+                                          : (quads ? "hare_voxel_pool_quad_g" : "hare_voxel_pool_tri_g"), pf);
+            return c;
+        }
+        if ((flags & 0x4000u) && have(&DeviceModule::voxel_persist_prof) && (!M || M->voxel_persist_prof) && !coarse && !quads) {
+            pick(Kern::VoxelProf, "hare_voxel_persist_prof", &DeviceModule::voxel_persist_prof);
+            return c;
+        }
+        pick(Kern::VoxelPersist, !coarse ? (quads ? "hare_voxel_persist_quad" : "hare_voxel_persist_tri")
+                                         : (quads ? "hare_voxel_persist_quad_g" : "hare_voxel_persist_tri_g"),
+             !coarse ? (quads ? &DeviceModule::voxel_persist_quad : &DeviceModule::voxel_persist_tri)
+                     : (quads ? &DeviceModule::voxel_persist_quad_g : &DeviceModule::voxel_persist_tri_g));
+        return c;
     }
-    return kOctreePoolDefault && n >= 65536;
-}
-bool voxel_pool_usable(const Scene& s, uint32_t flags)
-{
-    const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
-    return lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= 160u * 1024u && s.vox.ct <= 512 && !(flags & 0x4000u);
-}
-constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS;
-uint32_t sanitize_flags(uint32_t flags)
-{
-    const char* e = getenv("HARE_DEV");
-    const bool dev = e && *e && *e != '0';
-    return flags & (kPublicFlags | (dev ? 0xE000u : 0u));
+    if (kind == HARE_KIND_OCTREE) {
+        if (count) { pick(Kern::OctCount, "hare_octree_shoot_count", &DeviceModule::octree_count); return c; }
+        const int levels = std::max(1, s.oct_levels);
+        const bool small_tree = (int64_t)s.oct.nodes.size() < (1 << 23);
+        if (!simple && !huge && small_tree) {
+            const bool pool_wanted = s.opt.octree_kernel == 2 || (s.opt.octree_kernel == 0 && kOctreePoolDefault && n >= 65536);
+            if (pool_wanted && have(&DeviceModule::octree_pool)) { pick(Kern::OctPool, "hare_octree_pool", &DeviceModule::octree_pool); return c; }
+            if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist)) {
+                pick(Kern::OctPersist, "hare_octree_persist", &DeviceModule::octree_persist);
+                return c;
+            }
+        }
+        pick(Kern::OctSimple, "hare_octree_shoot", &DeviceModule::octree);
+        return c;
+    }
+    if (kind == HARE_KIND_KDTREE) {
+        if (count) pick(Kern::KdCount, "hare_kdtree_shoot_count", &DeviceModule::kdtree_count);
+        else pick(Kern::KdSimple, "hare_kdtree_shoot", &DeviceModule::kdtree);
+    }
+    return c;
 }
 
 // Frames the octree kernels keep per lane: one per interior level the tree really has.
@@ -392,10 +482,17 @@ int32_t octree_levels(const OctreeHost& o)
     return std::max(best, 1);
 }
 
+// [a, a + na) and [b, b + nb) share a byte
+bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb)
+{
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return a && b && x < y + nb && y < x + na;
+}
+
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
                       const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st)
 {
-    flags = sanitize_flags(flags);
+    flags = sanitize_flags(s, flags);
     if (n < 0 || top < 0 || top >= (int32_t)s.topos.size()) {
         set_error("hare_shoot: bad n or top_index");
         return HARE_E_INVALID;
@@ -408,6 +505,16 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     if (!d_rays || !d_out) {
         set_error("hare_shoot: null rays/out");
         return HARE_E_INVALID;
+    }
+    // A live ray's own X_Event slot is its scratch in the pool kernels, and rays[] is re-read while events are written: the
+    // buffers of one call must not alias (each other, the exclusion arrays, or the counters)
+    {
+        const size_t rb = (size_t)n * sizeof(hare_ray), ob = (size_t)n * sizeof(hare_xevent), eb = (size_t)n * sizeof(int32_t);
+        if (ranges_overlap(d_rays, rb, d_out, ob) || ranges_overlap(d_e1, eb, d_out, ob) || ranges_overlap(d_e2, eb, d_out, ob) ||
+            ranges_overlap(d_ctr, sizeof(hare_counters), d_out, ob) || ranges_overlap(d_ctr, sizeof(hare_counters), d_rays, rb)) {
+            set_error("hare_shoot: rays, exclusions, events and counters must not overlap");
+            return HARE_E_INVALID;
+        }
     }
     ShootIO io;
     memset(&io, 0, sizeof io);
@@ -425,22 +532,20 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.exact_min_parked = 8;
     io.audit_polys = s.topos[top].P;
     unsigned tune_blocks_per_cu = 0;
-    if (getenv("HARE_TUNE")) {   // developer sweeps (tools/sweep.py, tools/phase_prof.py): steps,refill,chunk,blocks_per_cu,exact;
-                                 // only blocks_per_cu reaches the production kernels, the rest the profiling build
-        int a = 0, b = 0, c = 0, d = 0, e = 0;
-        if (sscanf(getenv("HARE_TUNE"), "%d,%d,%d,%d,%d", &a, &b, &c, &d, &e) >= 3 && a > 0 && b > 0 && b <= 64 && c > 0) {
-            io.steps_per_round = a;
-            io.refill_min_idle = b;
-            io.ray_chunk = c;
-            tune_blocks_per_cu = d > 0 ? (unsigned)d : 0u;
-            if (e > 0 && e <= 64) io.exact_min_parked = e;
-        }
+    if (s.opt.tune[0] > 0 && s.opt.tune[1] > 0 && s.opt.tune[1] <= 64 && s.opt.tune[2] > 0) {
+        // developer sweeps (tools/sweep.py, tools/phase_prof.py): steps,refill,chunk,blocks_per_cu,exact;
+        // only blocks_per_cu reaches the production kernels, the rest the profiling build
+        io.steps_per_round = s.opt.tune[0];
+        io.refill_min_idle = s.opt.tune[1];
+        io.ray_chunk = s.opt.tune[2];
+        tune_blocks_per_cu = s.opt.tune[3] > 0 ? (unsigned)s.opt.tune[3] : 0u;
+        if (s.opt.tune[4] > 0 && s.opt.tune[4] <= 64) io.exact_min_parked = s.opt.tune[4];
     }
     const bool quads = s.topos[top].has_quads;
-    const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0;
     const DeviceModule& M = *s.module;
     const unsigned block = 256;
     const unsigned grid = (unsigned)((n + block - 1) / block);
+    const unsigned cus = (unsigned)std::max(1, M.cu_count);
 
     if (kind == HARE_KIND_VOXEL) {
         if (!s.vox.built || s.d_cells.empty()) {
@@ -464,87 +569,46 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             g.omax[a] = s.vox.omax[a];
             g.vd[a] = s.vox.vd[a];
         }
-        if (flags & 0x8000u) {   // tests only: FP32-cull audit (counters 5..7)
-            if (!M.cull_audit || quads) {
-                set_error("hare_shoot: cull audit needs an all-triangle topology and the audit kernel");
-                return HARE_E_STATE;
-            }
-            void* args[] = {&g, &io};
-            return launch(H, M.cull_audit, grid, block, 0, st, args);
+        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags);
+        if (!kc.f || (kc.k == Kern::VoxelAudit && quads)) {
+            set_error(kc.k == Kern::VoxelAudit ? "hare_shoot: cull audit needs an all-triangle topology and the audit kernel"
+                                               : "hare_shoot: kernel missing from code object");
+            return HARE_E_STATE;
         }
-        const bool simple = count || (flags & HARE_SHOOT_SIMPLE_KERNEL) || n >= 0x7FFFFF00ll || !M.voxel_persist_tri || !M.voxel_persist_quad ||
-                            !M.voxel_persist_tri_g || !M.voxel_persist_quad_g;
-        if (simple) {
-            hipFunction_t f = count ? M.voxel_count : (quads ? M.voxel_quad : M.voxel_tri);
-            if (!f) {
-                set_error("hare_shoot: kernel missing from code object");
-                return HARE_E_STATE;
-            }
-            void* args[] = {&g, &io};
-            return launch(H, f, grid, block, 0, st, args);
-        }
+        void* args[] = {&g, &io};
+        if (kc.k == Kern::VoxelAudit || kc.k == Kern::VoxelCount || kc.k == Kern::VoxelSimple)
+            return launch(H, kc.f, grid, block, 0, st, args);
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;     // the occupancy bitmap, <= 64 KB (occ_layout)
-        const bool coarse = s.occ_shift > 0;
-        // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
-        {
+        if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
+        if (kc.k == Kern::VoxelPool) {
+            // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
             const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
-            hipFunction_t pf = !coarse ? (quads ? M.voxel_pool_quad : M.voxel_pool_tri) : (quads ? M.voxel_pool_quad_g : M.voxel_pool_tri_g);
-            if (pf && voxel_pool_wanted(s, (size_t)top, n) && voxel_pool_usable(s, flags)) {
-                if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
-                unsigned pgrid = (unsigned)std::max(1, M.cu_count);
-                pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
-                if (pgrid == 0) pgrid = 1;
-                const unsigned slot = s.work_slot.fetch_add(1) % 64u;
-                io.part = nullptr;
-                if (io.ctr) {
-                    if (!M.ctr_reduce || !s.d_part) {
-                        set_error("hare_shoot: counter-reduce kernel missing from code object");
-                        return HARE_E_STATE;
-                    }
-                    pgrid = std::min(pgrid, kPartWaves / (unsigned)kPoolWaves);
-                    io.part = (unsigned long long*)s.d_part + (size_t)slot * kPartWaves * 2;
-                }
-                io.ticket_rays = n < 1572864 ? 32 : (n < 6291456 ? 64 : 128);
-                if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
-                io.work = (unsigned int*)s.d_work + slot;
-                HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
-                void* args[] = {&g, &io};
-                int rc = launch(H, pf, pgrid, 64u * (unsigned)kPoolWaves, plds, st, args);
-                if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * (unsigned)kPoolWaves, st);
-                return rc;
-            }
+            unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
+            if (pgrid == 0) pgrid = 1;
+            io.ticket_rays = ticket_rays_for(s, n, true);
+            return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args);
         }
         // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
         unsigned per_cu = 4;
         if (tune_blocks_per_cu) per_cu = tune_blocks_per_cu;
-        if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(160 * 1024 / lds));
-        unsigned pgrid = (unsigned)std::max(1, M.cu_count) * std::max(1u, per_cu);
+        if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(kLdsMax / lds));
+        unsigned pgrid = cus * std::max(1u, per_cu);
         pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
         if (pgrid == 0) pgrid = 1;
-        const unsigned slot = s.work_slot.fetch_add(1) % 64u;       // this launch's scratch: ticket word + counter partials
-        if (int rc = prepare_partials(s, M, io, pgrid, slot)) return rc;
-        // ticket size: measured optimum on MI355X (tools/sweep_ticket.py) -- 32 rays up to ~1.5M rays, where the
-        // end of the batch dominates, growing to 128 where the ~11 ns/ticket atomic rate would start to bind
-        io.ticket_rays = n < 1572864 ? 32 : (n < 6291456 ? 64 : (n < 12582912 ? 96 : 128));
-        if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
-        io.work = (unsigned int*)s.d_work + slot;
-        HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+        io.ticket_rays = ticket_rays_for(s, n, false);
         // static first chunk per wave (static_chunk_rays): at 262k rays, where 128 left half the grid's waves without work, 0.348 -> 0.239 ms
         io.static_rays = static_chunk_rays(n, pgrid, false);
-        if (getenv("HARE_K1P_STATIC_RAYS")) io.static_rays = std::max(32, std::min(256, atoi(getenv("HARE_K1P_STATIC_RAYS")) / 32 * 32));   // developer sweeps
-        void* args[] = {&g, &io};
-        hipFunction_t pf = !coarse ? (quads ? M.voxel_persist_quad : M.voxel_persist_tri)
-                                   : (quads ? M.voxel_persist_quad_g : M.voxel_persist_tri_g);
-        if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
-        if ((flags & 0x4000u) && M.voxel_persist_prof && !coarse && !quads && d_ctr) {
-            // developer profiling: phase statistics land in the 17 u64 words FOLLOWING the counters block
-            io.prof = (unsigned long long*)d_ctr + CTR_WORDS;
-            pf = M.voxel_persist_prof;
+        if (s.opt.k1p_static_rays > 0) io.static_rays = std::max(32, std::min(256, s.opt.k1p_static_rays / 32 * 32));   // developer sweeps
+        unsigned lds_total = lds;
+        if (kc.k == Kern::VoxelProf) {
+            if (!d_ctr) {
+                set_error("hare_shoot: the phase profile needs a counters block");
+                return HARE_E_INVALID;
+            }
+            io.prof = (unsigned long long*)d_ctr + CTR_WORDS;      // phase statistics land in the 17 u64 words FOLLOWING the counters block
+            lds_total += 4u * 18u * 8u;                            // + the profiling build's per-wave statistics
         }
-        const unsigned lds_total = lds + (pf == M.voxel_persist_prof ? 4u * 18u * 8u : 0u);   // + the profiling build's per-wave statistics
-        int rc = launch(H, pf, pgrid, block, lds_total, st, args);
-        if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * 4u, st);
-        return rc;
+        return launch_on_slot(s, H, kc.f, pgrid, block, lds_total, st, io, args);
     }
     if (kind == HARE_KIND_OCTREE) {
         if (!s.oct.built || !s.d_oct_nodes) {
@@ -564,102 +628,71 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.items = (const int32_t*)s.d_oct_items;
         g.n_nodes = (int32_t)s.oct.nodes.size();
         g.max_depth = std::max(1, s.oct_levels);   // frames per lane = interior levels the tree really has (<= maxDepth)
-        hipFunction_t f = count ? M.octree_count : M.octree;
-        if (!f) {
-            set_error("hare_shoot: octree kernel missing from code object");
-            return HARE_E_STATE;
-        }
-        constexpr unsigned kLdsMax = 160u * 1024u;
         if ((size_t)g.max_depth * 64u * 24u > kLdsMax) {   // (24 bytes per level and lane: the simple kernel's frames)   // cannot happen while hare_octree_build caps maxDepth at 24
             set_error("hare_shoot: octree is deeper than the per-lane frames the kernels keep in LDS (" +
                       std::to_string(g.max_depth) + " levels)");
             return HARE_E_UNSUPPORTED;
         }
-        const unsigned plds = (unsigned)g.max_depth * 256u * 20u;   // persistent kernel: 20 bytes x levels x 256 lanes per workgroup (interval + child word)
-        // K2q (octree_pool.hip): more rays than lanes; frames below the top one in a device scratch block per launch in flight
-        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_pool && n < 0x7FFFFF00ll && g.n_nodes < (1 << 23) && octree_pool_wanted(n)) {
+        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags);
+        if (!kc.f) {
+            set_error("hare_shoot: octree kernel missing from code object");
+            return HARE_E_STATE;
+        }
+        if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
+        if (kc.k == Kern::OctPool) {
+            // K2q (octree_pool.hip): more rays than lanes; frames below the top one in a device scratch block per launch in flight
             const unsigned stride = 24u + 24u * (unsigned)g.max_depth;
-            unsigned pgrid = (unsigned)std::max(1, M.cu_count);
-            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 64 * kOctPoolWaves - 1) / (64 * kOctPoolWaves)));
+            unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + 64 * kOctPoolWaves - 1) / (64 * kOctPoolWaves)));
             if (pgrid == 0) pgrid = 1;
-            pgrid = std::min(pgrid, kPartWaves / (unsigned)kOctPoolWaves);
-            const size_t need = (size_t)std::max(1, M.cu_count) * kOctPoolWaves * kOctPoolSlots * stride;
-            unsigned char* scratch = nullptr;
-            unsigned ring = 0;
-            {
-                std::lock_guard<std::mutex> lk(s.oct_scratch_mu);
-                if (s.oct_scratch_bytes < need) {          // first use, or a deeper tree since: (re)allocate the ring
-                    for (int k = 0; k < kOctScratchRing; ++k) {
-                        if (s.oct_scratch_ev[k]) (void)H->EventSynchronize(s.oct_scratch_ev[k]);
-                        dev_free(H, s.d_oct_scratch[k]);
-                    }
-                    s.oct_scratch_bytes = 0;
-                    for (int k = 0; k < kOctScratchRing; ++k) {
-                        HIP_TRY(H->Malloc(&s.d_oct_scratch[k], need));
-                        if (!s.oct_scratch_ev[k]) HIP_TRY(H->EventCreate(&s.oct_scratch_ev[k]));
-                    }
-                    s.oct_scratch_bytes = need;
-                    s.oct_scratch_next = 0;
+            const size_t need = (size_t)cus * kOctPoolWaves * kOctPoolSlots * stride;
+            // The scratch ring: the block's previous user must have finished before this launch starts, and the event that says
+            // so must have been RECORDED before a later launch waits on it -- so the lock is held across wait + launch + record
+            // (several host threads may launch on one scene: hare_shoot_batch runs up to 12 chunk streams).
+            std::lock_guard<std::mutex> lk(s.oct_scratch_mu);
+            if (s.oct_scratch_bytes < need) {          // first use, or a deeper tree since: (re)allocate the ring
+                for (int k = 0; k < kOctScratchRing; ++k) {
+                    if (s.oct_scratch_ev[k]) (void)H->EventSynchronize(s.oct_scratch_ev[k]);
+                    dev_free(H, s.d_oct_scratch[k]);
                 }
-                ring = s.oct_scratch_next.fetch_add(1) % (unsigned)kOctScratchRing;
-                scratch = (unsigned char*)s.d_oct_scratch[ring];
-                // the launch that used this block last must have finished before this one may start (another stream, maybe)
-                if (s.oct_scratch_next.load() > (unsigned)kOctScratchRing) HIP_TRY(H->StreamWaitEvent(st, s.oct_scratch_ev[ring], 0));
-            }
-            const unsigned slot = s.work_slot.fetch_add(1) % 64u;
-            io.part = nullptr;
-            if (io.ctr) {
-                if (!M.ctr_reduce || !s.d_part) {
-                    set_error("hare_shoot: counter-reduce kernel missing from code object");
-                    return HARE_E_STATE;
+                s.oct_scratch_bytes = 0;
+                for (int k = 0; k < kOctScratchRing; ++k) {
+                    HIP_TRY(H->Malloc(&s.d_oct_scratch[k], need));
+                    if (!s.oct_scratch_ev[k]) HIP_TRY(H->EventCreateWithFlags(&s.oct_scratch_ev[k], hipEventDisableTiming));
                 }
-                io.part = (unsigned long long*)s.d_part + (size_t)slot * kPartWaves * 2;
+                s.oct_scratch_bytes = need;
+                s.oct_scratch_next = 0;
             }
-            io.ticket_rays = 32;
-            if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
-            io.work = (unsigned int*)s.d_work + slot;
-            HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
+            const unsigned seq = s.oct_scratch_next.fetch_add(1);
+            const unsigned ring = seq % (unsigned)kOctScratchRing;
+            unsigned char* scratch = (unsigned char*)s.d_oct_scratch[ring];
+            if (seq >= (unsigned)kOctScratchRing) HIP_TRY(H->StreamWaitEvent(st, s.oct_scratch_ev[ring], 0));
+            io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 32;
             unsigned stride_arg = stride;
             void* qargs[] = {&g, &io, &scratch, &stride_arg};
-            int rc = launch(H, M.octree_pool, pgrid, 64u * (unsigned)kOctPoolWaves, (unsigned)kOctPoolWaves * (unsigned)kOctPoolWaveBytes, st, qargs);
-            if (rc == HARE_OK) {
-                std::lock_guard<std::mutex> lk(s.oct_scratch_mu);
-                HIP_TRY(H->EventRecord(s.oct_scratch_ev[ring], st));
-            }
-            if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * (unsigned)kOctPoolWaves, st);
+            const int rc = launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kOctPoolWaves, (unsigned)kOctPoolWaves * (unsigned)kOctPoolWaveBytes, st, io, qargs);
+            if (rc == HARE_OK) HIP_TRY(H->EventRecord(s.oct_scratch_ev[ring], st));
             return rc;
         }
-        if (!count && !(flags & HARE_SHOOT_SIMPLE_KERNEL) && M.octree_persist && n < 0x7FFFFF00ll && plds <= kLdsMax && g.n_nodes < (1 << 23)) {
+        void* args[] = {&g, &io};
+        if (kc.k == Kern::OctPersist) {
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
-#ifndef HARE_K2P_WAVES_PER_EU
-#define HARE_K2P_WAVES_PER_EU 4
-#endif
+            const unsigned plds = (unsigned)g.max_depth * 256u * 20u;   // 20 bytes x levels x 256 lanes per workgroup (interval + child word)
             unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
-            unsigned pgrid = (unsigned)std::max(1, M.cu_count) * per_cu;
+            unsigned pgrid = cus * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
-            const unsigned slot = s.work_slot.fetch_add(1) % 64u;
-            if (int rc = prepare_partials(s, M, io, pgrid, slot)) return rc;
-            io.ticket_rays = 32;                  // an octree ray costs ~10x a voxel ray: ticket atomics never bind
+            io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 32;   // an octree ray costs ~10x a voxel ray: ticket atomics never bind
             io.static_rays = static_chunk_rays(n, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
-            if (getenv("HARE_K2P_STATIC_RAYS")) io.static_rays = std::max(32, std::min(256, atoi(getenv("HARE_K2P_STATIC_RAYS")) / 32 * 32));   // developer sweeps
-            if (getenv("HARE_TICKET")) io.ticket_rays = std::max(8, std::min(4096, atoi(getenv("HARE_TICKET"))));   // developer sweeps
-            io.work = (unsigned int*)s.d_work + slot;
-            HIP_TRY(H->MemsetAsync(io.work, 0, sizeof(unsigned int), st));
-            if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
-            void* pargs[] = {&g, &io};
-            int rc = launch(H, M.octree_persist, pgrid, 256, plds, st, pargs);
-            if (rc == HARE_OK && io.ctr) rc = reduce_counters(H, M, io, pgrid * 4u, st);
-            return rc;
+            if (s.opt.k2p_static_rays > 0) io.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
+            return launch_on_slot(s, H, kc.f, pgrid, 256, plds, st, io, args);
         }
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
         const unsigned levels = (unsigned)g.max_depth;
         unsigned ob = 256;
         while (ob > 64 && (size_t)levels * ob * 24 > 64 * 1024) ob >>= 1;   // ob = 64: up to 106 levels fit 160 KB
         const unsigned lds = levels * ob * 24;
-        void* args[] = {&g, &io};
-        return launch(H, f, (unsigned)((n + ob - 1) / ob), ob, lds, st, args);
+        return launch(H, kc.f, (unsigned)((n + ob - 1) / ob), ob, lds, st, args);
     }
     if (kind == HARE_KIND_KDTREE) {
         if (!s.kd.built || !s.d_kd_nodes) {
@@ -678,7 +711,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.items = (const int32_t*)s.d_kd_items;
         g.n_nodes = (int32_t)s.kd.nodes.size();
         g.max_depth = s.kd.depth_reached;
-        hipFunction_t f = count ? M.kdtree_count : M.kdtree;
+        hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags).f;
         if (!f) {
             set_error("hare_shoot: kd-tree kernel missing from code object");
             return HARE_E_STATE;
@@ -786,6 +819,7 @@ int hare_scene_create(const hare_topology_desc* topos, int32_t n_topos, int32_t 
     try {
         std::unique_ptr<hare_scene> s(new hare_scene());
         s->device = device;
+        read_env_options(s->opt);          // the only place the environment is read for this scene
         s->topos.resize(n_topos);
         for (int32_t m = 0; m < n_topos; ++m) {
             const hare_topology_desc& d = topos[m];
@@ -833,7 +867,7 @@ void hare_scene_destroy(hare_scene* s)
         if (s->stream) (void)H->StreamSynchronize(s->stream);
         for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
-        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_part})
+        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work})
             dev_free(H, *p);
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
@@ -844,6 +878,8 @@ void hare_scene_destroy(hare_scene* s)
             dev_free(H, s->d_oct_scratch[k]);
             if (s->oct_scratch_ev[k]) (void)H->EventDestroy(s->oct_scratch_ev[k]);
         }
+        for (Scene::LaunchSlot& sl : s->slots)
+            if (sl.ev) { (void)H->EventSynchronize(sl.ev); (void)H->EventDestroy(sl.ev); sl.ev = nullptr; }
         if (s->stream) (void)H->StreamDestroy(s->stream);
     }
     delete s;
@@ -891,8 +927,7 @@ static int sync_partition_to_device(hare_scene* s, int kind)
 static int try_gpu_voxel_build(hare_scene* s, int32_t domain, int32_t max_domain, int32_t avg_polys, bool* on_gpu)
 {
     *on_gpu = false;
-    const char* mode = getenv("HARE_BUILD");
-    if (mode && strcmp(mode, "host") == 0) return HARE_OK;
+    if (s->opt.build_host) return HARE_OK;
     std::string e;
     const HipApi* H = hip_api(&e);
     int n = 0;
@@ -963,9 +998,8 @@ int hare_octree_build(hare_scene* s, int32_t max_depth, int32_t max_polys)
     if (rc) return rc;
     bool on_gpu = false;
     {   // SAT binning on the GPU when there is one (HARE_BUILD=host forces the host builder; identical output)
-        const char* mode = getenv("HARE_BUILD");
         std::string e;
-        const HipApi* H = (mode && strcmp(mode, "host") == 0) ? nullptr : hip_api(&e);
+        const HipApi* H = s->opt.build_host ? nullptr : hip_api(&e);
         int n = 0;
         if (H && H->GetDeviceCount(&n) == hipSuccess && n > 0) {
             rc = ensure_device(*s, H);
@@ -1169,7 +1203,7 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     // host-buffer callers get the reference's meaning of poly_origin: an index that matches no polygon (any negative
     // value) excludes nothing.  Only the device-resident bounce loop (hare_reflect_device + hare_shoot_device) may
     // retire rays, so the retire flag never passes here, nor do developer bits.
-    flags = sanitize_flags(flags) & ~HARE_SHOOT_RETIRED_RAYS;
+    flags = sanitize_flags(*s, flags) & ~HARE_SHOOT_RETIRED_RAYS;
     DeviceGuard dev_guard(hip_api(nullptr), s->device);
     const HipApi* H = nullptr;
     Scene::BatchCtx* c = nullptr;
@@ -1207,7 +1241,7 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     // upload, kernel and download of different chunks overlap (both PCIe directions busy), which measured +24 % on
     // pageable host buffers (402 -> 499 Mrays/s for 1M rays, 426 -> 537 for 4M).  More chunks lose again: small launches are inefficient.
     int K = n >= 196608 ? kMaxChunks : 1;
-    if (const char* e = getenv("HARE_BATCH_CHUNKS")) K = std::max(1, std::min(kMaxChunks, atoi(e)));
+    if (s->opt.batch_chunks > 0) K = std::max(1, std::min(kMaxChunks, s->opt.batch_chunks));     // developer sweeps
     for (int k = 0; k < K; ++k)
         if (!c->st[k]) HIP_TRY(H->StreamCreate(&c->st[k]));
     hare_counters parts[kMaxChunks];
@@ -1300,7 +1334,7 @@ int hare_shoot_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_
         return HARE_E_INVALID;
     }
     GUARD_BEGIN
-    flags = sanitize_flags(flags) & ~HARE_SHOOT_RETIRED_RAYS;
+    flags &= ~HARE_SHOOT_RETIRED_RAYS;      // each shard's hare_shoot_batch masks the rest by its own scene's options
     if (ctr) memset(ctr, 0, sizeof *ctr);
     const int G = n_scenes;
     std::vector<int> rcs((size_t)G, HARE_OK);
@@ -1373,22 +1407,39 @@ int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_ray
 
 const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t top_index, int64_t n, uint32_t flags)
 {
-    if (!s || top_index < 0 || top_index >= (int32_t)s->topos.size()) return "";
-    flags = sanitize_flags(flags);
-    const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0, simple = (flags & HARE_SHOOT_SIMPLE_KERNEL) != 0;
-    const bool quads = s->topos[(size_t)top_index].has_quads;
-    if (kind == HARE_KIND_VOXEL) {
-        if (count) return "hare_voxel_shoot_count";
-        if (simple || n >= 0x7FFFFF00ll) return quads ? "hare_voxel_shoot_quad" : "hare_voxel_shoot_tri";
-        const bool coarse = s->occ_shift > 0;
-        if (voxel_pool_wanted(*s, (size_t)top_index, n) && voxel_pool_usable(*s, flags))
-            return !coarse ? (quads ? "hare_voxel_pool_quad" : "hare_voxel_pool_tri") : (quads ? "hare_voxel_pool_quad_g" : "hare_voxel_pool_tri_g");
-        return !coarse ? (quads ? "hare_voxel_persist_quad" : "hare_voxel_persist_tri") : (quads ? "hare_voxel_persist_quad_g" : "hare_voxel_persist_tri_g");
+    if (!s || top_index < 0 || top_index >= (int32_t)s->topos.size() || kind < HARE_KIND_VOXEL || kind > HARE_KIND_KDTREE) return "";
+    // the launcher's own selection (choose_kernel), fall-backs included
+    return choose_kernel(*s, s->module, kind, (size_t)top_index, n, sanitize_flags(*s, flags)).name;
+}
+
+// Diagnostics / A-B switches of one scene (SceneOptions, scene.h).  Not thread-safe against shoots in flight on the scene.
+int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
+{
+    if (!s || !name) {
+        set_error("hare_scene_set_option: null argument");
+        return HARE_E_INVALID;
     }
-    if (kind == HARE_KIND_OCTREE)
-        return count ? "hare_octree_shoot_count" : ((simple || n >= 0x7FFFFF00ll) ? "hare_octree_shoot" : (octree_pool_wanted(n) ? "hare_octree_pool" : "hare_octree_persist"));
-    if (kind == HARE_KIND_KDTREE) return count ? "hare_kdtree_shoot_count" : "hare_kdtree_shoot";
-    return "";
+    struct { const char* name; int SceneOptions::*field; int64_t lo, hi; } table[] = {
+        {"dev", &SceneOptions::dev, 0, 1},
+        {"build_host", &SceneOptions::build_host, 0, 1},
+        {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
+        {"octree_kernel", &SceneOptions::octree_kernel, 0, 2},
+        {"ticket_rays", &SceneOptions::ticket_rays, 0, 4096},
+        {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 256},
+        {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},
+        {"batch_chunks", &SceneOptions::batch_chunks, 0, 3},
+    };
+    for (auto& t : table)
+        if (strcmp(t.name, name) == 0) {
+            if (value < t.lo || value > t.hi) {
+                set_error(std::string("hare_scene_set_option: value out of range for ") + name);
+                return HARE_E_INVALID;
+            }
+            s->opt.*(t.field) = (int)value;
+            return HARE_OK;
+        }
+    set_error(std::string("hare_scene_set_option: unknown option ") + name);
+    return HARE_E_INVALID;
 }
 
 int hare_occluded_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, void* d_rays, const void* d_excl1,

@@ -159,15 +159,30 @@ constexpr int kOctPoolWaveBytes = kOctPoolSlots * (5 * 8 + 11 * 4) + 4 * kOctPoo
 static_assert(kOctPoolSlots >= 64 && kOctPoolSlots <= 256 && kOctPoolSlots % 2 == 0 && kOctPoolWaveBytes % 8 == 0, "K2q pool geometry");
 constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool kernel that may be in flight (each owns a scratch block)
 
+// Scratch of ONE persistent launch in flight, in device memory (the scene keeps a ring of kLaunchSlots of them):
+//   ticket   next-ray ticket the waves draw from with atomicAdd
+//   done     waves that have finished, counted per blockIdx % 8 (the workgroups that share an XCD), and in done[8] the groups that
+//            have: 8 + 1 addresses instead of one keep the ~4000 end-of-kernel atomics from serialising on one word
+//   acc      {rays, hits} batch counters, sharded 64 ways (wave index % 64); the last wave of the grid sums them into the
+//            caller's counters
+struct LaunchSlotMem {
+    unsigned int ticket;
+    unsigned int done[9];
+    unsigned int pad[6];
+    unsigned long long acc[128];
+};
+static_assert(sizeof(LaunchSlotMem) == 64 + 1024, "launch slot layout (kernels index it by word)");
+constexpr unsigned kLaunchSlots = 64;     // launches of one scene that may be in flight; a 65th waits for the first (api.cpp)
+
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN
     const int32_t* excl1;      // nullable: poly_origin1 per ray
     const int32_t* excl2;      // nullable: poly_origin2 per ray
     XEventRec* out;            // n
     unsigned long long* ctr;   // nullable: CTR_WORDS counters, atomically accumulated
-    unsigned int* work;        // persistent kernels: next-ray ticket (zeroed before launch)
-    unsigned long long* part;  // persistent kernels with ctr: {rays, hits} per wave, plain stores; hare_ctr_reduce adds
-                               // them to ctr afterwards (8192 end-of-kernel atomics on two addresses cost ~45 us)
+    unsigned int* work;        // persistent kernels: this launch's LaunchSlotMem (below) -- word 0 is the next-ray ticket.  The slot
+                               // is all zero when a launch starts and the launch's last wave leaves it all zero again
+                               // (launch_epilogue, kernels.hip): no memset in front of a launch, no reduce kernel behind it
     unsigned long long* prof;  // developer profiling kernel: 17 x u64 phase statistics (else null)
     int64_t n;
     uint32_t flags;

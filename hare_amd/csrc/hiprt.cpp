@@ -71,6 +71,7 @@ void do_bind()
               bind(h, "hipModuleGetFunction", g_api.ModuleGetFunction, e) &&
               bind(h, "hipModuleLaunchKernel", g_api.ModuleLaunchKernel, e) &&
               bind(h, "hipGetErrorString", g_api.GetErrorString, e) && bind(h, "hipGetLastError", g_api.GetLastError, e) && bind(h, "hipEventCreate", g_api.EventCreate, e) &&
+              bind(h, "hipEventCreateWithFlags", g_api.EventCreateWithFlags, e) && bind(h, "hipMemset", g_api.Memset, e) &&
               bind(h, "hipEventDestroy", g_api.EventDestroy, e) && bind(h, "hipEventRecord", g_api.EventRecord, e) &&
               bind(h, "hipEventSynchronize", g_api.EventSynchronize, e) && bind(h, "hipStreamWaitEvent", g_api.StreamWaitEvent, e) &&
               bind(h, "hipEventElapsedTime", g_api.EventElapsedTime, e) && bind(h, "hipHostMalloc", g_api.HostMalloc, e) &&

@@ -34,6 +34,8 @@ struct HipApi {
     const char* (*GetErrorString)(hipError_t);
     hipError_t (*GetLastError)(void);
     hipError_t (*EventCreate)(hipEvent_t*);
+    hipError_t (*EventCreateWithFlags)(hipEvent_t*, unsigned int);
+    hipError_t (*Memset)(void*, int, size_t);
     hipError_t (*EventDestroy)(hipEvent_t);
     hipError_t (*EventRecord)(hipEvent_t, hipStream_t);
     hipError_t (*EventSynchronize)(hipEvent_t);

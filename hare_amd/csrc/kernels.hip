@@ -12,7 +12,6 @@
 //   hare_octree_persist    K2p  production Octree.Shoot; hare_octree_shoot* K2 simple/counting form
 //   hare_kdtree_shoot*          KDTree.Shoot (visits every leaf, like the reference)
 //   hare_reflect           K3   specular bounce between casts (harness-defined)
-//   hare_ctr_reduce             sums the persistent kernels' per-wave {rays, hits} partials into the batch counters
 //   hare_cull_audit             tests only: FP32 cull vs exact test on every ray x polygon pair
 //   hare_vb_*, hare_scan_*, hare_ob_*  Voxel_Grid / Octree construction (build_kernels.hip, included at the end)
 //
@@ -57,6 +56,70 @@ __device__ __forceinline__ unsigned long long wave_sum_u32(unsigned int v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     return s;  // valid in lane 0
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long s)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    return s;  // valid in lane 0
+}
+
+// End of a persistent launch, called by EVERY wave of the grid once it has no ray left (K1p, K1q, K2p, K2q).
+// Replaces what used to surround each launch on the stream -- a memset of the ticket word in front, a reduce kernel over
+// per-wave partials behind (2-3 % of a 0.49 ms launch) -- by work of the launch's own waves on its LaunchSlotMem (io.work):
+//   1. the wave adds its {rays, hits} to one of 64 accumulator shards (RETURNING agent-scope atomics: when they have
+//      returned, they have been performed at the memory side, whatever XCD the wave runs on);
+//   2. it counts itself done in the counter of its blockIdx % 8 group; the group's last wave counts the group done; every
+//      wave passes through here exactly once, so exactly one wave of the grid sees both counts complete;
+//   3. that wave fetches-and-zeroes the shards (atomic exchanges: memory side again, so it sees every add of step 1, each of
+//      which returned before its wave's done-count was issued), adds the sums to the caller's counters, and zeroes the done
+//      counters and the ticket word: the slot is all zero again for the launch that uses it next (the host orders launches
+//      on one slot, api.cpp).  No fence is needed anywhere: every word of the slot is only ever touched by atomics.
+// Cost: three dependent atomics per wave, off the ray path; ~4,000 done-counts spread over 8 + 1 addresses.
+__device__ __forceinline__ void launch_epilogue(const ShootIO& io, unsigned int nrays, unsigned int nhits, unsigned int waves_per_block)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned int* const done = io.work + 1;                                                   // LaunchSlotMem::done
+    unsigned long long* const acc = reinterpret_cast<unsigned long long*>(io.work + 16);    // LaunchSlotMem::acc
+    const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);               // valid in lane 0
+    int last = 0;
+    if (lane == 0) {
+        if (io.ctr) {
+            const unsigned shard = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) & 63u;
+            unsigned long long a = atomicAdd(&acc[2u * shard], r);
+            unsigned long long b = atomicAdd(&acc[2u * shard + 1u], h);
+            asm volatile("" ::"v"(a), "v"(b));          // the old values are "used": returning atomics, waited for ...
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... before the done-count below is issued
+        }
+        const unsigned xc = blockIdx.x & 7u;
+        const unsigned in_group = ((gridDim.x - xc + 7u) >> 3) * waves_per_block;            // waves of the blocks b with b % 8 == xc
+        if (atomicAdd(&done[xc], 1u) == in_group - 1u) {
+            atomicExch(&done[xc], 0u);
+            const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+            if (atomicAdd(&done[8], 1u) == groups - 1u) {
+                atomicExch(&done[8], 0u);
+                last = 1;
+            }
+        }
+    }
+    last = __shfl(last, 0, 64);
+    if (last) {
+        unsigned long long vr = 0, vh = 0;
+        if (io.ctr) {
+            vr = atomicExch(&acc[2u * lane], 0ull);
+            vh = atomicExch(&acc[2u * lane + 1u], 0ull);
+        }
+        vr = wave_sum_u64(vr);
+        vh = wave_sum_u64(vh);
+        if (lane == 0) {
+            if (io.ctr) {
+                atomicAdd(&io.ctr[CTR_RAYS], vr);
+                atomicAdd(&io.ctr[CTR_HITS], vh);
+            }
+            atomicExch(io.work, 0u);                    // the ticket word: every wave has long stopped drawing
+        }
+    }
 }
 
 // Per-wave accumulation of the batch counters: one atomic per counter per wave.
@@ -505,15 +568,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     }
 
     timeline(2);
-    // batch counters: per-wave partials, summed by hare_ctr_reduce
-    if (io.ctr) {
-        const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
-        if (lane == 0) {
-            unsigned long long* slot = io.part + 2ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-            slot[0] = r;
-            slot[1] = h;
-        }
-    }
+    launch_epilogue(io, nrays, nhits, 4u);     // batch counters + the launch slot left zeroed (4 waves per workgroup)
 }
 
 // Filter audit (tests only): for every candidate the reference algorithm would test, run BOTH the FP32
@@ -927,14 +982,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     }
 
     timeline(2);
-    if (io.ctr) {
-        const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
-        if (lane == 0) {
-            unsigned long long* slot = io.part + 2ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-            slot[0] = r;
-            slot[1] = h;
-        }
-    }
+    launch_epilogue(io, nrays, nhits, 4u);
 }
 
 
@@ -1008,29 +1056,6 @@ __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persis
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }
 __global__ __launch_bounds__(256) void hare_kdtree_shoot_count(KdArgs g, ShootIO io) { kdtree_shoot_body<true>(g, io); }
-
-// Batch counters of the persistent kernels: sum the per-wave {rays, hits} partials into ctr (one launch
-// of one workgroup after the shoot kernel, same stream).
-__global__ __launch_bounds__(256) void hare_ctr_reduce(const unsigned long long* part, int waves, unsigned long long* ctr)
-{
-    __shared__ unsigned long long sr[4], sh[4];
-    unsigned long long r = 0, h = 0;
-    for (int k = threadIdx.x; k < waves; k += blockDim.x) {
-        r += part[2 * k];
-        h += part[2 * k + 1];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off, 64);
-        h += __shfl_down(h, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) { sr[threadIdx.x >> 6] = r; sh[threadIdx.x >> 6] = h; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&ctr[CTR_RAYS], sr[0] + sr[1] + sr[2] + sr[3]);
-        atomicAdd(&ctr[CTR_HITS], sh[0] + sh[1] + sh[2] + sh[3]);
-    }
-}
 
 // K3: specular bounce (harness-defined): o' = X_Point, d' = d - (2*(d.n))*n,
 // next exclusion = the polygon just hit; rays that missed are marked dead (-2).

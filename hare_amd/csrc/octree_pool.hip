@@ -456,14 +456,7 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
         }
     }
 
-    if (io.ctr) {
-        const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
-        if (lane == 0) {
-            unsigned long long* sl = io.part + 2ull * (blockIdx.x * (unsigned)kOctPoolWaves + (unsigned)wave);
-            sl[0] = r;
-            sl[1] = h;
-        }
-    }
+    launch_epilogue(io, nrays, nhits, (unsigned)kOctPoolWaves);     // batch counters + the launch slot left zeroed
 }
 
 }  // namespace

@@ -26,8 +26,21 @@ inline void occ_layout(int ct, int32_t& shift, int32_t& cd, int32_t& words)
     }
 }
 
-constexpr unsigned kPartSlots = 64;       // ring of launches whose counter partials may be in flight (same depth as the ticket ring)
-constexpr unsigned kPartWaves = 8192;     // >= waves of one persistent launch (CUs x 4 workgroups x 4 waves)
+// Diagnostics and A/B switches of one scene.  Filled ONCE, at hare_scene_create, from the environment (HARE_BUILD always; the
+// developer variables HARE_VOXEL_KERNEL, HARE_OCTREE_KERNEL, HARE_TICKET, HARE_TUNE, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
+// HARE_BATCH_CHUNKS only when HARE_DEV=1), changed afterwards only through hare_scene_set_option: no getenv on any launch path,
+// so a host that calls setenv from another thread cannot race with a shoot, and a stray variable cannot change kernel choice.
+struct SceneOptions {
+    int dev = 0;               // HARE_DEV=1: developer flag bits (timeline, phase profile, cull audit) pass sanitize_flags
+    int build_host = 0;        // HARE_BUILD=host: host builders even when a GPU is present (identical output)
+    int voxel_kernel = 0;      // 0 = the library's rule, 1 = K1p (persist), 2 = K1q (pool)
+    int octree_kernel = 0;     // 0 = the library's rule (K2p), 1 = K2p (persist), 2 = K2q (pool)
+    int ticket_rays = 0;       // rays per ticket of the persistent kernels (0 = the host's rule)
+    int k1p_static_rays = 0;   // static first chunk per wave (0 = the host's rule)
+    int k2p_static_rays = 0;
+    int batch_chunks = 0;      // chunks hare_shoot_batch pipelines a batch over (0 = the host's rule)
+    int tune[5] = {0, 0, 0, 0, 0};   // HARE_TUNE: steps,refill,chunk,blocks_per_cu,exact (profiling build; blocks_per_cu: K1p)
+};
 
 struct Topo {
     int32_t P = 0;
@@ -74,7 +87,7 @@ struct DeviceModule {
     hipFunction_t voxel_pool_tri = nullptr, voxel_pool_quad = nullptr, voxel_pool_tri_g = nullptr, voxel_pool_quad_g = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
-    hipFunction_t reflect = nullptr, ctr_reduce = nullptr, occlusion = nullptr;
+    hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
     hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
@@ -129,9 +142,18 @@ struct Scene {
     void* d_oct_items = nullptr;
     void* d_kd_nodes = nullptr;
     void* d_kd_items = nullptr;
-    void* d_work = nullptr;                      // ticket counters for persistent kernels (64 x u32)
+    void* d_work = nullptr;                      // LaunchSlotMem[kLaunchSlots]: scratch of the persistent launches in flight
     std::atomic<unsigned> work_slot{0};
-    void* d_part = nullptr;                      // per-wave {rays, hits} partials: kPartSlots launches x kPartWaves waves
+    // host side of the launch-slot ring: a slot is re-used by every kLaunchSlots-th launch, which must not start before the
+    // launch that used it last has finished (they may be on different streams): each launch records an event behind itself
+    // and waits for the slot's previous one; `mu` keeps wait + launch + record of one slot together
+    struct LaunchSlot {
+        std::mutex mu;
+        hipEvent_t ev = nullptr;
+        bool used = false;
+    };
+    LaunchSlot slots[kLaunchSlots];
+    SceneOptions opt;
 
     // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
     // over), so that host threads calling on one scene run side by side instead of queueing on one mutex; `mu` guards

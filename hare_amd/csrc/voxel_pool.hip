@@ -23,6 +23,11 @@
 // The ray's own X_Event slot is its scratch until it finishes: .t = tmin of the hit so far (DBL_MAX: none),
 // .x .y .z = that hit's point, the {Hit, Poly_id} word = its polygon, .u = t_start of a ray whose origin
 // AABB.Intersect moved (the moved origin itself is o + d * t_start, the expression of AABB_Main.cs:254-256).
+// INVARIANT: that scratch (and, with origin write-back, the ray record) is written by one lane of the wave with plain stores
+// and read in a later phase by whichever lane pops the ray.  All of a wave's accesses go through its CU's one L1 in program
+// order, so the value is there; what states the ordering to the compiler is the wavefront-scope fence in front of every
+// phase (no instruction in hardware).  It holds only while no OTHER wave touches those bytes: the host refuses calls whose
+// rays / events / exclusion buffers overlap (api.cpp).
 #ifndef HARE_K1Q_WALK_STEPS
 #define HARE_K1Q_WALK_STEPS 16    // DDA steps per walk task at most
 #endif
@@ -176,6 +181,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     unsigned long long stat_lanes = 0, stat_distinct = 0, stat_batches = 0;
     // a wave serves ~n / (waves in the grid) rays in a few rounds each; the cap only exists so that a defect can never
     // turn into a wave that does not finish (rays it left behind would keep their scratch values and fail every parity test)
+#define HARE_K1Q_PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
     for (unsigned round = 0; round < (1u << 24); ++round) {
         // ------------------------------------------------------------------ set-up of new rays into free slots
         if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP == 0)) {
@@ -285,6 +291,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         const bool tail = drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_TAIL;
         const int sel = (nE >= (unsigned)HARE_K1Q_EXACT_MIN || (big == 0 && nP == 0)) ? 0
                         : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
+        HARE_K1Q_PHASE_FENCE();      // the set-up's scratch stores, before any phase reads them
         if (tail ? nW > 0 : sel == 3) {
             // -------------------------------------------------------------- DDA walk over empty voxels (no hit pending)
             bool act;
@@ -336,6 +343,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_free, hF, nF, exited, slot);
         }
+        HARE_K1Q_PHASE_FENCE();
         if (tail ? nC > 0 : sel == 2) {
             // -------------------------------------------------------------- FP32 pre-cull, 2 x CULL_PAIRS candidates per ray at most
             bool act;
@@ -440,6 +448,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_exact, hE, nE, to_exact, slot);
             push(Q_pend, hP, nP, to_pend, slot);
         }
+        HARE_K1Q_PHASE_FENCE();
         if (tail ? nE > 0 : sel == 0) {
             // -------------------------------------------------------------- exact FP64 test of one candidate per ray
             bool act;
@@ -507,6 +516,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_pend, hP, nP, to_pend, slot);
         }
+        HARE_K1Q_PHASE_FENCE();      // the exact phase's hit record, before the pending-hit walk reads it
         if (tail ? nP > 0 : sel == 1) {
             // -------------------------------------------------------------- walk with a pending hit (Voxel_Grid.cs:705-759)
             bool act;
@@ -583,6 +593,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         }
     }
 #undef HARE_K1Q_STEP
+#undef HARE_K1Q_PHASE_FENCE
     timeline(2, __builtin_amdgcn_s_memrealtime());
     timeline(3, rounds_done);
     if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
@@ -593,15 +604,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         }
     }
 
-    // batch counters: per-wave partials, summed by hare_ctr_reduce
-    if (io.ctr) {
-        const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);
-        if (lane == 0) {
-            unsigned long long* sl = io.part + 2ull * (blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave);
-            sl[0] = r;
-            sl[1] = h;
-        }
-    }
+    launch_epilogue(io, nrays, nhits, (unsigned)kPoolWaves);     // batch counters + the launch slot left zeroed
 }
 
 }  // namespace

@@ -164,6 +164,11 @@ class Spatial_Partition:
         self._h = h
         self.device = int(device)
 
+    def set_option(self, name: str, value: int):
+        """Diagnostics / A-B switch of this scene (hare_scene_set_option): e.g. ("voxel_kernel", 2) forces the pool kernel."""
+        check(lib.hare_scene_set_option(self._h, name.encode(), int(value)))
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
             lib.hare_scene_destroy(self._h)

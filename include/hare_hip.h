@@ -141,9 +141,21 @@ HARE_API int hare_topology_ingest(const double *soup, const int32_t *nverts, int
 HARE_API int hare_scene_create(const hare_topology_desc *topos, int32_t n_topos, int32_t device, hare_scene **out);
 HARE_API void hare_scene_destroy(hare_scene *s);
 
+/* Diagnostics and A/B switches of ONE scene, for tests, profiling and tools; production callers never need them.  A scene takes
+ * its defaults from the environment ONCE, inside hare_scene_create (HARE_BUILD=host; and, only in a process that opted in with
+ * HARE_DEV=1, HARE_VOXEL_KERNEL / HARE_OCTREE_KERNEL = pool|persist, HARE_TICKET, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
+ * HARE_BATCH_CHUNKS, HARE_TUNE): no call reads the environment afterwards.  Options:
+ *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
+ *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
+ *   "octree_kernel"   0: the library's rule, 1: hare_octree_persist (K2p), 2: hare_octree_pool (K2q)
+ *   "ticket_rays", "k1p_static_rays", "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
+ *   "dev"             1: developer flag bits of hare_shoot_* (timeline, phase profile, cull audit) pass
+ * Single-caller like the build calls: not to be changed while shoots are in flight on the scene. */
+HARE_API int hare_scene_set_option(hare_scene *s, const char *name, int64_t value);
+
 /* ---- partition constructors ----
  * The voxel grid and the octree (of a single topology) are built on the GPU when one is present (environment
- * HARE_BUILD=host forces the host builders); both builders produce identical lists.  The KDTree is built on the host.
+ * HARE_BUILD=host when the scene is created, or option "build_host", forces the host builders); both builders produce identical lists.  The KDTree is built on the host.
  * Voxel_Grid(Topology[] Model_in, int Domain)                      Voxel_Grid.cs:48-121  */
 HARE_API int hare_voxel_build(hare_scene *s, int32_t domain);
 /* Voxel_Grid(Topology[] Model_in, int MaxDomain, int Avg_polys)    Voxel_Grid.cs:128-254 */
@@ -215,8 +227,9 @@ HARE_API int hare_shoot_batch_sharded(hare_scene *const *scenes, int32_t n_scene
 /* Same with DEVICE pointers on the scene's device and a caller stream (hipStream_t as void*,
  * NULL = default stream); stream-ordered, does not synchronise.  d_counters (nullable) points to
  * a device hare_counters that the kernel ACCUMULATES into.  Calls may be issued from several host
- * threads and on several streams; the scene keeps per-launch scratch (work tickets, counter partials) in a
- * ring of 64 launches, so at most 64 launches of one scene may be in flight at a time. */
+ * threads and on several streams; the scene keeps per-launch scratch (work tickets, counter shards) in a ring of
+ * 64 slots: the 65th launch in flight is ordered behind the first (it waits for an event that launch recorded), so any
+ * number of launches may be queued.  rays, the exclusion arrays, events and counters must not overlap (HARE_E_INVALID). */
 HARE_API int hare_shoot_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
                       const void *d_excl1, const void *d_excl2, uint32_t flags, void *d_out,
                       void *d_counters, void *stream);

@@ -44,6 +44,34 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert j["roofline"]["kernel"] == "hare_voxel_persist_tri" and j["roofline"]["frac"] > 0
 
 
+def test_bench_rccl_branch_on_one_gpu_with_a_process_group_of_one():
+    """The driver's 8-GPU run is the first time ranks > 1 meet RCCL; its code path -- init_process_group(nccl, device_id), the
+    first all-reduce, the per-step async all-reduce with the two-slot hand-off, the all-gather of CUDA tensors, barrier and
+    destroy -- runs here with a process group of one and must give the line the plain run gives."""
+    n = 65536
+    a = _bench("--rays", str(n), "--steps", "4", "--warmup", "2")
+    b = _bench("--rays", str(n), "--steps", "4", "--warmup", "2", "--force-dist", "--backend", "nccl")
+    assert a["config"]["backend"] == "none" and b["config"]["backend"] == "rccl"
+    assert b["n_gpus"] == 1 and (b["hits"], b["rays"]) == (a["hits"], a["rays"]) and b["rays"] == n
+    assert a["x_event_parity_vs_oracle"] is True and b["x_event_parity_vs_oracle"] is True
+    assert b["cpu_baseline"]["value"] > 0 and b["roofline"]["frac"] > 0
+    assert b["ms_per_step_per_rank"]["max"] == b["ms_per_step_per_rank"]["min"] > 0
+
+
+def test_bench_appends_configs_3_4_5_to_the_one_line():
+    """The driver's N = 1 command measures the headline and then configs 3, 4 (shard) and 5 in the same process (here at
+    small sizes): each carries value, roofline, cpu_baseline and the parity flag."""
+    j = _bench("--rays", "32768", "--steps", "2", "--warmup", "1", "--extra-configs", "--extra-rays", "32768")
+    assert set(j["configs"]) == {"c3", "c4_shard", "c5"}
+    want = {"c3": "hare_octree_persist", "c4_shard": "hare_voxel_persist_tri_g", "c5": "hare_voxel_persist_tri_g"}
+    for name, sub in j["configs"].items():
+        assert sub["x_event_parity_vs_oracle"] is True, name
+        assert sub["value"] > 0 and sub["roofline"]["frac"] > 0 and sub["roofline"]["kernel"] == want[name]
+        assert sub["cpu_baseline"]["kind"] == "port" and sub["cpu_baseline"]["value"] > 0
+    assert j["configs"]["c5"]["roofline"]["live_casts_per_pass"] > 32768 * 7
+    assert j["metric"].startswith("Mrays/s") and j["x_event_parity_vs_oracle"] is True     # the headline fields are untouched
+
+
 @pytest.mark.parametrize("extra,kernel", [
     ((), "hare_voxel_persist_tri"),
     (("--kind", "octree"), "hare_octree_persist"),

@@ -236,6 +236,7 @@ def test_bounce_c5_full_size_1M_rays_x8_1M_tris():
 # batch size.  HARE_VOXEL_KERNEL forces one, so every case below runs on BOTH regardless of where the crossover sits.
 @pytest.mark.parametrize("kernel", ["pool", "persist"])
 def test_both_voxel_kernels_full_size_and_large_batches(hall, kernel, monkeypatch):
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
     m, T, To = hall
     g = H.Voxel_Grid([T], 64)
@@ -251,6 +252,7 @@ def test_both_voxel_kernels_full_size_and_large_batches(hall, kernel, monkeypatc
 
 @pytest.mark.parametrize("kernel", ["pool", "persist"])
 def test_both_voxel_kernels_quads_exclusions_outside_origins_and_writeback(kernel, monkeypatch):
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
     v, nv, size = soup()
     rays = soup_rays(30000, size)
@@ -274,6 +276,7 @@ def test_both_voxel_kernels_quads_exclusions_outside_origins_and_writeback(kerne
 def test_both_voxel_kernels_over_grid_sizes(hall, kernel, domain, monkeypatch):
     """1 bit per voxel up to 80^3, per 2^3 block up to 160^3, per 4^3 above; K1q needs the bitmap to leave room for its
     pools (<= 32 KB), so 65..80 stay with K1p whatever is asked for -- the name tells."""
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
     m, T, To = hall
     n = 150_000
@@ -289,6 +292,7 @@ def test_both_voxel_kernels_over_grid_sizes(hall, kernel, domain, monkeypatch):
 @pytest.mark.parametrize("kernel", ["pool", "persist"])
 def test_both_voxel_kernels_degenerate_rays_and_two_topologies(kernel, monkeypatch):
     from tests.test_gpu_parity import bits_equal, degenerate_rays
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
     m = H.scenes.shoebox()
     T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
@@ -316,6 +320,7 @@ def test_both_voxel_kernels_degenerate_rays_and_two_topologies(kernel, monkeypat
 @pytest.mark.parametrize("kernel", ["pool", "persist"])
 def test_both_voxel_kernels_bounce_loop_with_retired_rays(hall, kernel, monkeypatch):
     import torch
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
     m, T, To = hall
     n, bounces = 200_000, 5
@@ -357,6 +362,7 @@ def test_both_octree_kernels(hall, kernel, monkeypatch):
     quadrilaterals and exclusions, a 20-level tree, degenerate rays, and more launches in flight than K2q has scratch blocks."""
     import torch
     from tests.test_gpu_parity import bits_equal, degenerate_rays
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_OCTREE_KERNEL", kernel)
     m, T, To = hall
     n = 300_000
@@ -396,14 +402,22 @@ def test_both_octree_kernels(hall, kernel, monkeypatch):
         assert outs[k].cpu().numpy().tobytes() == ref.tobytes(), f"launch {k}"
 
 
-def test_concurrent_batch_callers_on_one_scene(hall):
+@pytest.mark.parametrize("what", ["voxel", "octree_pool", "octree_persist"])
+def test_concurrent_batch_callers_on_one_scene(hall, what):
     """Pachyderm shoots from many worker threads at once: six host threads call Shoot_batch on ONE scene at the same time
-    (four staging contexts: two of them wait their turn), different ray sets and sizes, voxel and octree; every result
-    equals the oracle's and the counters add up."""
+    (four staging contexts: two of them wait their turn; up to 12 chunk streams launch side by side), different ray sets and
+    sizes; every result equals the oracle's and the counters add up.  The octree pool kernel (K2q) keeps per-launch scratch
+    blocks in a ring of four guarded by events: wait + launch + record of a block must stay together under its lock."""
     import threading
     m, T, To = hall
-    g, o = H.Voxel_Grid([T], 64), po.VoxelGrid([To], domain=64)
-    sizes = [300_000, 70_000, 1_000, 250_000, 33, 120_000]
+    if what == "voxel":
+        g, o = H.Voxel_Grid([T], 64), po.VoxelGrid([To], domain=64)
+        sizes = [300_000, 70_000, 1_000, 250_000, 33, 120_000]
+    else:
+        g, o = H.Octree([T], 8, 16), po.Octree([To], 8, 16)
+        g.set_option("octree_kernel", 2 if what == "octree_pool" else 1)
+        sizes = [200_000, 70_000, 1_000, 66_000, 33, 100_000]          # three chunks from 196 608 rays: several launches per call
+        assert g.kernel_name(sizes[0]) == ("hare_octree_pool" if what == "octree_pool" else "hare_octree_persist")
     burst = H.scenes.burst_rays(1 << 22, m.size)
     sets = [burst[k::7][:n].copy() for k, n in enumerate(sizes)]
     assert [len(r) for r in sets] == sizes
@@ -433,5 +447,11 @@ def test_the_picker_follows_its_rule(hall):
     _, T, _ = hall
     g = H.Voxel_Grid([T], 64)
     want = {64: "persist", 65536: "persist", 393216: "persist", 1 << 20: "persist", 1179647: "persist", 1179648: "pool", 1 << 24: "pool"}
-    for n, k in want.items():
+    for n, k in want.items():      # 256 CUs x 12 waves x 128 rays = 393 216 rays fill every pool of the chip once; three fills = 1 179 648
         assert g.kernel_name(n) == f"hare_voxel_{k}_tri", (n, g.kernel_name(n))
+    g.set_option("voxel_kernel", 2)                      # the per-scene switch the A/B tests and tools use
+    assert g.kernel_name(64) == "hare_voxel_pool_tri"
+    g.set_option("voxel_kernel", 1)
+    assert g.kernel_name(1 << 24) == "hare_voxel_persist_tri"
+    with pytest.raises(H.HareError):
+        g.set_option("no_such_option", 1)

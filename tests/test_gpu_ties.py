@@ -77,6 +77,7 @@ def ties():
 @pytest.mark.parametrize("kernel", ["persist", "pool"])
 @pytest.mark.parametrize("domain", [1, 8, 21])
 def test_voxel_exact_ties(ties, kernel, domain, monkeypatch):
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_VOXEL_KERNEL", kernel)
     v, nv, size, rays = ties
     T, To = H.Topology(v, nv), po.Topology(v, nv)
@@ -95,6 +96,7 @@ def test_voxel_exact_ties(ties, kernel, domain, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["persist", "pool"])
 def test_tree_exact_ties(ties, kernel, monkeypatch):
+    monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_OCTREE_KERNEL", kernel)
     v, nv, size, rays = ties
     T, To = H.Topology(v, nv), po.Topology(v, nv)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export HARE_DEV=1   # developer overrides (HARE_VOXEL_KERNEL, HARE_TICKET, ...) are only read in a process that opted in
 # Developer A/B of the two voxel kernels through bench.py (parity against the oracle included): C2, C4 shard, C5
 for k in persist pool; do
   for cfg in "--steps 20 --warmup 3" "--rays 2097152 --steps 10 --warmup 2" "--rays 4194304 --steps 6 --warmup 2" "--scene cathedral --domain 128 --rays 2097152 --steps 8 --warmup 2" "--scene cathedral --domain 128 --bounces 8 --steps 4 --warmup 1"; do

@@ -51,7 +51,7 @@ print(" | ".join(msgs))
 ''' % here
 for spec in sys.argv[1:]:
     kern, lib = spec.split(":", 1)
-    env = dict(os.environ, HARE_VOXEL_KERNEL=kern)
+    env = dict(os.environ, HARE_DEV="1", HARE_VOXEL_KERNEL=kern)
     if lib != "default": env["HARE_LIB"] = os.path.abspath(lib)
     try:
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=float(os.environ.get("AB_TIMEOUT", 150)))

@@ -1,4 +1,5 @@
 # developer: is the bounce loop (C5) bound by where the polygon records live?  Same 8-bounce loop on a scene whose records are
+export HARE_DEV=1   # developer overrides (HARE_VOXEL_KERNEL, HARE_TICKET, ...) are only read in a process that opted in
 # L2 / Infinity-Cache resident (hall, 12.9 MB) and on the cathedral (126 MB); bench.py computes B/cast from the oracle on the
 # same rays, so the two `roofline.frac` values compare per algorithmic byte.  One step after another; nothing is retried.
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 # developer A/B on a coarse-bitmap grid (cathedral, D = 128): default build vs hare_amd/libhare_hip_$1.so, same session.
+export HARE_DEV=1   # developer overrides (HARE_VOXEL_KERNEL, HARE_TICKET, ...) are only read in a process that opted in
 # Parity first (burst, soup, every bounce cast against the oracle), then times.  Each leg has its own limit; nothing runs after
 # a leg that failed or timed out.
 V=${1:?variant name}

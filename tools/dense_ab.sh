@@ -1,4 +1,5 @@
 # developer A/B: pre-cull records gathered from the dense 48-byte copy (-DHARE_CULL_DENSE=1, hare_amd/libhare_hip_dense.so)
+export HARE_DEV=1   # developer overrides (HARE_VOXEL_KERNEL, HARE_TICKET, ...) are only read in a process that opted in
 # against the heads of the 128-byte records (default build), same session.  Parity lines first, then times.  Every leg has
 # its own time limit; nothing runs after a leg that failed or timed out.
 R=$GRAFT_REPO_ROOT

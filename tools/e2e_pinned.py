@@ -34,9 +34,9 @@ for n in (1 << 20, 1 << 22):
     print("n=%d: pageable %.3f ms (%.0f Mrays/s) | registered %.3f ms (%.0f Mrays/s), registering both buffers took %.1f ms | events equal: %s | hits %d"
           % (n, t_page * 1e3, n / t_page / 1e6, t_pin * 1e3, n / t_pin / 1e6, t_reg * 1e3, crc_page == crc_pin, ctr.hits))
     for chunks in (1, 2, 3):
-        os.environ["HARE_BATCH_CHUNKS"] = str(chunks)
+        g.set_option("batch_chunks", chunks)
         assert int(rt.cudaHostRegister(rays.ctypes.data, rays.nbytes, 0)) == 0 and int(rt.cudaHostRegister(ev.ctypes.data, ev.nbytes, 0)) == 0
         run(1); t = run()
         rt.cudaHostUnregister(rays.ctypes.data); rt.cudaHostUnregister(ev.ctypes.data)
         print("   registered, %d chunk(s): %.3f ms (%.0f Mrays/s)" % (chunks, t * 1e3, n / t / 1e6))
-    del os.environ["HARE_BATCH_CHUNKS"]
+    g.set_option("batch_chunks", 0)

@@ -39,7 +39,7 @@ def main():
         ref, _ = o.shoot(rays); refx, _ = o.shoot(rays, excl1=e1, excl2=e2)
         moved = rays.copy(); refm, _, movedref = o.shoot(rays, mutate=True)
         for kern in ("persist", "pool"):
-            os.environ["HARE_VOXEL_KERNEL"] = kern
+            g.set_option("voxel_kernel", {"persist": 1, "pool": 2}[kern])
             cfg = "seed %d voxel D=%d n=%d kernel=%s (%s)" % (seed, D, n, kern, g.kernel_name(n))
             for what, got, want in (("plain", g.Shoot_batch(rays)[0], ref), ("excl", g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], refx)):
                 bad = same(got, want); checks += 1
@@ -47,7 +47,7 @@ def main():
             r = rays.copy(); got, _ = g.Shoot_batch(r, writeback_origin=True); checks += 1
             bad = same(got, refm) or (None if np.array_equal(r.view(np.int64), movedref.view(np.int64)) else "moved origins differ")
             if bad: print("MISMATCH", cfg, "writeback", bad); return 1
-        os.environ.pop("HARE_VOXEL_KERNEL", None)
+        g.set_option("voxel_kernel", 0)
         depth, maxp = int(rng.integers(0, 9)), int(rng.integers(1, 40))
         # the reference pads child boxes by an ABSOLUTE 0.1 m ("Octree - alt.cs":99-111): below ~0.4 m a node's
         # polygons land in all eight children and the tree grows 8x per level in ANY implementation -- keep nodes above 1 m
@@ -56,12 +56,12 @@ def main():
         oc, oo = H.Octree([T], depth, maxp), po.Octree([To], depth, maxp)
         oref, _ = oo.shoot(rays); orefx, _ = oo.shoot(rays, excl1=e1, excl2=e2)
         for kern in ("persist", "pool"):
-            os.environ["HARE_OCTREE_KERNEL"] = kern
+            oc.set_option("octree_kernel", {"persist": 1, "pool": 2}[kern])
             cfg = "seed %d octree %d/%d n=%d kernel=%s" % (seed, depth, maxp, n, kern)
             for what, got, want in (("plain", oc.Shoot_batch(rays)[0], oref), ("excl", oc.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], orefx)):
                 bad = same(got, want); checks += 1
                 if bad: print("MISMATCH", cfg, what, bad); return 1
-        os.environ.pop("HARE_OCTREE_KERNEL", None)
+        oc.set_option("octree_kernel", 0)
         if seed % 5 == 0 and n >= 1000:
             # the device-resident bounce loop on this scene (open soups: many rays leave and are retired), both voxel kernels,
             # and the occlusion predicate on the first cast
@@ -69,7 +69,7 @@ def main():
             from hare_amd import capi
             st = torch.cuda.current_stream().cuda_stream
             for kern in ("persist", "pool"):
-                os.environ["HARE_VOXEL_KERNEL"] = kern
+                g.set_option("voxel_kernel", {"persist": 1, "pool": 2}[kern])
                 d_rays = torch.from_numpy(rays.copy()).cuda(); d_ev = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
                 d_ex = torch.full((n,), -1, dtype=torch.int32, device="cuda")
                 cur, excl, dead = rays.copy(), np.full(n, -1, np.int32), np.zeros(n, bool)
@@ -87,7 +87,7 @@ def main():
                     cur = po.reflect_batch(To, cur, want)
                     excl = np.where(alive_, want["poly_id"], -2).astype(np.int32)
                     dead |= ~alive_
-            os.environ.pop("HARE_VOXEL_KERNEL", None)
+            g.set_option("voxel_kernel", 0)
             tmax = np.abs(rng.normal(0, 1, n)) * float(np.nanmedian(ref["t"][ref["hit"] == 1])) if (ref["hit"] == 1).any() else np.ones(n)
             occ = g.Occluded_batch(rays, t_max=tmax)[0]
             want_occ = (ref["hit"] == 1) & (ref["t"] < tmax); checks += 1

@@ -1,4 +1,5 @@
 # developer sweep over K1q builds: tools/k1q_variants.sh name1 name2 ...  (hare_amd/libhare_hip_<name>.so, tools/build_variants.sh)
+export HARE_DEV=1   # developer overrides (HARE_VOXEL_KERNEL, HARE_TICKET, ...) are only read in a process that opted in
 # hall D=64 (1M, 4M rays) and cathedral D=128 (1M, 2M rays) through tools/ab_pool.py (parity + kernel time), then the 8-bounce
 # loop in the cathedral (parity per bounce + per-cast times).  Nothing runs after a leg that failed or timed out.
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 # Developer profile: is the vector-memory front end (TA address processing / TCP tag lookups) what bounds the traversal kernels?
+export HARE_DEV=1   # developer overrides (HARE_VOXEL_KERNEL, HARE_TICKET, ...) are only read in a process that opted in
 # usage: bash tools/prof_ta.sh k1p k1q [k2p k2q]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

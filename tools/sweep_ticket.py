@@ -13,7 +13,7 @@ for N in sizes:
     dr = torch.from_numpy(rays).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
     row = []
     for t in tickets:
-        os.environ["HARE_TICKET"] = str(t)
+        g.set_option("ticket_rays", t)
         K = max(5, min(40, (1 << 25) // N))
         for _ in range(2): g.shoot_device(N, dr.data_ptr(), out.data_ptr(), stream=st)
         torch.cuda.synchronize()

@@ -3,8 +3,8 @@ started, took its last rays, and ended, grouped by residency tier (blockIdx // (
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ["HARE_DEV"] = "1"      # the timeline bit is a developer flag; read when the scene is created
 import hare_amd as H
-os.environ["HARE_DEV"] = "1"      # the timeline bit is a developer flag
 N = int(os.environ.get("RAYS", 1 << 20)); D = 64
 mesh = H.scenes.hall(); g = H.Voxel_Grid([H.Topology(mesh.verts, mesh.nverts)], D)
 rays = H.scenes.burst_rays(N, mesh.size)
@@ -13,8 +13,7 @@ W = 4096
 buf = torch.zeros(8 + 32 + 4 * W, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET values to compare
-    if cfg == "default": os.environ.pop("HARE_TICKET", None)
-    else: os.environ["HARE_TICKET"] = cfg
+    g.set_option("ticket_rays", 0 if cfg == "default" else int(cfg))
     for rep in range(2):
         buf.zero_()
         g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x2000)
