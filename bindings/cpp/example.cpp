@@ -30,6 +30,12 @@ int main()
         std::vector<hare_xevent> evs;
         const unsigned long long hits = grid.Shoot(rays, 0, evs);          // the batch entry: HIP kernels, no CPU fallback
         std::printf("batch: %llu hits, t = %.17g and %.17g\n", hits, evs[0].t, evs[1].t);
+        // the bounce loop in one call: ray 0 runs along +x inside the cube, 1.5 to the wall, then 2 from wall to wall
+        std::vector<hare_xevent> all;
+        std::vector<hare_counters> per_cast;
+        const unsigned long long bh = grid.Bounce(rays, 0, 3, all, nullptr, nullptr, &per_cast);
+        std::printf("bounce: %llu hits, ray 0 t = %.17g, %.17g, %.17g; cast 2: %llu rays\n", bh, all[0].t, all[2].t, all[4].t,
+                    (unsigned long long)per_cast[2].rays);
     } catch (const std::exception& e) {
         std::printf("exception: %s\n", e.what());
         return 2;

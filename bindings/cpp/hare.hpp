@@ -138,6 +138,20 @@ public:
                                   occ.data(), nullptr, nullptr));
         return occ;
     }
+    // the bounce loop in one call (harness-defined; the reference leaves reflection to its caller, who re-shoots with
+    // poly_origin1 = the polygon just hit, Spatial_Partition.cs:33): `bounces` casts, rays resident on the GPU throughout.
+    // events_all: bounces x rays.size() records, cast-major.  Returns the hits over all casts.
+    uint64_t Bounce(const std::vector<hare_ray>& rays, int top_index, int bounces, std::vector<hare_xevent>& events_all,
+                    const int32_t* poly_origin1 = nullptr, const int32_t* poly_origin2 = nullptr, std::vector<hare_counters>* per_cast = nullptr)
+    {
+        events_all.resize(rays.size() * (size_t)(bounces > 0 ? bounces : 0));
+        if (per_cast) per_cast->resize((size_t)(bounces > 0 ? bounces : 0));
+        hare_counters c{};
+        check(hare_bounce_batch(scene_, kind_, top_index, (int64_t)rays.size(), rays.data(), poly_origin1, poly_origin2, bounces, 0u,
+                                events_all.data(), nullptr, &c, per_cast ? per_cast->data() : nullptr));
+        return c.hits;
+    }
+    void SetOption(const char* name, int64_t value) { check(hare_scene_set_option(scene_, name, value)); }
     hare_scene* native() const { return scene_; }
 
 protected:

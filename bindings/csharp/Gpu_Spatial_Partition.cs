@@ -181,6 +181,57 @@ namespace Hare
                 return res;
             }
 
+            /// <summary>The bounce loop a Pachyderm-style caller runs per ray with the reference -- Shoot, reflect about
+            /// Model[top_index].Normal(Poly_id) (Hare_Geometry_Polygons.cs:161-171), Shoot again with poly_origin1 = the
+            /// polygon just hit (Spatial_Partition.cs:33) -- for a whole batch and `bounces` casts in ONE native call: the rays
+            /// stay on the GPU(s) for all casts, only events come back.  events_all receives bounces x rays.Length records,
+            /// cast-major (cast b of ray i at [b * rays.Length + i]); a ray that missed in an earlier cast holds the miss record
+            /// (hit == 0, poly_id == -1) from then on.  Returns the number of hits over all casts; per_cast (optional,
+            /// `bounces` entries) receives the rays alive and the hits of every cast.</summary>
+            public long Bounce(hare_ray[] rays, int top_index, int bounces, hare_xevent[] events_all, int[] poly_origin1 = null,
+                               int[] poly_origin2 = null, hare_counters[] per_cast = null)
+            {
+                if (bounces < 1) throw new ArgumentException("bounces must be at least 1");
+                if (events_all == null || events_all.LongLength < (long)bounces * rays.LongLength) throw new ArgumentException("events_all must hold bounces x rays.Length records");
+                if (per_cast != null && per_cast.Length < bounces) throw new ArgumentException("per_cast is shorter than bounces");
+                hare_counters ctr;
+                HareHip.Check(HareHip.hare_bounce_batch_sharded(scenes, scenes.Length, Kind, top_index, rays.LongLength, rays, poly_origin1, poly_origin2,
+                                                                bounces, 0u, events_all, null, out ctr, per_cast));
+                return (long)ctr.hits;
+            }
+
+            /// <summary>The same on managed objects: result[b][i] is the X_Event of ray i in cast b (X_Event() once the ray has
+            /// left the model).  rays[] is not modified.</summary>
+            public X_Event[][] Bounce(Ray[] rays, int top_index, int bounces)
+            {
+                int n = rays.Length;
+                var r = new hare_ray[n];
+                for (int i = 0; i < n; i++)
+                {
+                    r[i].x = rays[i].x; r[i].y = rays[i].y; r[i].z = rays[i].z;
+                    r[i].dx = rays[i].dx; r[i].dy = rays[i].dy; r[i].dz = rays[i].dz;
+                }
+                var ev = new hare_xevent[(long)bounces * n];
+                Bounce(r, top_index, bounces, ev);
+                var res = new X_Event[bounces][];
+                for (int b = 0; b < bounces; b++)
+                {
+                    res[b] = new X_Event[n];
+                    for (int i = 0; i < n; i++)
+                    {
+                        hare_xevent e = ev[(long)b * n + i];
+                        res[b][i] = e.hit != 0 ? new X_Event(new Point(e.x, e.y, e.z), e.u, e.v, e.t, e.poly_id) : new X_Event();
+                    }
+                }
+                return res;
+            }
+
+            /// <summary>Diagnostics / A-B switch on every replica (hare_scene_set_option), e.g. SetOption("voxel_kernel", 2).</summary>
+            public void SetOption(string name, long value)
+            {
+                foreach (IntPtr s in scenes) HareHip.Check(HareHip.hare_scene_set_option(s, name, value));
+            }
+
             void Release()
             {
                 for (int k = 0; k < scenes.Length; k++)

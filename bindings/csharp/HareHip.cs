@@ -91,6 +91,16 @@ namespace Hare
             public static extern unsafe int hare_shoot_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
                                                                      hare_ray* rays, int* excl1, int* excl2, uint flags,
                                                                      hare_xevent* ev, hare_counters* ctr);
+            /// <summary>The device-resident specular bounce loop from host buffers (include/hare_hip.h): `bounces` casts with a
+            /// reflection about Normal(Poly_id) between them; events_all is bounces x n records, cast-major; any output may be null.</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_bounce_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
+                                                               [In] hare_ray[] rays, int[] excl1, int[] excl2, int bounces, uint flags,
+                                                               [Out] hare_xevent[] events_all, [Out] hare_xevent[] events_last,
+                                                               out hare_counters ctr, [Out] hare_counters[] ctr_per_cast);
+            /// <summary>Diagnostics / A-B switch of one scene ("voxel_kernel", "octree_kernel", "build_host", ...: include/hare_hip.h).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl, CharSet = CharSet.Ansi)]
+            public static extern int hare_scene_set_option(IntPtr scene, string name, long value);
             /// <summary>Spatial_Partition.Shoot for ONE ray on the calling thread (host trace, no GPU round trip, lock-free):
             /// what the single-ray overrides call.  ray is updated like the reference moves R (AABB_Main.cs:254-257).</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]

@@ -85,6 +85,8 @@ SYMBOLS = {
     "hare_reflect_device": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
     "hare_shoot_kernel_name": (C.c_char_p, [_vp, _i32, _i32, _i64, _u32]),
     "hare_shoot_one": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hare_bounce_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp]),
+    "hare_bounce_batch_sharded": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp]),
     "hare_occluded_device": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "hare_occluded_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
 }

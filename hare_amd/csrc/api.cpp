@@ -90,6 +90,11 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
         {"hare_occlusion", &m->occlusion},
+        {"hare_live_count", &m->live_count},
+        {"hare_scan_tiles", &m->scan_tiles},
+        {"hare_reflect_compact", &m->reflect_compact},
+        {"hare_events_fill_miss", &m->events_fill_miss},
+        {"hare_events_expand", &m->events_expand},
         {"hare_cull_audit", &m->cull_audit},
         {"hare_voxel_persist_prof", &m->voxel_persist_prof},
         {"hare_vb_count", &m->vb_count},
@@ -869,6 +874,7 @@ void hare_scene_destroy(hare_scene* s)
             for (void*& p : *v) dev_free(H, p);
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work})
             dev_free(H, *p);
+        free_bounce_buffers(H, *s);
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
                 if (x) { (void)H->StreamSynchronize(x); (void)H->StreamDestroy(x); x = nullptr; }

@@ -11,7 +11,8 @@
 //   hare_voxel_shoot_*     K1   the reference loop structure as is (work counters, A/B baseline)
 //   hare_octree_persist    K2p  production Octree.Shoot; hare_octree_shoot* K2 simple/counting form
 //   hare_kdtree_shoot*          KDTree.Shoot (visits every leaf, like the reference)
-//   hare_reflect           K3   specular bounce between casts (harness-defined)
+//   hare_reflect           K3   specular bounce between casts (harness-defined); hare_live_count / hare_scan_tiles /
+//                               hare_reflect_compact / hare_events_*: the same with the survivors packed (hare_bounce_batch)
 //   hare_cull_audit             tests only: FP32 cull vs exact test on every ray x polygon pair
 //   hare_vb_*, hare_scan_*, hare_ob_*  Voxel_Grid / Octree construction (build_kernels.hip, included at the end)
 //
@@ -1080,6 +1081,115 @@ __global__ __launch_bounds__(256) void hare_reflect(const PolyRec* polys, RayRec
     o.dz = r.dz - k * p.n[2];
     rays[i] = o;
     excl_out[i] = e.poly_id;
+}
+
+// ---- dead-ray compaction of the bounce loop (hare_bounce_batch; SURVEY.md 7.1 step 9, 8(a) A9 "reflect_compact") ----
+// In an open scene most rays leave after a few bounces; instead of streaming the retired rays' records through every later
+// cast, the loop packs the survivors: (1) live rays counted per tile of 2048 events, (2) the tile counts scanned by one
+// workgroup, (3) reflection written to the packed position.  The packing is STABLE (survivors keep their relative order, so
+// the burst's locality survives and so does run-to-run determinism); `idx` carries each packed ray's position in the caller's
+// arrays for the way back (hare_events_expand).
+constexpr int kCompactTile = 2048;      // events per workgroup: 8 passes of 256 lanes
+
+__global__ __launch_bounds__(256) void hare_live_count(const XEventRec* ev, long long m, uint32_t* tile_counts)
+{
+    __shared__ uint32_t ws[4];
+    const long long base = (long long)blockIdx.x * kCompactTile;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kCompactTile / 256; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < m && ev[i].hit != 0) ++c;
+    }
+    const unsigned long long s = wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = (uint32_t)s;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of the tile counts in place, by ONE workgroup (a million rays are 512 tiles); total[0] = the sum
+__global__ __launch_bounds__(1024) void hare_scan_tiles(uint32_t* counts, long long nt, uint32_t* total)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long long base = 0; base < nt; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const uint32_t v = i < nt ? counts[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        uint32_t woff = carry;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        if (i < nt) counts[i] = woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+
+// hare_reflect for the survivors only, written to their packed positions; idx_in null = the rays are still in caller order
+__global__ __launch_bounds__(256) void hare_reflect_compact(const PolyRec* polys, const RayRec* rays_in, const XEventRec* ev,
+                                                            const int32_t* idx_in, const uint32_t* tile_offsets, long long m,
+                                                            RayRec* rays_out, int32_t* excl_out, int32_t* idx_out)
+{
+    __shared__ uint32_t wc[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const long long base = (long long)blockIdx.x * kCompactTile;
+    uint32_t run = tile_offsets[blockIdx.x];
+#pragma unroll 1
+    for (int k = 0; k < kCompactTile / 256; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        XEventRec e;
+        e.hit = 0;
+        if (i < m) e = ev[i];
+        const bool live = i < m && e.hit != 0;
+        const unsigned long long bm = __ballot(live);
+        if (lane == 0) wc[wid] = (uint32_t)__popcll(bm);
+        __syncthreads();
+        uint32_t off = run + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wid; ++w) off += wc[w];
+        run += wc[0] + wc[1] + wc[2] + wc[3];
+        __syncthreads();
+        if (live) {
+            const RayRec r = rays_in[i];
+            const PolyRec& p = polys[e.poly_id];
+            const double dn = dot3(r.dx, r.dy, r.dz, p.n[0], p.n[1], p.n[2]);
+            const double kk = 2.0 * dn;
+            RayRec o;
+            o.x = e.x; o.y = e.y; o.z = e.z;
+            o.dx = r.dx - kk * p.n[0];
+            o.dy = r.dy - kk * p.n[1];
+            o.dz = r.dz - kk * p.n[2];
+            rays_out[off] = o;
+            excl_out[off] = e.poly_id;
+            idx_out[off] = idx_in ? idx_in[i] : (int32_t)i;
+        }
+    }
+}
+
+// The way back: events of the packed rays to their positions in the caller's order; every other position is the miss record
+__global__ __launch_bounds__(256) void hare_events_fill_miss(XEventRec* full, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XEventRec e;
+    set_miss(e);
+    full[i] = e;
+}
+__global__ __launch_bounds__(256) void hare_events_expand(const XEventRec* ev, const int32_t* idx, long long m, XEventRec* full)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    full[idx[i]] = ev[i];
 }
 
 // A9 occlusion predicate (harness-defined): a ray is occluded when its CLOSEST hit -- the

@@ -88,6 +88,7 @@ struct DeviceModule {
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
+    hipFunction_t live_count = nullptr, scan_tiles = nullptr, reflect_compact = nullptr, events_fill_miss = nullptr, events_expand = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
     hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
@@ -158,7 +159,24 @@ struct Scene {
     // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
     // over), so that host threads calling on one scene run side by side instead of queueing on one mutex; `mu` guards
     // the one-time device set-up and the hand-out of contexts only, never a transfer or a kernel
+    // device buffers of one hare_bounce_batch call in flight (bounce.cpp): the rays and their exclusions double-buffered
+    // (a packed copy is written while the previous one is read), events double-buffered (the download of one cast runs
+    // beside the next cast), the map back to the caller's order, the expanded events of a packed cast, tile counts
+    struct BounceBuf {
+        void* rays[2] = {nullptr, nullptr};
+        void* excl[2] = {nullptr, nullptr};
+        void* excl2 = nullptr;
+        void* idx[2] = {nullptr, nullptr};
+        void* ev[2] = {nullptr, nullptr};
+        void* full = nullptr;
+        void* tiles = nullptr;
+        void* ctr = nullptr;            // hare_counters per cast (+ one word for the packed count)
+        int64_t cap = 0;
+        int32_t ctr_cap = 0;
+        hipStream_t copy_st = nullptr;
+    };
     struct BatchCtx {
+        BounceBuf bounce;
         hipStream_t st[3] = {nullptr, nullptr, nullptr};
         void* d_rays = nullptr;
         void* d_e1 = nullptr;
@@ -194,6 +212,13 @@ void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<Qua
 // error plumbing (thread-local message)
 void set_error(const std::string& msg);
 const char* last_error();
+
+// the launcher behind every shoot entry point (api.cpp)
+int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays, const void* d_e1, const void* d_e2,
+                      uint32_t flags, void* d_out, void* d_ctr, hipStream_t st);
+uint32_t sanitize_flags(const Scene& s, uint32_t flags);
+int dev_free(const HipApi* H, void*& p);
+void free_bounce_buffers(const HipApi* H, Scene& s);          // bounce.cpp
 
 // device plumbing shared by api.cpp and build_gpu.cpp
 const HipApi* api_or_err();

@@ -263,6 +263,41 @@ class Spatial_Partition:
                                            capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0, ptr(out), C.addressof(ctr)))
         return out, ctr.as_dict()
 
+    def Bounce_batch(self, rays, bounces: int, top_index: int = 0, poly_origin1=None, poly_origin2=None, all_casts: bool = False,
+                     per_cast: bool = False, simple_kernel: bool = False):
+        """The device-resident specular bounce loop from host buffers (hare_bounce_batch): `bounces` casts with a reflection
+        between them, rays resident on the GPU throughout.  Returns (events, counters) -- events of the LAST cast [n], or with
+        all_casts=True of every cast [bounces, n]; with per_cast=True a third value: the list of per-cast counter dicts."""
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+        n, B = rays.shape[0], int(bounces)
+        e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
+        e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
+        ev_all = np.zeros((B, n), XEVENT_DTYPE) if all_casts else None
+        ev_last = None if all_casts else np.zeros(n, XEVENT_DTYPE)
+        ctr = capi.Counters()
+        pcs = (capi.Counters * max(B, 1))()
+        check(lib.hare_bounce_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), B,
+                                    capi.SHOOT_SIMPLE_KERNEL if simple_kernel else 0, ptr(ev_all), ptr(ev_last), C.addressof(ctr),
+                                    C.addressof(pcs)))
+        out = (ev_all if all_casts else ev_last, ctr.as_dict())
+        return out + ([pcs[b].as_dict() for b in range(B)],) if per_cast else out
+
+    @staticmethod
+    def Bounce_batch_sharded(partitions, rays, bounces: int, top_index: int = 0, all_casts: bool = False):
+        """hare_bounce_batch_sharded: the loop over several devices from one process (contiguous ray shards, as Shoot_batch_sharded)."""
+        parts = list(partitions)
+        if not parts or any(p._kind != parts[0]._kind for p in parts):
+            raise ValueError("need one or more partitions of the same kind")
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+        n, B = rays.shape[0], int(bounces)
+        ev_all = np.zeros((B, n), XEVENT_DTYPE) if all_casts else None
+        ev_last = None if all_casts else np.zeros(n, XEVENT_DTYPE)
+        handles = (C.c_void_p * len(parts))(*[p._h for p in parts])
+        ctr = capi.Counters()
+        check(lib.hare_bounce_batch_sharded(handles, len(parts), parts[0]._kind, int(top_index), n, ptr(rays), None, None, B, 0,
+                                            ptr(ev_all), ptr(ev_last), C.addressof(ctr), None))
+        return (ev_all if all_casts else ev_last), ctr.as_dict()
+
     def shoot_device(self, n: int, d_rays: int, d_out: int, top_index: int = 0, d_excl1: int = 0, d_excl2: int = 0,
                      d_counters: int = 0, stream: int = 0, flags: int = 0):
         """Device-resident shoot: raw device addresses (e.g. torch.Tensor.data_ptr()) + a hipStream_t."""

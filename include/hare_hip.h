@@ -274,6 +274,33 @@ HARE_API int hare_occluded_batch(hare_scene *s, int32_t kind, int32_t top_index,
 HARE_API int hare_reflect_device(hare_scene *s, int32_t top_index, int64_t n, void *d_rays, const void *d_events,
                         void *d_excl_out, void *stream);
 
+/* ---- the whole bounce loop behind one call, from host buffers (harness-defined like hare_reflect_device) ----
+ * What a Pachyderm-style caller does per ray with the reference -- Shoot, reflect about Model[top].Normal(Poly_id)
+ * (Hare_Geometry_Polygons.cs:161-171), Shoot again with poly_origin1 = the polygon just hit (Spatial_Partition.cs:33;
+ * Voxel_Grid.cs:351,477) -- for n rays and `bounces` casts, device-resident: the rays go up once, every cast and every
+ * reflection runs on the scene's GPU, and only the requested X_Events come down (the download of a cast overlaps the next cast).
+ *   cast 0 shoots rays[] with excl1 / excl2 (nullable; poly_origin1 / poly_origin2 per ray as in hare_shoot_batch: a negative
+ *   index excludes nothing); cast b > 0 shoots the reflections of the rays that hit in cast b - 1, excluding the polygon they
+ *   left.  A ray that misses is retired: its X_Event in every later cast is the miss record X_Event(), and it is not counted.
+ *   When a quarter or more of the rays in flight have died the survivors are packed (stably) and later casts run on them
+ *   alone; their events are put back in the caller's order on the device.  Results do not depend on whether that happened.
+ *   events_all     nullable: bounces x n records, cast-major (cast b at events_all + b * n)
+ *   events_last    nullable: the n records of the last cast
+ *   ctr            nullable: counters summed over the casts (rays = live casts)
+ *   ctr_per_cast   nullable: `bounces` blocks, one per cast (rays = rays alive in that cast, hits = rays that live on)
+ *   flags          HARE_SHOOT_COUNT_WORK / HARE_SHOOT_SIMPLE_KERNEL only; rays[] is never written
+ * Threading as hare_shoot_batch (a staging context per call in flight, four per scene). */
+HARE_API int hare_bounce_batch(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, const hare_ray *rays,
+                               const int32_t *excl1, const int32_t *excl2, int32_t bounces, uint32_t flags,
+                               hare_xevent *events_all, hare_xevent *events_last, hare_counters *ctr,
+                               hare_counters *ctr_per_cast);
+/* The same over several devices from one process: rays [n*k/G, n*(k+1)/G) go to scenes[k] (as hare_shoot_batch_sharded); every
+ * shard keeps its rays resident on its own device for all casts; outputs are byte-identical to the one-device call. */
+HARE_API int hare_bounce_batch_sharded(hare_scene *const *scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n,
+                                       const hare_ray *rays, const int32_t *excl1, const int32_t *excl2, int32_t bounces,
+                                       uint32_t flags, hare_xevent *events_all, hare_xevent *events_last, hare_counters *ctr,
+                                       hare_counters *ctr_per_cast);
+
 #ifdef __cplusplus
 }
 #endif

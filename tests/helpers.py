@@ -44,3 +44,30 @@ def assert_events_equal(a, b, fields=FIELDS, what=""):
             bad = np.nonzero(a[f] != b[f])[0]
             raise AssertionError(f"{what} X_Event.{f} differs on {bad.size} of {len(a)} rays; first {bad[:5]}: "
                                  f"{a[bad[:3]]} vs {b[bad[:3]]}")
+
+
+def oracle_bounce_loop(po, ot, og, rays, bounces, excl1=None, excl2=None, nthreads=16):
+    """The harness-defined bounce loop on the CPU, cast by cast with the oracle: shoot, reflect the rays
+    that hit about the polygon's normal, exclude the polygon just left; a ray that misses is retired (miss records from
+    then on, not counted).  Returns (events [bounces, n], per-cast counters)."""
+    n = len(rays)
+    cur = np.array(rays, np.float64).reshape(-1, 6).copy()
+    e1 = np.full(n, -1, np.int32) if excl1 is None else np.asarray(excl1, np.int32).copy()
+    e2 = None if excl2 is None else np.asarray(excl2, np.int32).copy()
+    dead = np.zeros(n, bool)
+    out = np.zeros((bounces, n), po.XEVENT_DTYPE)
+    out["poly_id"] = -1
+    ctrs = []
+    for b in range(bounces):
+        live = ~dead
+        c = {"rays": 0, "hits": 0}
+        if live.any():
+            ev, c = og.shoot(cur[live], excl1=e1[live], excl2=None if e2 is None else e2[live], nthreads=nthreads)
+            out[b][live] = ev
+        ctrs.append({"rays": int(c["rays"]), "hits": int(c["hits"])})
+        alive = (out[b]["hit"] == 1) & live
+        cur = po.reflect_batch(ot, cur, out[b])
+        e1 = np.where(alive, out[b]["poly_id"], -2).astype(np.int32)
+        e2 = None
+        dead |= ~alive
+    return out, ctrs

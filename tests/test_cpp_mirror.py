@@ -34,3 +34,4 @@ def test_cpp_mirror_shoots_on_gpu(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "hit poly" in r.stdout and "t = 1.5 " in r.stdout and "(2.000, 0.750, 1.000)" in r.stdout
     assert "batch: 2 hits, t = 1.5 and 1" in r.stdout
+    assert "bounce: 6 hits, ray 0 t = 1.5, 2, 2; cast 2: 2 rays" in r.stdout

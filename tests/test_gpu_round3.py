@@ -92,3 +92,86 @@ def test_environment_overrides_need_the_opt_in(hall, monkeypatch):
     assert g2.kernel_name(1000) == "hare_voxel_pool_tri"
     monkeypatch.setenv("HARE_VOXEL_KERNEL", "persist")
     assert g2.kernel_name(1000) == "hare_voxel_pool_tri"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# hare_bounce_batch: the whole bounce loop behind one C-ABI call from host buffers
+from tests.helpers import oracle_bounce_loop, soup, soup_rays   # noqa: E402
+
+
+def test_bounce_batch_c5_full_size_every_cast_equals_the_oracle():
+    """BASELINE config[4] at its per-GPU size through ONE call: 1 048 576 rays x 8 casts in the 1M-triangle cathedral, D = 128;
+    the events of every cast, the summed and the per-cast counters equal the oracle's loop."""
+    m = H.scenes.cathedral()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    n, B = 1 << 20, 8
+    rays = H.scenes.burst_rays(8 << 20, m.size, start=5 << 20, count=n)     # one rank's shard of the 8M-ray burst
+    g, o = H.Voxel_Grid([T], 128), po.VoxelGrid([To], domain=128)
+    ref, rc = oracle_bounce_loop(po, To, o, rays, B)
+    ev, c, pcs = g.Bounce_batch(rays, B, all_casts=True, per_cast=True)
+    for b in range(B):
+        assert_events_equal(ev[b], ref[b], what=f"bounce batch, cast {b}")
+        assert (pcs[b]["rays"], pcs[b]["hits"]) == (rc[b]["rays"], rc[b]["hits"])
+    assert (c["rays"], c["hits"]) == (sum(x["rays"] for x in rc), sum(x["hits"] for x in rc))
+    last, c2 = g.Bounce_batch(rays, B)                                        # events of the last cast only
+    assert_events_equal(last, ref[B - 1], what="bounce batch, last cast only")
+    assert c2 == c
+
+
+@pytest.mark.parametrize("kind", ["voxel_persist", "voxel_pool", "octree", "kdtree"])
+def test_bounce_batch_open_scene_packs_the_survivors(kind):
+    """A polygon soup with no walls: most rays leave within a few bounces.  The loop packs the survivors (stably) once a
+    quarter of the rays in flight have died and later reflects in place again -- every cast still equals the oracle's, in
+    the caller's ray order, with quads, caller exclusions on the first cast and origins outside the grid."""
+    v, nv, size = soup(n_tri=1500, n_quad=400, seed=5)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    n, B = (60_000, 7) if kind != "kdtree" else (20_000, 4)
+    rays = soup_rays(n, size, seed=21)
+    rng = np.random.default_rng(2)
+    e1 = rng.integers(-3, len(nv), n).astype(np.int32)       # negative: excludes nothing (the reference compares indices only)
+    e2 = rng.integers(-1, len(nv), n).astype(np.int32)
+    if kind.startswith("voxel"):
+        g, o = H.Voxel_Grid([T], 24), po.VoxelGrid([To], domain=24)
+        g.set_option("voxel_kernel", 2 if kind.endswith("pool") else 1)
+    elif kind == "octree":
+        g, o = H.Octree([T], 5, 8), po.Octree([To], 5, 8)
+    else:
+        g, o = H.KDTree([T], 8, 8), po.KDTree([To], 8, 8)
+    ref, rc = oracle_bounce_loop(po, To, o, rays, B, e1, e2)
+    ev, c, pcs = g.Bounce_batch(rays, B, poly_origin1=e1, poly_origin2=e2, all_casts=True, per_cast=True)
+    alive = [x["rays"] for x in rc]
+    assert alive[0] == n and alive[2] < 0.75 * n and alive[-1] > 0, alive       # the packing rule did trigger, rays were left
+    for b in range(B):
+        assert_events_equal(ev[b], ref[b], what=f"{kind}: open scene, cast {b}")
+        assert (pcs[b]["rays"], pcs[b]["hits"]) == (rc[b]["rays"], rc[b]["hits"]), (b, pcs[b], rc[b])
+    assert c["rays"] == sum(alive)
+
+
+def test_bounce_batch_edges_and_sharding():
+    m = H.scenes.shoebox()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    g, o = H.Voxel_Grid([T], 8), po.VoxelGrid([To], domain=8)
+    rays = H.scenes.random_rays(5000, m.size)
+    # one cast == Shoot_batch
+    ev1, c1 = g.Bounce_batch(rays, 1)
+    ev0, c0 = g.Shoot_batch(rays)
+    assert ev1.tobytes() == ev0.tobytes() and (c1["rays"], c1["hits"]) == (c0["rays"], c0["hits"])
+    # no ray, one ray, every ray dead after the first cast (origins far outside, pointing away)
+    ev, c = g.Bounce_batch(np.zeros((0, 6)), 3, all_casts=True)
+    assert ev.shape == (3, 0) and c["rays"] == 0
+    ev, c = g.Bounce_batch(rays[:1], 4, all_casts=True)
+    ref, _ = oracle_bounce_loop(po, To, o, rays[:1], 4)
+    assert ev.tobytes() == ref.tobytes()
+    away = rays.copy()
+    away[:, :3] = 100.0
+    away[:, 3:] = 1.0
+    ev, c, pcs = g.Bounce_batch(away, 5, all_casts=True, per_cast=True)
+    assert not ev["hit"].any() and (ev["poly_id"] == -1).all() and c["rays"] == len(away) and pcs[1]["rays"] == 0
+    # two scenes on this device standing in for two devices: byte-identical to the one-scene call
+    g2 = H.Voxel_Grid([T], 8)
+    ref, rc = oracle_bounce_loop(po, To, o, rays, 6)
+    a, ca = g.Bounce_batch(rays, 6, all_casts=True)
+    b, cb = H.Spatial_Partition.Bounce_batch_sharded([g, g2], rays, 6, all_casts=True)
+    assert a.tobytes() == ref.tobytes() and b.tobytes() == ref.tobytes() and ca == cb
+    with pytest.raises(H.HareError):
+        g.Bounce_batch(rays, 0)
