@@ -385,10 +385,7 @@ int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_p
         std::vector<uint32_t> task_child;              // BFS index of the child a task belongs to
         for (size_t n = level_begin; n < level_end; ++n) {
             if ((int64_t)nodes[n].count <= (int64_t)max_polys) continue;          // :93
-            if (nodes.size() + 8 > 0x7FFFFFF0ull) {
-                set_error("hare_octree_build: more than 2^31 nodes");
-                return HARE_E_UNSUPPORTED;
-            }
+            if (nodes.size() + 8 > kOctMaxNodes) return octree_budget_error("nodes");
             nodes[n].first_child = (int32_t)nodes.size();
             const BNode parent = nodes[n];
             for (int i = 0; i < 8; ++i) {
@@ -440,10 +437,7 @@ int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_p
             tasks[k].ostart = (uint32_t)total;
             c.count += counts[k];
             total += counts[k];
-            if (total > 0x7FFFFFF0ull) {
-                set_error("hare_octree_build: more than 2^31 list entries on one level");
-                return HARE_E_UNSUPPORTED;
-            }
+            if (total > kOctMaxItems) return octree_budget_error("polygon-list entries");
         }
         void* d_next = nullptr;
         rc = mem.alloc(&d_next, (size_t)total * 4, false);

@@ -290,11 +290,18 @@ struct OBuild {
     int max_depth, max_polys;
     std::vector<OctNode> nodes;
     std::vector<std::vector<int32_t>> lists;  // per node
+    size_t live_items = 0;                    // entries held by the lists
+    int failed = 0;                           // HARE_E_NOMEM: a budget was exceeded, the recursion unwinds
 };
 
 void oct_split(OBuild& b, int32_t ni, int depth)
 {
+    if (b.failed) return;
     if (depth >= b.max_depth || (int)b.lists[ni].size() <= b.max_polys) return;   // :93
+    if (b.nodes.size() + 8 > kOctMaxNodes) {
+        b.failed = octree_budget_error("nodes");
+        return;
+    }
     double nmin[3], nmax[3];
     for (int a = 0; a < 3; ++a) {
         nmin[a] = b.nodes[ni].bmin[a];
@@ -313,11 +320,20 @@ void oct_split(OBuild& b, int32_t ni, int depth)
     const Topo& T = *b.T0;                       // Model[0].Polygon_Vertices(polyId), :123
     std::vector<int32_t> mine;
     mine.swap(b.lists[ni]);                      // node.Polygons.Clear(), :132
-    for (int32_t pid : mine)
+    for (int32_t pid : mine) {
         for (int c = 0; c < 8; ++c) {
             const OctNode& ch = b.nodes[first + c];
-            if (poly_box_overlap(ch.bmin, ch.bmax, &T.verts[(size_t)pid * 12], T.nverts[pid])) b.lists[first + c].push_back(pid);
+            if (poly_box_overlap(ch.bmin, ch.bmax, &T.verts[(size_t)pid * 12], T.nverts[pid])) {
+                b.lists[first + c].push_back(pid);
+                ++b.live_items;
+            }
         }
+        if (b.live_items > kOctMaxItems) {
+            b.failed = octree_budget_error("polygon-list entries");
+            return;
+        }
+    }
+    b.live_items -= mine.size();
     for (int c = 0; c < 8; ++c) oct_split(b, first + c, depth + 1);
 }
 
@@ -351,6 +367,14 @@ void octree_root_box(const Topo& T, double bmin[3], double bmax[3])
         bmin[a] = center - maxdim - 1e-1;
         bmax[a] = center + maxdim + 1e-1;
     }
+}
+
+int octree_budget_error(const char* what)
+{
+    set_error(std::string("hare_octree_build: the tree outgrows its budget of ") + what + " (2^24 nodes, 2^28 list entries).  The reference "
+              "pads child boxes by an absolute 0.1 m (\"Octree - alt.cs\":99-111): once nodes are smaller than ~0.4 m every polygon lands in "
+              "all eight children and the tree grows 8x per level -- lower maxDepth (a node of the root's size halves per level)");
+    return HARE_E_NOMEM;
 }
 
 int octree_check_args(const Scene& s, int32_t max_depth, int32_t max_polys)
@@ -391,7 +415,9 @@ int build_octree(Scene& s, int32_t max_depth, int32_t max_polys)
     b.lists.emplace_back();
     b.lists[0].resize(T.P);
     for (int32_t i = 0; i < T.P; ++i) b.lists[0][i] = i;
+    b.live_items = (size_t)T.P;
     oct_split(b, 0, 0);
+    if (b.failed) return b.failed;
 
     OctreeHost o;
     o.max_depth = max_depth;

@@ -238,6 +238,14 @@ int gpu_build_voxel_fixed(Scene& s, const HipApi* H, int32_t domain, bool* used)
 int gpu_build_voxel_adaptive(Scene& s, const HipApi* H, int32_t max_domain, int32_t avg_polys, bool* used);
 int gpu_build_octree(Scene& s, const HipApi* H, int32_t max_depth, int32_t max_polys, bool* used);
 
+// Budgets of one octree (host and GPU builder alike; HARE_E_NOMEM beyond them, before the machine is exhausted).  The reference
+// has none and would run until the process dies: its child boxes are padded by an ABSOLUTE 0.1 m ("Octree - alt.cs":99-111),
+// so once nodes are smaller than ~0.4 m every polygon lands in all eight children and the tree grows 8x per level whatever the
+// polygon count -- a 60-triangle soup at maxDepth 17 asks for 8^17 nodes.
+constexpr size_t kOctMaxNodes = (size_t)1 << 24;          // 64 B each on the device: 1 GB
+constexpr size_t kOctMaxItems = (size_t)1 << 28;          // polygon-list entries alive at once: 1 GB
+int octree_budget_error(const char* what);                // sets the message, returns HARE_E_NOMEM (build_host.cpp)
+
 // builders (host); return HARE_* codes
 int build_voxel_fixed(Scene& s, int32_t domain);
 int build_voxel_adaptive(Scene& s, int32_t max_domain, int32_t avg_polys);

@@ -18,6 +18,7 @@
 #ifndef HARE_ORACLE_H
 #define HARE_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -120,6 +121,18 @@ ho_voxel_pool *ho_voxel_pool_new(const ho_voxel_grid *g, const ho_topology *mode
 void ho_voxel_pool_free(ho_voxel_pool *p);
 int ho_voxel_pool_shoot(ho_voxel_pool *p, ho_ray *R, int32_t ray_id, int32_t top_index,
                         int32_t poly_origin1, int32_t poly_origin2, ho_xevent *out);
+
+/* ---------- allocation failures and tree budgets ----------
+ * Every builder returns NULL when an allocation fails or a tree outgrows its budget, and ho_last_error() (thread-local)
+ * says which; nothing dereferences an unchecked realloc.  The budgets are not in the reference (which would run until the
+ * process dies): a loose octree whose nodes shrink below ~0.4 m grows 8x per level whatever the polygon count
+ * ("Octree - alt.cs":99-111 pads child boxes by an ABSOLUTE 0.1 m), so a careless maxDepth exhausts any machine. */
+#define HO_MAX_TREE_NODES (1 << 24)          /* nodes of one octree / kd-tree                 */
+#define HO_MAX_TREE_ITEMS (1ll << 28)        /* polygon-list entries alive at any one time    */
+const char *ho_last_error(void);
+void ho_set_error(const char *msg);
+/* grow *p to `bytes` (realloc); 0 = ok, -1 = failed (*p unchanged, error set) */
+int ho_grow(void **p, size_t bytes);
 
 /* ---------- Octree ("Octree - alt.cs") ---------- */
 typedef struct ho_octree ho_octree;

@@ -29,13 +29,22 @@ struct ho_kdtree {
     int32_t max_depth, max_polys;
     const ho_topology *model0;
     double *centroids; /* Model[0].Polygon_Centroid */
+    int64_t live_items;
+    int failed;        /* allocation failure / budget: the build unwinds, ho_kdtree_build returns NULL */
 };
 
 static int32_t knew(ho_kdtree *k, const double mn[3], const double mx[3])
 {
+    if (k->failed) return -1;
+    if (k->n >= HO_MAX_TREE_NODES) {
+        ho_set_error("oracle kd-tree: more than 2^24 nodes -- lower maxDepth");
+        k->failed = 1;
+        return -1;
+    }
     if (k->n == k->cap) {
-        k->cap = k->cap ? k->cap * 2 : 64;
-        k->nodes = (knode *)realloc(k->nodes, (size_t)k->cap * sizeof(knode));
+        const int32_t ncap = k->cap ? k->cap * 2 : 64;
+        if (ho_grow((void **)&k->nodes, (size_t)ncap * sizeof(knode))) { k->failed = 1; return -1; }
+        k->cap = ncap;
     }
     knode *nd = &k->nodes[k->n];
     memset(nd, 0, sizeof *nd);
@@ -65,11 +74,18 @@ static int cmp_skey(const void *a, const void *b)
 /* BuildKDTree: KDTree.cs:90-139 */
 static void kbuild(ho_kdtree *k, int32_t ni, int depth, const double mn[3], const double mx[3])
 {
+    if (k->failed) return;
     if (depth >= k->max_depth || k->nodes[ni].npolys <= k->max_polys) return;
     const ho_topology *T = k->model0;
     int axis = depth % 3;
     int32_t cnt = k->nodes[ni].npolys;
-    skey *sk = (skey *)malloc((size_t)cnt * sizeof(skey));
+    if (k->live_items + 2 * (int64_t)cnt > HO_MAX_TREE_ITEMS) {
+        ho_set_error("oracle kd-tree: more than 2^28 polygon-list entries alive -- lower maxDepth");
+        k->failed = 1;
+        return;
+    }
+    skey *sk = (skey *)malloc((size_t)(cnt ? cnt : 1) * sizeof(skey));
+    if (!sk) { ho_set_error("oracle: out of memory"); k->failed = 1; return; }
     for (int32_t q = 0; q < cnt; ++q) {
         int32_t id = k->nodes[ni].polys[q];
         sk[q].key = k->centroids[3 * (size_t)id + axis];
@@ -89,10 +105,17 @@ static void kbuild(ho_kdtree *k, int32_t ni, int depth, const double mn[3], cons
 
     int32_t L = knew(k, mn, leftMax);
     int32_t Rr = knew(k, rightMin, mx);
+    if (L < 0 || Rr < 0) { free(sk); return; }
+    k->nodes[L].polys = (int32_t *)malloc((size_t)(cnt ? cnt : 1) * sizeof(int32_t));
+    k->nodes[Rr].polys = (int32_t *)malloc((size_t)(cnt ? cnt : 1) * sizeof(int32_t));
+    if (!k->nodes[L].polys || !k->nodes[Rr].polys) {
+        ho_set_error("oracle: out of memory");
+        k->failed = 1;
+        free(sk);
+        return;
+    }
     k->nodes[ni].left = L;
     k->nodes[ni].right = Rr;
-    k->nodes[L].polys = (int32_t *)malloc((size_t)cnt * sizeof(int32_t));
-    k->nodes[Rr].polys = (int32_t *)malloc((size_t)cnt * sizeof(int32_t));
 
     for (int32_t q = 0; q < cnt; ++q) {
         int32_t id = sk[q].id;
@@ -106,6 +129,7 @@ static void kbuild(ho_kdtree *k, int32_t ni, int depth, const double mn[3], cons
         if (anygt) k->nodes[Rr].polys[k->nodes[Rr].npolys++] = id;
     }
     free(sk);
+    k->live_items += (int64_t)k->nodes[L].npolys + k->nodes[Rr].npolys - cnt;
     free(k->nodes[ni].polys); /* node.Polygons.Clear() */
     k->nodes[ni].polys = NULL;
     k->nodes[ni].npolys = 0;
@@ -119,10 +143,12 @@ static void kbuild(ho_kdtree *k, int32_t ni, int depth, const double mn[3], cons
 ho_kdtree *ho_kdtree_build(const ho_topology *models, int32_t M, int32_t max_depth, int32_t max_polys)
 {
     ho_kdtree *k = (ho_kdtree *)calloc(1, sizeof *k);
+    if (!k) { ho_set_error("oracle: out of memory"); return NULL; }
     k->max_depth = max_depth;
     k->max_polys = max_polys;
     k->model0 = &models[0];
     k->centroids = (double *)malloc((size_t)(models[0].P ? models[0].P : 1) * 3 * sizeof(double));
+    if (!k->centroids) { ho_set_error("oracle: out of memory"); free(k); return NULL; }
     ho_polygon_centroids(models[0].verts, models[0].nverts, models[0].P, k->centroids);
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int32_t m = 0; m < M; ++m) {
@@ -136,11 +162,22 @@ ho_kdtree *ho_kdtree_build(const ho_topology *models, int32_t M, int32_t max_dep
                 }
         for (int32_t i = 0; i < k->n; ++i) free(k->nodes[i].polys);
         k->n = 0;
+        k->live_items = 0;
         int32_t root = knew(k, mn, mx);
-        k->nodes[root].polys = (int32_t *)malloc((size_t)(T->P ? T->P : 1) * sizeof(int32_t));
-        for (int32_t i = 0; i < T->P; ++i) k->nodes[root].polys[i] = i;
-        k->nodes[root].npolys = T->P;
-        kbuild(k, root, 0, mn, mx);
+        if (root >= 0) {
+            k->nodes[root].polys = (int32_t *)malloc((size_t)(T->P ? T->P : 1) * sizeof(int32_t));
+            if (!k->nodes[root].polys) { ho_set_error("oracle: out of memory"); k->failed = 1; }
+        }
+        if (!k->failed) {
+            for (int32_t i = 0; i < T->P; ++i) k->nodes[root].polys[i] = i;
+            k->nodes[root].npolys = T->P;
+            k->live_items = T->P;
+            kbuild(k, root, 0, mn, mx);
+        }
+        if (k->failed) {
+            ho_kdtree_free(k);
+            return NULL;
+        }
     }
     return k;
 }
@@ -196,6 +233,7 @@ int ho_kdtree_shoot(const ho_kdtree *k, const ho_topology *models, const ho_ray 
 
     int scap = k->max_depth + 8;
     int32_t *stack = (int32_t *)malloc((size_t)scap * sizeof(int32_t));
+    if (!stack) { ho_set_error("oracle: out of memory"); return 0; }      /* out already holds the miss record */
     int sp = 0;
     stack[sp++] = 0;
     const double o[3] = {ray->x, ray->y, ray->z};
@@ -245,8 +283,13 @@ int ho_kdtree_shoot(const ho_kdtree *k, const ho_topology *models, const ho_ray 
                 else { first = cur->right; second = cur->left; }
             }
             if (sp + 2 > scap) {
+                if (ho_grow((void **)&stack, (size_t)scap * 2 * sizeof(int32_t))) {       /* cannot continue this ray: report the failure as a miss */
+                    free(stack);
+                    memset(out, 0, sizeof *out);
+                    out->poly_id = -1;
+                    return 0;
+                }
                 scap *= 2;
-                stack = (int32_t *)realloc(stack, (size_t)scap * sizeof(int32_t));
             }
             stack[sp++] = second;
             stack[sp++] = first;

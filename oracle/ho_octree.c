@@ -24,13 +24,23 @@ struct ho_octree {
     int32_t n, cap;
     int32_t max_depth, max_polys;
     const ho_topology *model0;
+    int64_t live_items;   /* list entries currently held by nodes */
+    int failed;           /* an allocation failed or a budget was exceeded: the build unwinds, ho_octree_build returns NULL */
 };
 
 static int32_t new_node(ho_octree *o, const double mn[3], const double mx[3])
 {
+    if (o->failed) return -1;
+    if (o->n >= HO_MAX_TREE_NODES) {
+        ho_set_error("oracle octree: more than 2^24 nodes (child boxes are padded by an absolute 0.1 m, \"Octree - alt.cs\":99-111: "
+                     "below ~0.4 m node size the tree grows 8x per level -- lower maxDepth)");
+        o->failed = 1;
+        return -1;
+    }
     if (o->n == o->cap) {
-        o->cap = o->cap ? o->cap * 2 : 64;
-        o->nodes = (onode *)realloc(o->nodes, (size_t)o->cap * sizeof(onode));
+        const int32_t ncap = o->cap ? o->cap * 2 : 64;
+        if (ho_grow((void **)&o->nodes, (size_t)ncap * sizeof(onode))) { o->failed = 1; return -1; }
+        o->cap = ncap;
     }
     onode *nd = &o->nodes[o->n];
     memset(nd, 0, sizeof *nd);
@@ -40,18 +50,28 @@ static int32_t new_node(ho_octree *o, const double mn[3], const double mx[3])
     return o->n++;
 }
 
-static void node_push(onode *nd, int32_t p)
+static void node_push(ho_octree *o, onode *nd, int32_t p)
 {
+    if (o->failed) return;
+    if (o->live_items >= HO_MAX_TREE_ITEMS) {
+        ho_set_error("oracle octree: more than 2^28 polygon-list entries alive (the tree grows 8x per level once nodes are smaller "
+                     "than the 0.1 m padding of \"Octree - alt.cs\":99-111 -- lower maxDepth)");
+        o->failed = 1;
+        return;
+    }
     if (nd->npolys == nd->cap) {
-        nd->cap = nd->cap ? nd->cap * 2 : 8;
-        nd->polys = (int32_t *)realloc(nd->polys, (size_t)nd->cap * sizeof(int32_t));
+        const int32_t ncap = nd->cap ? nd->cap * 2 : 8;
+        if (ho_grow((void **)&nd->polys, (size_t)ncap * sizeof(int32_t))) { o->failed = 1; return; }
+        nd->cap = ncap;
     }
     nd->polys[nd->npolys++] = p;
+    o->live_items++;
 }
 
 /* BuildOctree: "Octree - alt.cs":91-138 */
 static void build(ho_octree *o, int32_t ni, int depth)
 {
+    if (o->failed) return;
     if (depth >= o->max_depth || o->nodes[ni].npolys <= o->max_polys) return;
 
     double nmin[3], nmax[3], center[3];
@@ -68,6 +88,7 @@ static void build(ho_octree *o, int32_t ni, int depth)
             mx[a] = ((i & bit[a]) == 0 ? center[a] : nmax[a]) + 0.1;
         }
         int32_t c = new_node(o, mn, mx);
+        if (c < 0) return;              /* budget / memory: the eight children are not all there, leave the node a leaf */
         if (i == 0) first = c;
     }
     o->nodes[ni].first_child = first;
@@ -78,10 +99,12 @@ static void build(ho_octree *o, int32_t ni, int depth)
         for (int c = 0; c < 8; ++c) {
             onode *ch = &o->nodes[first + c];
             if (ho_poly_box_overlap(ch->bmin, ch->bmax, T->verts + (size_t)pid * 12, T->nverts[pid]))
-                node_push(ch, pid);
+                node_push(o, ch, pid);
         }
+        if (o->failed) return;
         /* polygons that overlap no child are dropped (lostpolys is never used, :116,:129) */
     }
+    o->live_items -= o->nodes[ni].npolys;
     free(o->nodes[ni].polys); /* node.Polygons.Clear() */
     o->nodes[ni].polys = NULL;
     o->nodes[ni].npolys = 0;
@@ -96,6 +119,7 @@ static void build(ho_octree *o, int32_t ni, int depth)
 ho_octree *ho_octree_build(const ho_topology *models, int32_t M, int32_t max_depth, int32_t max_polys)
 {
     ho_octree *o = (ho_octree *)calloc(1, sizeof *o);
+    if (!o) { ho_set_error("oracle: out of memory"); return NULL; }
     o->max_depth = max_depth;
     o->max_polys = max_polys;
     o->model0 = &models[0];
@@ -119,9 +143,16 @@ ho_octree *ho_octree_build(const ho_topology *models, int32_t M, int32_t max_dep
         /* a fresh root per topology: drop what an earlier topology built */
         for (int32_t i = 0; i < o->n; ++i) free(o->nodes[i].polys);
         o->n = 0;
+        o->live_items = 0;
         int32_t root = new_node(o, mn, mx);
-        for (int32_t i = 0; i < T->P; ++i) node_push(&o->nodes[root], i);
-        build(o, root, 0);
+        if (root >= 0) {
+            for (int32_t i = 0; i < T->P; ++i) node_push(o, &o->nodes[root], i);
+            build(o, root, 0);
+        }
+        if (o->failed) {
+            ho_octree_free(o);
+            return NULL;
+        }
     }
     return o;
 }
@@ -213,6 +244,7 @@ int ho_octree_shoot(const ho_octree *o, const ho_topology *models, const ho_ray 
 
     int scap = 8 * (o->max_depth + 2);
     sentry *stack = (sentry *)malloc((size_t)scap * sizeof(sentry));
+    if (!stack) { ho_set_error("oracle: out of memory"); miss(out); return 0; }
     int sp = 0;
     stack[sp].node = 0;
     stack[sp].tmin = tmin;
@@ -277,8 +309,12 @@ int ho_octree_shoot(const ho_octree *o, const ho_topology *models, const ho_ray 
                 double childTmax = ho_dotnet_min(ho_dotnet_min(cTx1, cTy1), cTz1);
                 if (childTmax < childTmin || childTmax < 0 || childTmin > nodeTmax || childTmax < nodeTmin) continue;
                 if (sp == scap) {
+                    if (ho_grow((void **)&stack, (size_t)scap * 2 * sizeof(sentry))) {     /* cannot continue this ray: report the failure as a miss */
+                        free(stack);
+                        miss(out);
+                        return 0;
+                    }
                     scap *= 2;
-                    stack = (sentry *)realloc(stack, (size_t)scap * sizeof(sentry));
                 }
                 stack[sp].node = ci;
                 stack[sp].tmin = ho_dotnet_max(childTmin, nodeTmin);

@@ -607,3 +607,23 @@ void ho_reflect_batch(const ho_topology *T, int64_t n, const ho_ray *rays, const
         else out[i] = rays[i];
     }
 }
+
+
+/* ---- allocation failures and budgets (hare_oracle.h) ---- */
+static __thread char ho_err[256];
+const char *ho_last_error(void) { return ho_err; }
+void ho_set_error(const char *msg)
+{
+    strncpy(ho_err, msg ? msg : "", sizeof ho_err - 1);
+    ho_err[sizeof ho_err - 1] = 0;
+}
+int ho_grow(void **p, size_t bytes)
+{
+    void *q = realloc(*p, bytes ? bytes : 1);
+    if (!q) {
+        ho_set_error("oracle: out of memory");
+        return -1;
+    }
+    *p = q;
+    return 0;
+}

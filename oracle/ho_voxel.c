@@ -60,23 +60,49 @@ static void grid_set_ct(ho_voxel_grid *g, int32_t ct)
     g->char_step = (vd[0] < vd[1]) ? ((vd[0] < vd[2]) ? vd[0] : vd[2]) : (vd[1] < vd[2] ? vd[1] : vd[2]);
 }
 
+/* An allocation that fails during a grid build sets this (thread-local) flag and the build goes on without writing; the
+ * builders look at it before they return and hand back NULL instead of a grid (ho_last_error() says why). */
+static __thread int vox_failed;
 typedef struct ilist { int32_t *v; uint32_t n, cap; } ilist;
 static void il_push(ilist *l, int32_t x)
 {
+    if (vox_failed) return;
     if (l->n == l->cap) {
-        l->cap = l->cap ? l->cap * 2 : 8;
-        l->v = (int32_t *)realloc(l->v, l->cap * sizeof(int32_t));
+        const uint32_t ncap = l->cap ? l->cap * 2 : 8;
+        if (ho_grow((void **)&l->v, (size_t)ncap * sizeof(int32_t))) { vox_failed = 1; return; }
+        l->cap = ncap;
     }
     l->v[l->n++] = x;
+}
+static void *vox_calloc(size_t n, size_t size)
+{
+    void *p = calloc(n ? n : 1, size);
+    if (!p) {
+        ho_set_error("oracle voxel grid: out of memory");
+        vox_failed = 1;
+    }
+    return p;
 }
 
 static void lists_to_csr(ilist *lists, size_t ncell, uint32_t **start_out, int32_t **items_out)
 {
+    *start_out = NULL;
+    *items_out = NULL;
     uint32_t *start = (uint32_t *)malloc((ncell + 1) * sizeof(uint32_t));
     size_t tot = 0;
+    for (size_t c = 0; c < ncell; ++c) tot += lists[c].n;
+    int32_t *items = (int32_t *)malloc((tot ? tot : 1) * sizeof(int32_t));
+    if (!start || !items || tot > 0xFFFFFFF0u) {
+        ho_set_error(tot > 0xFFFFFFF0u ? "oracle voxel grid: more than 2^32 list entries" : "oracle voxel grid: out of memory");
+        vox_failed = 1;
+        free(start);
+        free(items);
+        for (size_t c = 0; c < ncell; ++c) free(lists[c].v);
+        return;
+    }
+    tot = 0;
     for (size_t c = 0; c < ncell; ++c) { start[c] = (uint32_t)tot; tot += lists[c].n; }
     start[ncell] = (uint32_t)tot;
-    int32_t *items = (int32_t *)malloc((tot ? tot : 1) * sizeof(int32_t));
     for (size_t c = 0; c < ncell; ++c) {
         if (lists[c].n) memcpy(items + start[c], lists[c].v, lists[c].n * sizeof(int32_t));
         free(lists[c].v);
@@ -94,18 +120,22 @@ static int cmp_i32(const void *a, const void *b)
 /* Voxel_Grid(Topology[], int Domain): Voxel_Grid.cs:48-121, Fill_Voxels :273-304. */
 ho_voxel_grid *ho_voxel_build(const ho_topology *models, int32_t M, int32_t domain, int build_mode)
 {
-    ho_voxel_grid *g = (ho_voxel_grid *)calloc(1, sizeof *g);
+    vox_failed = 0;
+    ho_voxel_grid *g = (ho_voxel_grid *)vox_calloc(1, sizeof *g);
+    if (!g) return NULL;
     g->M = M;
     grid_bounds(g, models, M);
     grid_set_ct(g, domain);
-    g->cell_start = (uint32_t **)calloc((size_t)M, sizeof(uint32_t *));
-    g->cell_items = (int32_t **)calloc((size_t)M, sizeof(int32_t *));
+    g->cell_start = (uint32_t **)vox_calloc((size_t)M, sizeof(uint32_t *));
+    g->cell_items = (int32_t **)vox_calloc((size_t)M, sizeof(int32_t *));
+    if (vox_failed) { ho_voxel_free(g); return NULL; }
     const int32_t ct = domain;
     const size_t ncell = (size_t)ct * ct * ct;
 
-    for (int32_t m = 0; m < M; ++m) {
+    for (int32_t m = 0; m < M && !vox_failed; ++m) {
         const ho_topology *T = &models[m];
-        ilist *lists = (ilist *)calloc(ncell, sizeof(ilist));
+        ilist *lists = (ilist *)vox_calloc(ncell, sizeof(ilist));
+        if (!lists) break;
         if (build_mode == 0) {
             /* literal: for every voxel, for every polygon (Voxel_Grid.cs:276-294) */
             for (int32_t x = 0; x < ct; ++x)
@@ -152,24 +182,36 @@ ho_voxel_grid *ho_voxel_build(const ho_topology *models, int32_t M, int32_t doma
         lists_to_csr(lists, ncell, &g->cell_start[m], &g->cell_items[m]);
         free(lists);
     }
+    if (vox_failed) { ho_voxel_free(g); return NULL; }
     return g;
 }
 
 /* Voxel_Grid(Topology[], int MaxDomain, int Avg_polys): Voxel_Grid.cs:128-254. */
 ho_voxel_grid *ho_voxel_build_adaptive(const ho_topology *models, int32_t M, int32_t max_domain, int32_t avg_polys)
 {
-    ho_voxel_grid *g = (ho_voxel_grid *)calloc(1, sizeof *g);
+    vox_failed = 0;
+    ho_voxel_grid *g = (ho_voxel_grid *)vox_calloc(1, sizeof *g);
+    if (!g) return NULL;
     g->M = M;
     grid_bounds(g, models, M);
-    g->cell_start = (uint32_t **)calloc((size_t)M, sizeof(uint32_t *));
-    g->cell_items = (int32_t **)calloc((size_t)M, sizeof(int32_t *));
+    g->cell_start = (uint32_t **)vox_calloc((size_t)M, sizeof(uint32_t *));
+    g->cell_items = (int32_t **)vox_calloc((size_t)M, sizeof(int32_t *));
 
     /* level "-1": one voxel holding every polygon (Voxel_Grid.cs:157-166) */
     int32_t ct = 1;
-    ilist **lv = (ilist **)calloc((size_t)M, sizeof(ilist *));
-    for (int32_t m = 0; m < M; ++m) {
-        lv[m] = (ilist *)calloc(1, sizeof(ilist));
+    ilist **lv = (ilist **)vox_calloc((size_t)M, sizeof(ilist *));
+    for (int32_t m = 0; m < M && !vox_failed; ++m) {
+        lv[m] = (ilist *)vox_calloc(1, sizeof(ilist));
+        if (!lv[m]) break;
         for (int32_t j = 0; j < models[m].P; ++j) il_push(&lv[m][0], j);
+    }
+    if (vox_failed) {
+        if (lv)
+            for (int32_t m = 0; m < M; ++m)
+                if (lv[m]) { free(lv[m][0].v); free(lv[m]); }
+        free(lv);
+        ho_voxel_free(g);
+        return NULL;
     }
     g->ct = 1; /* if max_domain == 0 the C# keeps the 1x1x1 grid with VoxelDims unset; treat ct=1 */
     grid_set_ct(g, 1);
@@ -182,7 +224,18 @@ ho_voxel_grid *ho_voxel_build_adaptive(const ho_topology *models, int32_t M, int
         for (int32_t m = 0; m < M; ++m) {
             const ho_topology *T = &models[m];
             size_t ncell = (size_t)nct * nct * nct;
-            ilist *nl = (ilist *)calloc(ncell, sizeof(ilist));
+            ilist *nl = (ilist *)vox_calloc(ncell, sizeof(ilist));
+            if (!nl) {            /* the finer level does not fit: give up cleanly (lists of the coarser level are freed below) */
+                for (int32_t mm = 0; mm < M; ++mm) {
+                    size_t oc = (size_t)(mm < m ? nct : ct);
+                    oc = oc * oc * oc;
+                    for (size_t c = 0; c < oc; ++c) free(lv[mm][c].v);
+                    free(lv[mm]);
+                }
+                free(lv);
+                ho_voxel_free(g);
+                return NULL;
+            }
             for (int32_t x = 0; x < nct; ++x)
                 for (int32_t y = 0; y < nct; ++y)
                     for (int32_t z = 0; z < nct; ++z) {
@@ -211,12 +264,19 @@ ho_voxel_grid *ho_voxel_build_adaptive(const ho_topology *models, int32_t M, int
         free(lv[m]);
     }
     free(lv);
+    if (vox_failed) { ho_voxel_free(g); return NULL; }
     return g;
 }
 
 void ho_voxel_free(ho_voxel_grid *g)
 {
     if (!g) return;
+    if (!g->cell_start || !g->cell_items) {
+        free(g->cell_start);
+        free(g->cell_items);
+        free(g);
+        return;
+    }
     for (int32_t m = 0; m < g->M; ++m) {
         free(g->cell_start[m]);
         free(g->cell_items[m]);

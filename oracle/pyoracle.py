@@ -83,6 +83,8 @@ def lib():
         L.ho_voxel_pool_new.argtypes = [vp, vp]
         L.ho_voxel_pool_free.argtypes = [vp]
         L.ho_voxel_pool_shoot.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+        L.ho_last_error.restype = C.c_char_p
+        L.ho_last_error.argtypes = []
         L.ho_octree_build.restype = vp
         L.ho_octree_build.argtypes = [vp, i32, i32, i32]
         L.ho_octree_free.argtypes = [vp]
@@ -173,6 +175,7 @@ class VoxelGrid:
             self.h = L.ho_voxel_build(self.models.arr, self.models.M, int(domain), int(build_mode))
         else:
             self.h = L.ho_voxel_build_adaptive(self.models.arr, self.models.M, int(max_domain), int(avg_polys))
+        _built(self.h)
         self.ct = int(L.ho_voxel_ct(self.h))
         self.char_step = float(L.ho_voxel_char_step(self.h))
         self.obox_min = np.zeros(3)
@@ -218,6 +221,13 @@ class VoxelGrid:
         return VoxelPool(self)
 
 
+def _built(handle):
+    """A builder returns NULL when an allocation failed or a tree outgrew its budget (hare_oracle.h): an exception, not a
+    segmentation fault in the next call."""
+    if not handle:
+        raise MemoryError((lib().ho_last_error() or b"oracle build failed").decode())
+
+
 class VoxelPool:
     """Faithful 500-slot mailbox pool (Voxel_Grid.cs:54-62, :334-342), single-threaded."""
 
@@ -244,6 +254,7 @@ class Octree:
         L = lib()
         self.models = _Models(topos)
         self.h = L.ho_octree_build(self.models.arr, self.models.M, int(max_depth), int(max_polys))
+        _built(self.h)
         self.n_nodes = int(L.ho_octree_node_count(self.h))
 
     def __del__(self):
@@ -283,6 +294,7 @@ class KDTree:
         L = lib()
         self.models = _Models(topos)
         self.h = L.ho_kdtree_build(self.models.arr, self.models.M, int(max_depth), int(max_polys))
+        _built(self.h)
         self.n_nodes = int(L.ho_kdtree_node_count(self.h))
 
     def __del__(self):
