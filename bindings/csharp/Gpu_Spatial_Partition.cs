@@ -170,12 +170,14 @@ namespace Hare
 
             /// <summary>Occlusion predicate for a batch (harness-defined; the reference has no any-hit call, its seam is
             /// Spatial_Partition.cs:32-33): occluded[i] = the closest hit of rays[i] exists and lies before t_max[i]
-            /// (t_max null: any hit).  Runs on the GPU like the batch Shoot.</summary>
+            /// (t_max null: any hit).  Runs on the GPU(s) like the batch Shoot, sharded over Devices.</summary>
             public bool[] Occluded(hare_ray[] rays, int top_index, double[] t_max = null, int[] poly_origin1 = null, int[] poly_origin2 = null)
             {
                 var occ = new int[rays.Length];
                 hare_counters ctr;
-                HareHip.Check(HareHip.hare_occluded_batch(scene, Kind, top_index, rays.Length, rays, poly_origin1, poly_origin2, t_max, 0u, occ, null, out ctr));
+                // every replica takes a contiguous shard, like the batch Shoot; no events: the kernels stop each ray once its flag is decided
+                HareHip.Check(HareHip.hare_occluded_batch_sharded(scenes, scenes.Length, Kind, top_index, rays.LongLength, rays, poly_origin1, poly_origin2,
+                                                                  t_max, 0u, occ, null, out ctr));
                 var res = new bool[rays.Length];
                 for (int i = 0; i < res.Length; i++) res[i] = occ[i] != 0;
                 return res;

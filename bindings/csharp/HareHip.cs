@@ -112,6 +112,12 @@ namespace Hare
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_occluded_batch(IntPtr scene, int kind, int top_index, long n, [In, Out] hare_ray[] rays, int[] excl1, int[] excl2,
                                                          double[] tmax, uint flags, [Out] int[] occluded, [Out] hare_xevent[] events, out hare_counters ctr);
+            /// <summary>The same over several scenes (one per device), contiguous shards; events may be null (flags only: the traversal
+            /// of a ray ends as soon as its flag is decided, 4 bytes per ray come back instead of 56).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_occluded_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n, [In] hare_ray[] rays,
+                                                                 int[] excl1, int[] excl2, double[] tmax, uint flags, [Out] int[] occluded,
+                                                                 [Out] hare_xevent[] events, out hare_counters ctr);
             /// <summary>Topology(Point[][]) ingest for hosts holding a raw polygon soup (include/hare_hip.h).</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_topology_ingest([In] double[] soup, [In] int[] nverts, int P, [Out] double[] verts_out,

@@ -89,6 +89,7 @@ SYMBOLS = {
     "hare_bounce_batch_sharded": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp]),
     "hare_occluded_device": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "hare_occluded_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "hare_occluded_batch_sharded": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -90,6 +90,11 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
         {"hare_occlusion", &m->occlusion},
+        {"hare_voxel_occl_tri", &m->voxel_occl_tri},
+        {"hare_voxel_occl_quad", &m->voxel_occl_quad},
+        {"hare_voxel_occl_tri_g", &m->voxel_occl_tri_g},
+        {"hare_voxel_occl_quad_g", &m->voxel_occl_quad_g},
+        {"hare_octree_occl", &m->octree_occl},
         {"hare_live_count", &m->live_count},
         {"hare_scan_tiles", &m->scan_tiles},
         {"hare_reflect_compact", &m->reflect_compact},
@@ -389,7 +394,8 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 //  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): from three fills (1 179 648 rays: -2 %
 //    there, -9 % at 1.5M, -20 % at 16M; +7 % at the 1M-ray headline, +17 ... +68 % from 65k to 524k).
 // Both thresholds scale with the CU count of the device the scene lives on.
-enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, OctSimple, OctCount, OctPool, OctPersist, KdSimple, KdCount, None };
+enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctOccl,
+                  KdSimple, KdCount, None };
 struct KernChoice {
     Kern k = Kern::None;
     const char* name = "";
@@ -401,7 +407,9 @@ constexpr bool kOctreePoolDefault = false;
 #define HARE_K2P_WAVES_PER_EU 4
 #endif
 
-KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, size_t top, int64_t n, uint32_t flags)
+// flags_only: an occlusion query without events (hare_occluded_* with events == NULL): the hare_*_occl kernels, which write the
+// flag and cut the traversal short; the simple kernels (counting, forced, kd-tree) write the flag after the full trace.
+KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, size_t top, int64_t n, uint32_t flags, bool flags_only = false)
 {
     KernChoice c;
     const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0, simple = (flags & HARE_SHOOT_SIMPLE_KERNEL) != 0;
@@ -425,6 +433,18 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             return c;
         }
         const bool coarse = s.occ_shift > 0;
+        if (flags_only) {
+            hipFunction_t DeviceModule::*of = !coarse ? (quads ? &DeviceModule::voxel_occl_quad : &DeviceModule::voxel_occl_tri)
+                                                       : (quads ? &DeviceModule::voxel_occl_quad_g : &DeviceModule::voxel_occl_tri_g);
+            if (have(of)) {
+                pick(Kern::VoxelOccl, !coarse ? (quads ? "hare_voxel_occl_quad" : "hare_voxel_occl_tri")
+                                              : (quads ? "hare_voxel_occl_quad_g" : "hare_voxel_occl_tri_g"), of);
+                return c;
+            }
+            if (quads) pick(Kern::VoxelSimple, "hare_voxel_shoot_quad", &DeviceModule::voxel_quad);
+            else pick(Kern::VoxelSimple, "hare_voxel_shoot_tri", &DeviceModule::voxel_tri);
+            return c;
+        }
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
         const bool pool_fits = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= kLdsMax && s.vox.ct <= 512 && !(flags & 0x4000u);
         const int64_t fill = (int64_t)cus * kPoolWaves * kPoolSlots;          // rays in flight when every pool of the chip is full
@@ -451,7 +471,12 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         if (count) { pick(Kern::OctCount, "hare_octree_shoot_count", &DeviceModule::octree_count); return c; }
         const int levels = std::max(1, s.oct_levels);
         const bool small_tree = (int64_t)s.oct.nodes.size() < (1 << 23);
-        if (!simple && !huge && small_tree) {
+        if (!simple && !huge && small_tree && flags_only) {
+            if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_occl)) {
+                pick(Kern::OctOccl, "hare_octree_occl", &DeviceModule::octree_occl);
+                return c;
+            }
+        } else if (!simple && !huge && small_tree) {
             const bool pool_wanted = s.opt.octree_kernel == 2 || (s.opt.octree_kernel == 0 && kOctreePoolDefault && n >= 65536);
             if (pool_wanted && have(&DeviceModule::octree_pool)) { pick(Kern::OctPool, "hare_octree_pool", &DeviceModule::octree_pool); return c; }
             if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist)) {
@@ -495,8 +520,22 @@ bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb)
 }
 
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
-                      const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st)
+                      const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st, const void* d_tmax,
+                      void* d_occ)
 {
+    if (d_out && d_occ) {
+        // events AND flags: the closest-hit cast as it is, then one compare per ray on the events it wrote (hare_occlusion)
+        int rc = shoot_device_impl(s, H, kind, top, n, d_rays, d_e1, d_e2, flags, d_out, d_ctr, st, nullptr, nullptr);
+        if (rc || n <= 0) return rc;
+        if (!s.module->occlusion) {
+            set_error("hare_occluded: kernel missing from code object");
+            return HARE_E_STATE;
+        }
+        const void* ev = d_out;
+        void* args[] = {&ev, &d_tmax, &d_occ, &n};
+        return launch(H, s.module->occlusion, (unsigned)((n + 255) / 256), 256, 0, st, args);
+    }
+    const bool flags_only = d_occ != nullptr;
     flags = sanitize_flags(s, flags);
     if (n < 0 || top < 0 || top >= (int32_t)s.topos.size()) {
         set_error("hare_shoot: bad n or top_index");
@@ -507,14 +546,20 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         set_error("hare_shoot: batch too large");
         return HARE_E_INVALID;
     }
-    if (!d_rays || !d_out) {
+    if (!d_rays || (!d_out && !d_occ)) {
         set_error("hare_shoot: null rays/out");
         return HARE_E_INVALID;
     }
+    if (flags_only) flags &= ~(uint32_t)SHOOT_WRITEBACK_ORIGIN & ~0xE000u;     // a predicate: rays are input only, no developer modes
     // A live ray's own X_Event slot is its scratch in the pool kernels, and rays[] is re-read while events are written: the
     // buffers of one call must not alias (each other, the exclusion arrays, or the counters)
     {
         const size_t rb = (size_t)n * sizeof(hare_ray), ob = (size_t)n * sizeof(hare_xevent), eb = (size_t)n * sizeof(int32_t);
+        if (ranges_overlap(d_rays, rb, d_occ, eb) || ranges_overlap(d_tmax, (size_t)n * 8, d_occ, eb) || ranges_overlap(d_e1, eb, d_occ, eb) ||
+            ranges_overlap(d_e2, eb, d_occ, eb) || ranges_overlap(d_ctr, sizeof(hare_counters), d_occ, eb)) {
+            set_error("hare_occluded: rays, exclusions, t_max, flags and counters must not overlap");
+            return HARE_E_INVALID;
+        }
         if (ranges_overlap(d_rays, rb, d_out, ob) || ranges_overlap(d_e1, eb, d_out, ob) || ranges_overlap(d_e2, eb, d_out, ob) ||
             ranges_overlap(d_ctr, sizeof(hare_counters), d_out, ob) || ranges_overlap(d_ctr, sizeof(hare_counters), d_rays, rb)) {
             set_error("hare_shoot: rays, exclusions, events and counters must not overlap");
@@ -529,6 +574,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.out = (XEventRec*)d_out;
     io.ctr = (unsigned long long*)d_ctr;
     io.work = (unsigned int*)s.d_work;
+    io.tmax = (const double*)d_tmax;
+    io.occluded = (int32_t*)d_occ;
     io.n = n;
     io.flags = flags;
     io.steps_per_round = 10;
@@ -574,7 +621,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             g.omax[a] = s.vox.omax[a];
             g.vd[a] = s.vox.vd[a];
         }
-        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags);
+        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
         if (!kc.f || (kc.k == Kern::VoxelAudit && quads)) {
             set_error(kc.k == Kern::VoxelAudit ? "hare_shoot: cull audit needs an all-triangle topology and the audit kernel"
                                                : "hare_shoot: kernel missing from code object");
@@ -594,7 +641,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args);
         }
         // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
-        unsigned per_cu = 4;
+        unsigned per_cu = kc.k == Kern::VoxelOccl ? 3 : 4;       // the occlusion build needs 131-136 VGPRs: three waves per SIMD are resident
         if (tune_blocks_per_cu) per_cu = tune_blocks_per_cu;
         if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(kLdsMax / lds));
         unsigned pgrid = cus * std::max(1u, per_cu);
@@ -638,7 +685,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
                       std::to_string(g.max_depth) + " levels)");
             return HARE_E_UNSUPPORTED;
         }
-        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags);
+        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
         if (!kc.f) {
             set_error("hare_shoot: octree kernel missing from code object");
             return HARE_E_STATE;
@@ -679,7 +726,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return rc;
         }
         void* args[] = {&g, &io};
-        if (kc.k == Kern::OctPersist) {
+        if (kc.k == Kern::OctPersist || kc.k == Kern::OctOccl) {
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
             const unsigned plds = (unsigned)g.max_depth * 256u * 20u;   // 20 bytes x levels x 256 lanes per workgroup (interval + child word)
@@ -716,7 +763,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.items = (const int32_t*)s.d_kd_items;
         g.n_nodes = (int32_t)s.kd.nodes.size();
         g.max_depth = s.kd.depth_reached;
-        hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags).f;
+        hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only).f;
         if (!f) {
             set_error("hare_shoot: kd-tree kernel missing from code object");
             return HARE_E_STATE;
@@ -878,7 +925,7 @@ void hare_scene_destroy(hare_scene* s)
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
                 if (x) { (void)H->StreamSynchronize(x); (void)H->StreamDestroy(x); x = nullptr; }
-            for (void** p : {&c.d_rays, &c.d_e1, &c.d_e2, &c.d_out, &c.d_ctr}) dev_free(H, *p);
+            for (void** p : {&c.d_rays, &c.d_e1, &c.d_e2, &c.d_out, &c.d_ctr, &c.d_tmax, &c.d_occ}) dev_free(H, *p);
         }
         for (int k = 0; k < kOctScratchRing; ++k) {
             dev_free(H, s->d_oct_scratch[k]);
@@ -1194,17 +1241,13 @@ int hare_shoot_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
     GUARD_END
 }
 
-int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays, const int32_t* excl1,
-                     const int32_t* excl2, uint32_t flags, hare_xevent* out, hare_counters* ctr)
+// hare_shoot_batch and hare_occluded_batch: host buffers in, host buffers out, pipelined over up to three chunks.
+//   out != null, occluded == null   closest-hit events (hare_shoot_batch)
+//   out != null, occluded != null   events and the occlusion flags derived from them
+//   out == null, occluded != null   flags only: the t_max-bounded kernels; 4 bytes per ray come back instead of 56
+static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays, const int32_t* excl1,
+                      const int32_t* excl2, uint32_t flags, hare_xevent* out, hare_counters* ctr, const double* tmax, int32_t* occluded)
 {
-    if (!s) {
-        set_error("null scene");
-        return HARE_E_INVALID;
-    }
-    if (n < 0 || (n > 0 && (!rays || !out))) {
-        set_error("hare_shoot_batch: bad arguments");
-        return HARE_E_INVALID;
-    }
     GUARD_BEGIN
     // host-buffer callers get the reference's meaning of poly_origin: an index that matches no polygon (any negative
     // value) excludes nothing.  Only the device-resident bounce loop (hare_reflect_device + hare_shoot_device) may
@@ -1234,13 +1277,21 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     } release{s, c};
     constexpr int kMaxChunks = 3;
     if (n > c->cap) {
-        for (void** p : {&c->d_rays, &c->d_e1, &c->d_e2, &c->d_out}) dev_free(H, *p);
+        for (void** p : {&c->d_rays, &c->d_e1, &c->d_e2, &c->d_out, &c->d_tmax, &c->d_occ}) dev_free(H, *p);
         c->cap = 0;
+        c->occ_cap = 0;
         HIP_TRY(H->Malloc(&c->d_rays, (size_t)n * sizeof(hare_ray)));
         HIP_TRY(H->Malloc(&c->d_e1, (size_t)n * sizeof(int32_t)));
         HIP_TRY(H->Malloc(&c->d_e2, (size_t)n * sizeof(int32_t)));
         HIP_TRY(H->Malloc(&c->d_out, (size_t)n * sizeof(hare_xevent)));
         c->cap = n;
+    }
+    if (occluded && n > c->occ_cap) {
+        for (void** p : {&c->d_tmax, &c->d_occ}) dev_free(H, *p);
+        c->occ_cap = 0;
+        HIP_TRY(H->Malloc(&c->d_tmax, (size_t)n * sizeof(double)));
+        HIP_TRY(H->Malloc(&c->d_occ, (size_t)n * sizeof(int32_t)));
+        c->occ_cap = n;
     }
     if (!c->d_ctr) HIP_TRY(H->Malloc(&c->d_ctr, kMaxChunks * sizeof(hare_counters)));
     // A large batch is pipelined as up to three chunks, each on its own stream and driven by its own host thread:
@@ -1260,15 +1311,19 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
         hare_ray* dr = (hare_ray*)c->d_rays + lo;
         int32_t* de1 = (int32_t*)c->d_e1 + lo;
         int32_t* de2 = (int32_t*)c->d_e2 + lo;
-        hare_xevent* dout = (hare_xevent*)c->d_out + lo;
+        hare_xevent* dout = out ? (hare_xevent*)c->d_out + lo : nullptr;
         hare_counters* dctr = (hare_counters*)c->d_ctr + k;
+        double* dtm = (occluded && tmax) ? (double*)c->d_tmax + lo : nullptr;
+        int32_t* docc = occluded ? (int32_t*)c->d_occ + lo : nullptr;
         HIP_TRY(H->MemcpyAsync(dr, rays + lo, (size_t)m * sizeof(hare_ray), hipMemcpyHostToDevice, st));
+        if (dtm) HIP_TRY(H->MemcpyAsync(dtm, tmax + lo, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
         if (excl1) HIP_TRY(H->MemcpyAsync(de1, excl1 + lo, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (excl2) HIP_TRY(H->MemcpyAsync(de2, excl2 + lo, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
         HIP_TRY(H->MemsetAsync(dctr, 0, sizeof(hare_counters), st));
-        const int r = shoot_device_impl(*s, H, kind, top_index, m, dr, excl1 ? de1 : nullptr, excl2 ? de2 : nullptr, flags, dout, dctr, st);
+        const int r = shoot_device_impl(*s, H, kind, top_index, m, dr, excl1 ? de1 : nullptr, excl2 ? de2 : nullptr, flags, dout, dctr, st, dtm, docc);
         if (r) return r;
-        HIP_TRY(H->MemcpyAsync(out + lo, dout, (size_t)m * sizeof(hare_xevent), hipMemcpyDeviceToHost, st));
+        if (out) HIP_TRY(H->MemcpyAsync(out + lo, dout, (size_t)m * sizeof(hare_xevent), hipMemcpyDeviceToHost, st));
+        if (occluded) HIP_TRY(H->MemcpyAsync(occluded + lo, docc, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         if (flags & HARE_SHOOT_WRITEBACK_ORIGIN)
             HIP_TRY(H->MemcpyAsync(rays + lo, dr, (size_t)m * sizeof(hare_ray), hipMemcpyDeviceToHost, st));
         HIP_TRY(H->MemcpyAsync(&parts[k], dctr, sizeof(hare_counters), hipMemcpyDeviceToHost, st));
@@ -1320,6 +1375,20 @@ int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, 
     }
     return HARE_OK;
     GUARD_END
+}
+
+int hare_shoot_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays, const int32_t* excl1,
+                     const int32_t* excl2, uint32_t flags, hare_xevent* out, hare_counters* ctr)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    if (n < 0 || (n > 0 && (!rays || !out))) {
+        set_error("hare_shoot_batch: bad arguments");
+        return HARE_E_INVALID;
+    }
+    return batch_impl(s, kind, top_index, n, rays, excl1, excl2, flags, out, ctr, nullptr, nullptr);
 }
 
 int hare_shoot_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n,
@@ -1456,7 +1525,7 @@ int hare_occluded_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t
         set_error("null scene");
         return HARE_E_INVALID;
     }
-    if (n < 0 || (n > 0 && (!d_events || !d_occluded))) {
+    if (n < 0 || (n > 0 && !d_occluded)) {
         set_error("hare_occluded_device: bad arguments");
         return HARE_E_INVALID;
     }
@@ -1468,16 +1537,9 @@ int hare_occluded_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t
         int rc = ensure_device(*s, H);
         if (rc) return rc;
     }
-    int rc = shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_events, d_counters, (hipStream_t)stream);
-    if (rc || n == 0) return rc;
-    if (!s->module->occlusion) {
-        set_error("hare_occluded_device: kernel missing from code object");
-        return HARE_E_STATE;
-    }
-    const void* ev = d_events;
-    void* args[] = {&ev, &d_tmax, &d_occluded, &n};
-    const unsigned block = 256;
-    return launch(H, s->module->occlusion, (unsigned)((n + block - 1) / block), block, 0, (hipStream_t)stream, args);
+    // with events: the closest-hit cast + one compare per ray; without: the flags-only kernels, whose walk ends at t_max
+    return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_events, d_counters, (hipStream_t)stream, d_tmax,
+                             d_occluded);
     GUARD_END
 }
 
@@ -1493,16 +1555,64 @@ int hare_occluded_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t 
         set_error("hare_occluded_batch: bad arguments");
         return HARE_E_INVALID;
     }
-    GUARD_BEGIN
-    std::vector<hare_xevent> tmp;
-    if (!events && n > 0) {
-        tmp.resize((size_t)n);
-        events = tmp.data();
+    return batch_impl(s, kind, top_index, n, rays, excl1, excl2, flags & ~HARE_SHOOT_WRITEBACK_ORIGIN, events, ctr, tmax, occluded);
+}
+
+int hare_occluded_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays,
+                                const int32_t* excl1, const int32_t* excl2, const double* tmax, uint32_t flags, int32_t* occluded,
+                                hare_xevent* events, hare_counters* ctr)
+{
+    if (!scenes || n_scenes < 1 || n_scenes > 64) {
+        set_error("hare_occluded_batch_sharded: need 1..64 scenes");
+        return HARE_E_INVALID;
     }
-    const int rc = hare_shoot_batch(s, kind, top_index, n, rays, excl1, excl2, flags, events, ctr);   // the GPU does the casting
-    if (rc) return rc;
-    for (int64_t i = 0; i < n; ++i)     // the predicate itself: closest hit before t_max
-        occluded[i] = (events[i].hit != 0 && (!tmax || events[i].t < tmax[i])) ? 1 : 0;
+    for (int32_t k = 0; k < n_scenes; ++k)
+        if (!scenes[k]) {
+            set_error("hare_occluded_batch_sharded: null scene");
+            return HARE_E_INVALID;
+        }
+    if (n < 0 || (n > 0 && (!rays || !occluded))) {
+        set_error("hare_occluded_batch_sharded: bad arguments");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    if (ctr) memset(ctr, 0, sizeof *ctr);
+    const int G = n_scenes;
+    std::vector<int> rcs((size_t)G, HARE_OK);
+    std::vector<std::string> errs((size_t)G);
+    std::vector<hare_counters> parts((size_t)G);
+    auto shard = [&](int k) {
+        const int64_t lo = (int64_t)((__int128)n * k / G), hi = (int64_t)((__int128)n * (k + 1) / G);
+        memset(&parts[(size_t)k], 0, sizeof(hare_counters));
+        rcs[(size_t)k] = hare_occluded_batch(scenes[k], kind, top_index, hi - lo, rays + lo, excl1 ? excl1 + lo : nullptr,
+                                             excl2 ? excl2 + lo : nullptr, tmax ? tmax + lo : nullptr, flags, occluded + lo,
+                                             events ? events + lo : nullptr, &parts[(size_t)k]);
+        if (rcs[(size_t)k] != HARE_OK) errs[(size_t)k] = hare_last_error();     // thread-local: carry it to the caller's thread
+    };
+    std::vector<std::thread> workers;
+    workers.reserve((size_t)G);
+    for (int k = 1; k < G; ++k) {
+        try {
+            workers.emplace_back(shard, k);
+        } catch (...) {
+            shard(k);                // no thread to be had: run the shard here
+        }
+    }
+    shard(0);
+    for (auto& w : workers) w.join();
+    for (int k = 0; k < G; ++k)
+        if (rcs[(size_t)k] != HARE_OK) {
+            set_error("shard " + std::to_string(k) + ": " + errs[(size_t)k]);
+            return rcs[(size_t)k];
+        }
+    if (ctr)
+        for (int k = 0; k < G; ++k) {
+            ctr->rays += parts[(size_t)k].rays;
+            ctr->hits += parts[(size_t)k].hits;
+            ctr->cells += parts[(size_t)k].cells;
+            ctr->entries += parts[(size_t)k].entries;
+            ctr->tests += parts[(size_t)k].tests;
+        }
     return HARE_OK;
     GUARD_END
 }

@@ -199,6 +199,11 @@ struct ShootIO {
     // persistent voxel kernel: rays in every wave's static first chunk (a multiple of 32, <= 128): the host shrinks it for
     // batches too small to give every wave of the grid 128 rays -- idle waves cost more than a shorter static share
     int32_t static_rays;
+    // occlusion predicate (hare_occluded_*; harness-defined): occluded[i] = Shoot(rays[i]) hits AND that closest
+    // hit has t < tmax[i] (tmax null: any hit).  With `occluded` set and `out` null the kernels write only the flag; the
+    // hare_*_occl_* kernels then also cut the traversal short where that cannot change the flag (kernels.hip).
+    const double* tmax;        // nullable
+    int32_t* occluded;         // nullable: n flags
 };
 
 }  // namespace hare

@@ -163,7 +163,12 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
         const int e2 = io.excl2 ? io.excl2[i] : -1;
         live = !(e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS));   // a ray the bounce loop retired (hare_reflect); else -2 is an ordinary "none"
         const bool moved = live && trace_voxel<QUADS, COUNT>(g, o, d, e1, e2, ev, w);
-        io.out[i] = ev;
+        if (io.out) io.out[i] = ev;
+        if (io.occluded) {
+            const bool occ = ev.hit != 0 && (io.tmax == nullptr || ev.t < io.tmax[i]);
+            io.occluded[i] = occ ? 1 : 0;
+            if (!io.out) ev.hit = occ ? 1 : 0;        // flags only: the batch counter `hits` counts occluded rays
+        }
         if (moved && (io.flags & SHOOT_WRITEBACK_ORIGIN)) {
             io.rays[i].x = o.x;
             io.rays[i].y = o.y;
@@ -200,7 +205,15 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 #define HARE_K1P_STEPS 10
 #define HARE_K1P_CULLS 4
 #endif
-template <bool QUADS, bool COARSE, bool PROF = false, int STEPS = HARE_K1P_STEPS, int CULLS = HARE_K1P_CULLS>
+// OCC (hare_voxel_occl_*): the occlusion predicate instead of the X_Event.  The flag is "Shoot hits and the returned t is below
+// t_max", so the walk may stop as soon as that is decided: a hit the reference would RETURN needs its point inside a voxel
+// the walk reaches (Voxel_Grid.cs:705), and a polygon whose hit point lies in a voxel is in that voxel's list -- so every hit
+// not found yet lies in the current voxel or beyond.  The current voxel was entered through the padded face of the previous
+// one at parameter te; the next voxel's own padded box starts 2 mm before that face, i.e. at te - 0.002 / |d_axis|.  Once
+// that is beyond t_max - t_start, and no hit below t_max is pending, nothing the rest of the walk finds can be below t_max:
+// not occluded.  (Margins: 2.5 mm instead of 2, and t_max + 1e-9 relative, so that rounding can only make the walk longer;
+// a pending hit is never acted on before the reference would confirm it, leaving the grid stays a miss: F12.)
+template <bool QUADS, bool COARSE, bool PROF = false, int STEPS = HARE_K1P_STEPS, int CULLS = HARE_K1P_CULLS, bool OCC = false>
 __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -301,6 +314,8 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     double tmin = kDblMax;
     int pid = -1;
     unsigned int nhits = 0, nrays = 0;
+    double occ_tstart = 0, occ_lim = kDblMax;      // OCC only: t_start of a clipped origin; t_max - t_start with its margin
+    const double occ_px = 0.0025 / g.vd[0], occ_py = 0.0025 / g.vd[1], occ_pz = 0.0025 / g.vd[2];   // OCC only (wave-uniform)
 
     // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the ones
     // this ray has just tested is exact; it replaces the reference's Poly_Ray_ID mailbox
@@ -310,6 +325,13 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
 #endif
     auto skip = [&](int i) { return i == e1 || i == e2 || (HARE_K1P_MAILBOX >= 1 && i == done1) || (HARE_K1P_MAILBOX >= 2 && i == done2); };
     auto finish = [&](bool hit) {
+        if (OCC) {       // the flag only: hit && (tmin + t_start) < t_max, the comparison hare_occlusion makes on the event's t
+            const bool occ = hit && (io.tmax == nullptr || (tmin + occ_tstart) < io.tmax[ray]);
+            io.occluded[ray] = occ ? 1 : 0;
+            if (occ) nhits++;
+            alive = false;
+            return;
+        }
         XEventRec ev;
         if (hit) {
             double t_start = 0;
@@ -391,6 +413,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     parked = false;
                     moved = false;
                     alive = true;
+                    if (OCC) occ_tstart = 0;
                     if (e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {           // retired by the bounce loop: miss, not counted
                         finish(false);
                     } else {
@@ -405,7 +428,8 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                                 finish(false);
                             } else {
                                 moved = true;
-                                io.out[ray].t = t_start;          // read back by finish(); keeps 2 VGPRs free
+                                if (OCC) occ_tstart = t_start;
+                                else io.out[ray].t = t_start;     // read back by finish(); keeps 2 VGPRs free
                                 if (io.flags & SHOOT_WRITEBACK_ORIGIN) {
                                     io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z;
                                 }
@@ -423,6 +447,13 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                             dcx = dx1 * ct * ct; dcy = dy1 * ct; dcz = dz1;
                             dfx = (float)d.x; dfy = (float)d.y; dfz = (float)d.z;
                             dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                            if (OCC) {
+                                occ_lim = kDblMax;                           // no t_max: only the walk's own end decides
+                                if (io.tmax) {
+                                    const double tl = io.tmax[ray] - occ_tstart;
+                                    occ_lim = tl + (fabs(tl) * 1e-9 + 1e-12);   // NaN t_max: every comparison below is false, the walk runs its course
+                                }
+                            }
                             if (d.x < 0) { tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
                             else         { tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
                             if (d.y < 0) { tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
@@ -471,6 +502,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     const bool sy = (!cxy) & cyz;
                     const bool sz = !(sx | sy);
                     const double nX = tMaxX + tDeltaX, nY = tMaxY + tDeltaY, nZ = tMaxZ + tDeltaZ;
+                    const double te = OCC ? (sx ? tMaxX : (sy ? tMaxY : tMaxZ)) : 0.0;     // parameter at which the next voxel is entered
                     X += sx ? dx1 : 0;
                     Y += sy ? dy1 : 0;
                     Z += sz ? dz1 : 0;
@@ -479,7 +511,13 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     tMaxZ = sz ? nZ : tMaxZ;
                     cell += sx ? dcx : (sy ? dcy : dcz);
                     const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
-                    if (out) finish(false);     // leaving the grid: miss, even with a pending hit (F12)
+                    bool beyond = false;
+                    if (OCC) {
+                        // entered through the stepped axis' padded face at te (the tMax just consumed); 0.0025 / |d_axis| = 0.0025 * tDelta / vd
+                        const double pad = sx ? tDeltaX * occ_px : (sy ? tDeltaY * occ_py : tDeltaZ * occ_pz);
+                        beyond = (pid < 0 || tmin > occ_lim) && (te - pad > occ_lim);
+                    }
+                    if (out | beyond) finish(false);     // leaving the grid: miss, even with a pending hit (F12); beyond t_max: not occluded
                     else enter_cell();
                 }
             }
@@ -638,7 +676,12 @@ __device__ __forceinline__ void octree_shoot_body(const OctreeArgs& g, const Sho
         const int e2 = io.excl2 ? io.excl2[i] : -1;
         live = !(e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS));
         if (live) trace_octree<COUNT, !COUNT>(g, fr, threadIdx.x, blockDim.x, o, d, e1, e2, ev, w);
-        io.out[i] = ev;
+        if (io.out) io.out[i] = ev;
+        if (io.occluded) {
+            const bool occ = ev.hit != 0 && (io.tmax == nullptr || ev.t < io.tmax[i]);
+            io.occluded[i] = occ ? 1 : 0;
+            if (!io.out) ev.hit = occ ? 1 : 0;        // flags only: the batch counter `hits` counts occluded rays
+        }
     }
     flush_counters(io.ctr, valid && live, ev.hit != 0, w, COUNT);
 }
@@ -664,6 +707,13 @@ __device__ __forceinline__ void octree_shoot_body(const OctreeArgs& g, const Sho
 __device__ __forceinline__ double omax(double a, double b) { return (b < a || a != a) ? a : b; }   // NaN-propagating like Math.Max
 __device__ __forceinline__ double omin(double a, double b) { return (a < b || a != a) ? a : b; }
 
+// OCC (hare_octree_occl): the occlusion predicate instead of the X_Event.  Octree.Shoot has no pending-hit rule: the first hit
+// found already makes Hit true and the returned t can only get smaller, so the walk stops at the first hit below t_max (the
+// classic any-hit early out, exact here).  What is NOT exact, and therefore not done: skipping nodes whose entry lies beyond
+// t_max.  The reference pops the FAR children first and returns early as soon as a hit lies in front of the current leaf's
+// entry ("Octree - alt.cs":233), so a far leaf can end the query with a hit beyond t_max (not occluded) that a
+// walk without that leaf would replace by a nearer one (occluded): the flag would differ from the reference's closest hit.
+template <bool OCC>
 __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -721,6 +771,13 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     unsigned int nhits = 0, nrays = 0;
 
     auto finish = [&]() {
+        if (OCC) {
+            const bool occ = hit && (io.tmax == nullptr || closestT < io.tmax[ray]);
+            io.occluded[ray] = occ ? 1 : 0;
+            if (occ) nhits++;
+            alive = false;
+            return;
+        }
         XEventRec ev;
         if (hit) {
             ev.t = closestT; ev.u = bu; ev.v = bv;
@@ -976,6 +1033,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         closestT = t; bu = u; bv = v; pid = i;
                         hit = true;
                         if (closestT <= leaf_ca) finish();                                // :233
+                        else if (OCC && (io.tmax == nullptr || closestT < io.tmax[ray])) finish();   // any hit below t_max decides the flag
                     }
                 }
             }
@@ -1006,7 +1064,12 @@ __device__ __forceinline__ void kdtree_shoot_body(const KdArgs& g, const ShootIO
         const int e2 = io.excl2 ? io.excl2[i] : -1;
         live = !(e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS));
         if (live) trace_kdtree<COUNT>(g, stack, threadIdx.x, blockDim.x, o, d, e1, e2, ev, w);
-        io.out[i] = ev;
+        if (io.out) io.out[i] = ev;
+        if (io.occluded) {
+            const bool occ = ev.hit != 0 && (io.tmax == nullptr || ev.t < io.tmax[i]);
+            io.occluded[i] = occ ? 1 : 0;
+            if (!io.out) ev.hit = occ ? 1 : 0;        // flags only: the batch counter `hits` counts occluded rays
+        }
     }
     flush_counters(io.ctr, valid && live, ev.hit != 0, w, COUNT);
 }
@@ -1038,6 +1101,12 @@ __global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, Shoo
 __global__ __launch_bounds__(256) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
 __global__ __launch_bounds__(256) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
 
+// the occlusion predicate on K1p's walk, cut short at t_max (flags only: ShootIO::occluded, ShootIO::tmax); same launch geometry
+__global__ __launch_bounds__(256) void hare_voxel_occl_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_occl_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_occl_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256) void hare_voxel_occl_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+
 // developer profiling build of the persistent kernel (phase stamps into ShootIO::prof)
 __global__ __launch_bounds__(256) void hare_voxel_persist_prof(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false, true>(g, io); }
 
@@ -1052,7 +1121,9 @@ __global__ __launch_bounds__(256) void hare_octree_shoot_count(OctreeArgs g, Sho
 #ifndef HARE_K2P_WAVES_PER_EU
 #define HARE_K2P_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body(g, io); }
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body<false>(g, io); }
+// the occlusion predicate on the same walk (flags only, any-hit early out); same launch geometry
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true>(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }

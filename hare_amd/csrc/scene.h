@@ -88,6 +88,7 @@ struct DeviceModule {
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
+    hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr;
     hipFunction_t live_count = nullptr, scan_tiles = nullptr, reflect_compact = nullptr, events_fill_miss = nullptr, events_expand = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
@@ -183,7 +184,10 @@ struct Scene {
         void* d_e2 = nullptr;
         void* d_out = nullptr;
         void* d_ctr = nullptr;
+        void* d_tmax = nullptr;      // occlusion queries: t_max per ray, flags per ray
+        void* d_occ = nullptr;
         int64_t cap = 0;
+        int64_t occ_cap = 0;
         bool busy = false;
     };
     static constexpr int kBatchCtx = 4;
@@ -214,8 +218,9 @@ void set_error(const std::string& msg);
 const char* last_error();
 
 // the launcher behind every shoot entry point (api.cpp)
+// d_occ != null: also (d_out != null) or only (d_out == null) the occlusion flags against d_tmax (nullable: any hit)
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays, const void* d_e1, const void* d_e2,
-                      uint32_t flags, void* d_out, void* d_ctr, hipStream_t st);
+                      uint32_t flags, void* d_out, void* d_ctr, hipStream_t st, const void* d_tmax = nullptr, void* d_occ = nullptr);
 uint32_t sanitize_flags(const Scene& s, uint32_t flags);
 int dev_free(const HipApi* H, void*& p);
 void free_bounce_buffers(const HipApi* H, Scene& s);          // bounce.cpp

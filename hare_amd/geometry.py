@@ -197,19 +197,22 @@ class Spatial_Partition:
         check(lib.hare_shoot_one(self._h, self._kind, int(top_index), ptr(ray6), int(poly_origin1), int(poly_origin2), ptr(ev)))
         return ev[0]
 
-    def Occluded_batch(self, rays, t_max=None, top_index: int = 0, poly_origin1=None, poly_origin2=None):
+    def Occluded_batch(self, rays, t_max=None, top_index: int = 0, poly_origin1=None, poly_origin2=None, events: bool = True,
+                       simple_kernel: bool = False):
         """Harness-defined occlusion predicate: closest hit exists and t < t_max (t_max None: any hit).
-        Returns (occluded int32[n], events)."""
+        Returns (occluded int32[n], events) -- or, with events=False, (occluded, counters): flags only, from the kernels that
+        end a ray's traversal as soon as its flag is decided (hits = number of occluded rays)."""
         rays = np.array(rays, np.float64, order="C").reshape(-1, 6)
         n = rays.shape[0]
         occ = np.zeros(n, np.int32)
-        out = np.zeros(n, XEVENT_DTYPE)
+        out = np.zeros(n, XEVENT_DTYPE) if events else None
         tm = None if t_max is None else np.ascontiguousarray(np.broadcast_to(np.asarray(t_max, np.float64), (n,)))
         e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
         e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
-        check(lib.hare_occluded_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), ptr(tm), 0,
-                                      ptr(occ), ptr(out), None))
-        return occ, out
+        ctr = capi.Counters()
+        check(lib.hare_occluded_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), ptr(tm),
+                                      capi.SHOOT_SIMPLE_KERNEL if simple_kernel else 0, ptr(occ), ptr(out), C.addressof(ctr)))
+        return (occ, out) if events else (occ, ctr.as_dict())
 
     def occluded_device(self, n: int, d_rays: int, d_events: int, d_occluded: int, d_tmax: int = 0, top_index: int = 0,
                         d_excl1: int = 0, d_excl2: int = 0, d_counters: int = 0, stream: int = 0, flags: int = 0):

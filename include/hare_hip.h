@@ -252,17 +252,28 @@ HARE_API int hare_shoot_one(hare_scene *s, int32_t kind, int32_t top_index, hare
 /* ---- occlusion predicate (harness-defined, SURVEY.md F13 / 8(a) A9: the reference has no any-hit API; the seam it
  * would sit beside is Spatial_Partition.cs:32-33) ----
  * occluded[i] = Shoot(rays[i]) hit something AND that closest hit has t < tmax[i]  (tmax NULL: any hit counts).
- * Defined on the CLOSEST hit so that it is pinned by the same oracle as Shoot, including the reference's
- * miss-on-grid-exit rule (Voxel_Grid.cs:716-757).  The closest-hit records themselves are returned in `events`
- * (device call: required, n x 56 B; host call: nullable). */
+ * Defined on the CLOSEST hit the reference's Shoot would return, so that it is pinned by the same oracle as Shoot, including
+ * the reference's miss-on-grid-exit rule (Voxel_Grid.cs:716-757) and the octree's early return ("Octree - alt.cs":233).
+ *   events != NULL   the closest-hit cast as hare_shoot_*, the X_Events returned, the flags derived from them
+ *   events == NULL   flags only, from kernels that stop a ray as soon as its flag is decided: the voxel walk ends when it has
+ *                    passed t_max without a hit below it pending (the pending-hit confirmation of Voxel_Grid.cs:705-709 is
+ *                    kept: a hit counts when the reference would return it); the octree walk ends at the first hit below
+ *                    t_max (no node is skipped for lying beyond t_max: with the reference's far-to-near order and early
+ *                    return that would change which hit is "the" hit).  The flags are identical either way; the host call
+ *                    then brings back 4 bytes per ray instead of 56.  counters: rays, and hits = number of occluded rays.
+ * rays[] is never written. */
 HARE_API int hare_occluded_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
                                   const void *d_excl1, const void *d_excl2, const void *d_tmax /* n doubles, nullable */,
-                                  uint32_t flags, void *d_events, void *d_occluded /* n int32 */, void *d_counters,
-                                  void *stream);
+                                  uint32_t flags, void *d_events /* n x 56 B, nullable */, void *d_occluded /* n int32 */,
+                                  void *d_counters, void *stream);
 HARE_API int hare_occluded_batch(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, hare_ray *rays,
                                  const int32_t *excl1, const int32_t *excl2, const double *tmax /* nullable */,
                                  uint32_t flags, int32_t *occluded, hare_xevent *events /* nullable */,
                                  hare_counters *ctr /* nullable */);
+/* the same over several devices from one process (contiguous ray shards, as hare_shoot_batch_sharded) */
+HARE_API int hare_occluded_batch_sharded(hare_scene *const *scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n,
+                                         hare_ray *rays, const int32_t *excl1, const int32_t *excl2, const double *tmax,
+                                         uint32_t flags, int32_t *occluded, hare_xevent *events, hare_counters *ctr);
 
 /* ---- specular bounce (harness-defined; the reference leaves reflection to its caller, which
  * re-shoots with poly_origin1 = the previous Poly_id -- Voxel_Grid.cs:351,477) ----

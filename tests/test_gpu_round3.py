@@ -175,3 +175,96 @@ def test_bounce_batch_edges_and_sharding():
     assert a.tobytes() == ref.tobytes() and b.tobytes() == ref.tobytes() and ca == cb
     with pytest.raises(H.HareError):
         g.Bounce_batch(rays, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The occlusion predicate without events: traversal ends as soon as a ray's flag is decided
+def _want(ref, tmax):
+    return ((ref["hit"] != 0) & (True if tmax is None else (ref["t"] < tmax))).astype(np.int32)
+
+
+@pytest.mark.parametrize("domain", [64, 128, 9])
+def test_bounded_occlusion_equals_the_closest_hit_predicate_voxel(hall, domain):
+    """t_max distributions from far too short to far too long, scaled to every ray's own hit distance and to the room's mean free
+    path; exactly at the hit (strict <); infinities, NaN, negatives; rays that start outside the grid (t includes the clip
+    distance).  Flags from the flags-only kernels == flags derived from the oracle's closest hit, on every ray."""
+    import torch
+    m, T, To = hall
+    n = 400_000
+    rays = H.scenes.burst_rays(n, m.size)
+    rng = np.random.default_rng(7)
+    rays[::5, :3] += rng.normal(0, 30.0, (len(rays[::5]), 3))           # a fifth of the origins far outside the grid
+    rays[1::5, :3] = rng.uniform(0, 1, (len(rays[1::5]), 3)) * np.asarray(m.size)
+    o = po.VoxelGrid([To], domain=domain)
+    ref, _ = o.shoot(rays, nthreads=16)
+    g = H.Voxel_Grid([T], domain)
+    mfp = float(np.median(ref["t"][ref["hit"] != 0]))
+    scale = rng.choice([0.02, 0.1, 0.25, 0.5, 0.9, 0.999999, 1.0, 1.000001, 1.1, 2.0, 10.0], n)
+    tmax = np.where(rng.random(n) < 0.5, ref["t"] * scale, mfp * scale * rng.random(n) * 2)
+    tmax[::101] = np.inf
+    tmax[7::101] = np.nan
+    tmax[13::101] = -1.0
+    tmax[19::101] = 0.0
+    want = _want(ref, tmax)
+    assert 0.2 < want.mean() < 0.8
+    assert g.kernel_name(n) .startswith("hare_voxel_p")                    # Shoot itself is untouched
+    occ, c = g.Occluded_batch(rays, tmax, events=False)
+    bad = np.nonzero(occ != want)[0]
+    assert bad.size == 0, (domain, bad[:5], tmax[bad[:5]], ref[bad[:5]])
+    assert (c["rays"], c["hits"]) == (n, int(want.sum()))
+    occ_any, _ = g.Occluded_batch(rays, None, events=False)               # no t_max: any hit
+    assert np.array_equal(occ_any, _want(ref, None))
+    occ_e, ev = g.Occluded_batch(rays, tmax)                               # with events: the closest-hit cast, identical flags
+    assert np.array_equal(occ_e, want) and ev.tobytes() == ref.tobytes()
+    occ_s, _ = g.Occluded_batch(rays[:50_000], tmax[:50_000], events=False, simple_kernel=True)
+    assert np.array_equal(occ_s, want[:50_000])
+    # device-resident form, no events buffer
+    d_rays = torch.from_numpy(rays).cuda()
+    d_tmax = torch.from_numpy(tmax).cuda()
+    d_occ = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    g.occluded_device(n, d_rays.data_ptr(), 0, d_occ.data_ptr(), d_tmax=d_tmax.data_ptr(), d_counters=d_ctr.data_ptr(),
+                      stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_occ.cpu().numpy(), want) and int(d_ctr[1]) == int(want.sum())
+    assert np.array_equal(d_rays.cpu().numpy(), rays)                     # a predicate: the rays are not touched
+
+
+def test_bounded_occlusion_quads_exclusions_and_trees():
+    v, nv, size = soup(n_tri=1500, n_quad=400, seed=9)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    n = 80_000
+    rays = soup_rays(n, size, seed=31)
+    rng = np.random.default_rng(3)
+    e1 = rng.integers(-3, len(nv), n).astype(np.int32)
+    e2 = rng.integers(-1, len(nv), n).astype(np.int32)
+    for name, g, o in (("voxel", H.Voxel_Grid([T], 20), po.VoxelGrid([To], domain=20)),
+                       ("octree", H.Octree([T], 5, 8), po.Octree([To], 5, 8)),
+                       ("kdtree", H.KDTree([T], 8, 8), po.KDTree([To], 8, 8))):
+        m_ = n if name != "kdtree" else 15_000
+        ref, _ = o.shoot(rays[:m_], excl1=e1[:m_], excl2=e2[:m_], nthreads=16)
+        tmax = ref["t"] * rng.choice([0.3, 0.999999, 1.0, 1.000001, 3.0], m_)
+        tmax[ref["hit"] == 0] = rng.uniform(0.1, 20.0, int((ref["hit"] == 0).sum()))
+        want = _want(ref, tmax)
+        assert 0.02 * m_ < want.sum() < 0.9 * m_, (name, want.mean())      # an open soup: most rays hit nothing
+        occ, c = g.Occluded_batch(rays[:m_], tmax, poly_origin1=e1[:m_], poly_origin2=e2[:m_], events=False)
+        bad = np.nonzero(occ != want)[0]
+        assert bad.size == 0, (name, bad[:5])
+        assert c["hits"] == int(want.sum())
+        occ_any, _ = g.Occluded_batch(rays[:m_], None, poly_origin1=e1[:m_], poly_origin2=e2[:m_], events=False)
+        assert np.array_equal(occ_any, _want(ref, None)), name
+
+
+def test_bounded_octree_occlusion_on_the_hall(hall):
+    """The octree's closest hit is the reference's, quirk included (far children first, early return: DESIGN.md F15) -- the
+    flags-only kernel stops at the first hit below t_max and must still agree with it on every ray."""
+    m, T, To = hall
+    n = 200_000
+    rays = H.scenes.burst_rays(n, m.size)
+    refo, _ = po.Octree([To], 8, 16).shoot(rays, nthreads=16)
+    rng = np.random.default_rng(12)
+    tmax = refo["t"] * rng.choice([0.1, 0.5, 0.999999, 1.0, 1.000001, 1.5, 4.0], n)
+    oc = H.Octree([T], 8, 16)
+    occ, c = oc.Occluded_batch(rays, tmax, events=False)
+    want = _want(refo, tmax)
+    assert np.array_equal(occ, want) and c["hits"] == int(want.sum())
