@@ -367,6 +367,7 @@ def measure(w, env):
     copy_gbs = None
     e2e = None
     e2e_slim = None
+    slim_ok = None
     bounce_batch = None
     if rank == 0:
         if w.get("copy_bw", True):
@@ -401,6 +402,23 @@ def measure(w, env):
                 dt = time.perf_counter() - t1
                 best = dt if best is None else min(best, dt)
             e2e = n / best / 1e6
+            # the same call with slim result records (HARE_SHOOT_SLIM_EVENTS): 16 B (trees: 32 B) per ray come back instead of 56
+            slim_dt = H.capi.SLIM_DTYPE if kind == "voxel" else H.capi.SLIM_UV_DTYPE
+            sl_h = np.zeros(n, slim_dt)
+
+            def host_call_slim():
+                H.capi.check(H.capi.lib.hare_shoot_batch(part._h, part._kind, 0, n, rays_h.ctypes.data, None, None, H.capi.SHOOT_SLIM_EVENTS,
+                                                         sl_h.ctypes.data, C.addressof(ctr_h)))
+
+            host_call_slim()
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                host_call_slim()
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            e2e_slim = n / best / 1e6
+            slim_ok = bool(part.expand_events(rays_h, sl_h).tobytes() == ev_h.tobytes())     # rebuilt X_Events == the full call's, byte for byte
         if B > 1 and w.get("bounce_api") == "batch" and hasattr(part, "Bounce_batch"):
             # the same loop through ONE C-ABI call from host buffers (hare_bounce_batch): H2D once, B casts and B-1 reflections on
             # the device, the final events D2H -- what a C# / Pachyderm caller without device pointers gets
@@ -540,6 +558,7 @@ def measure(w, env):
     }
     if e2e_slim is not None:
         line["end_to_end_slim_mrays_s"] = round(e2e_slim, 1)
+        line["slim_events_rebuild_identical"] = slim_ok
     if bounce_batch is not None:
         line["bounce_batch"] = bounce_batch
     del ray_sets, out_sets, d_rays, d_out, d_rays0, d_excl

@@ -16,14 +16,16 @@ LIB_PATH = os.environ.get("HARE_LIB") or os.path.join(_HERE, "libhare_hip.so")  
 HARE_OK = 0
 HARE_E_INVALID, HARE_E_NOMEM, HARE_E_HIP, HARE_E_NODEVICE, HARE_E_STATE, HARE_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 KIND_VOXEL, KIND_OCTREE, KIND_KDTREE = 0, 1, 2
-SHOOT_WRITEBACK_ORIGIN, SHOOT_COUNT_WORK, SHOOT_SIMPLE_KERNEL, SHOOT_RETIRED_RAYS = 1, 2, 4, 8
+SHOOT_WRITEBACK_ORIGIN, SHOOT_COUNT_WORK, SHOOT_SIMPLE_KERNEL, SHOOT_RETIRED_RAYS, SHOOT_SLIM_EVENTS = 1, 2, 4, 8, 16
 
 RAY_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("dx", "<f8"), ("dy", "<f8"), ("dz", "<f8")])
 XEVENT_DTYPE = np.dtype(
     [("t", "<f8"), ("u", "<f8"), ("v", "<f8"), ("x", "<f8"), ("y", "<f8"), ("z", "<f8"),
      ("poly_id", "<i4"), ("hit", "<i4")]
 )
-assert RAY_DTYPE.itemsize == 48 and XEVENT_DTYPE.itemsize == 56
+SLIM_DTYPE = np.dtype([("t", "<f8"), ("poly_id", "<i4"), ("hit", "<i4")])                                  # hare_slim_event (Voxel_Grid)
+SLIM_UV_DTYPE = np.dtype([("t", "<f8"), ("u", "<f8"), ("v", "<f8"), ("poly_id", "<i4"), ("hit", "<i4")])    # hare_slim_event_uv (trees)
+assert RAY_DTYPE.itemsize == 48 and XEVENT_DTYPE.itemsize == 56 and SLIM_DTYPE.itemsize == 16 and SLIM_UV_DTYPE.itemsize == 32
 
 
 class HareError(RuntimeError):
@@ -80,6 +82,7 @@ SYMBOLS = {
     "hare_kdtree_get_info": (C.c_int, [_vp, _vp]),
     "hare_kdtree_get_nodes": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hare_shoot_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "hare_expand_events": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp]),
     "hare_shoot_batch_sharded": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
     "hare_shoot_device": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "hare_reflect_device": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),

@@ -95,6 +95,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_occl_tri_g", &m->voxel_occl_tri_g},
         {"hare_voxel_occl_quad_g", &m->voxel_occl_quad_g},
         {"hare_octree_occl", &m->octree_occl},
+        {"hare_events_pack_slim", &m->events_pack_slim},
         {"hare_live_count", &m->live_count},
         {"hare_scan_tiles", &m->scan_tiles},
         {"hare_reflect_compact", &m->reflect_compact},
@@ -327,7 +328,7 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass on a scene whose
 // `dev` option is set (HARE_DEV=1 when the scene was created, or hare_scene_set_option), so a stray bit from a caller can
 // never reach a kernel.
-constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS;
+constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS | HARE_SHOOT_SLIM_EVENTS;
 uint32_t sanitize_flags(const Scene& s, uint32_t flags)
 {
     return flags & (kPublicFlags | (s.opt.dev ? 0xE000u : 0u));
@@ -641,7 +642,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args);
         }
         // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
-        unsigned per_cu = kc.k == Kern::VoxelOccl ? 3 : 4;       // the occlusion build needs 131-136 VGPRs: three waves per SIMD are resident
+#ifndef HARE_OCCL_WAVES_PER_EU
+#define HARE_OCCL_WAVES_PER_EU 4
+#endif
+        unsigned per_cu = kc.k == Kern::VoxelOccl ? HARE_OCCL_WAVES_PER_EU : 4;       // what the occlusion build is compiled for (kernels.hip)
         if (tune_blocks_per_cu) per_cu = tune_blocks_per_cu;
         if (lds) per_cu = std::min<unsigned>(per_cu, (unsigned)(kLdsMax / lds));
         unsigned pgrid = cus * std::max(1u, per_cu);
@@ -925,7 +929,7 @@ void hare_scene_destroy(hare_scene* s)
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
                 if (x) { (void)H->StreamSynchronize(x); (void)H->StreamDestroy(x); x = nullptr; }
-            for (void** p : {&c.d_rays, &c.d_e1, &c.d_e2, &c.d_out, &c.d_ctr, &c.d_tmax, &c.d_occ}) dev_free(H, *p);
+            for (void** p : {&c.d_rays, &c.d_e1, &c.d_e2, &c.d_out, &c.d_ctr, &c.d_tmax, &c.d_occ, &c.d_slim}) dev_free(H, *p);
         }
         for (int k = 0; k < kOctScratchRing; ++k) {
             dev_free(H, s->d_oct_scratch[k]);
@@ -1236,7 +1240,8 @@ int hare_shoot_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
         int rc = ensure_device(*s, H);
         if (rc) return rc;
     }
-    return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_out, d_counters,
+    // slim records are a format of the host-buffer calls (they are packed from the events in a staging buffer)
+    return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags & ~HARE_SHOOT_SLIM_EVENTS, d_out, d_counters,
                              (hipStream_t)stream);
     GUARD_END
 }
@@ -1277,7 +1282,7 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
     } release{s, c};
     constexpr int kMaxChunks = 3;
     if (n > c->cap) {
-        for (void** p : {&c->d_rays, &c->d_e1, &c->d_e2, &c->d_out, &c->d_tmax, &c->d_occ}) dev_free(H, *p);
+        for (void** p : {&c->d_rays, &c->d_e1, &c->d_e2, &c->d_out, &c->d_tmax, &c->d_occ, &c->d_slim}) dev_free(H, *p);
         c->cap = 0;
         c->occ_cap = 0;
         HIP_TRY(H->Malloc(&c->d_rays, (size_t)n * sizeof(hare_ray)));
@@ -1285,6 +1290,16 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
         HIP_TRY(H->Malloc(&c->d_e2, (size_t)n * sizeof(int32_t)));
         HIP_TRY(H->Malloc(&c->d_out, (size_t)n * sizeof(hare_xevent)));
         c->cap = n;
+    }
+    const bool slim = out && (flags & HARE_SHOOT_SLIM_EVENTS) != 0;
+    const bool slim_uv = kind != HARE_KIND_VOXEL;                 // the trees return u, v: 32-byte records
+    const size_t slim_bytes = slim_uv ? sizeof(hare_slim_event_uv) : sizeof(hare_slim_event);
+    if (slim) {
+        if (!s->module->events_pack_slim) {
+            set_error("hare_shoot_batch: slim-event kernel missing from code object");
+            return HARE_E_STATE;
+        }
+        if (!c->d_slim) HIP_TRY(H->Malloc(&c->d_slim, (size_t)c->cap * sizeof(hare_slim_event_uv)));
     }
     if (occluded && n > c->occ_cap) {
         for (void** p : {&c->d_tmax, &c->d_occ}) dev_free(H, *p);
@@ -1322,7 +1337,15 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
         HIP_TRY(H->MemsetAsync(dctr, 0, sizeof(hare_counters), st));
         const int r = shoot_device_impl(*s, H, kind, top_index, m, dr, excl1 ? de1 : nullptr, excl2 ? de2 : nullptr, flags, dout, dctr, st, dtm, docc);
         if (r) return r;
-        if (out) HIP_TRY(H->MemcpyAsync(out + lo, dout, (size_t)m * sizeof(hare_xevent), hipMemcpyDeviceToHost, st));
+        if (slim) {      // pack {t[, u, v], poly_id, hit} on the device; 16 (32) bytes per ray cross the link instead of 56
+            unsigned char* dsl = (unsigned char*)c->d_slim + (size_t)lo * slim_bytes;
+            const void* evp = dout;
+            long long mm = m;
+            int uv = slim_uv ? 1 : 0;
+            void* pargs[] = {&evp, &mm, &uv, &dsl};
+            if (int pr = launch(H, s->module->events_pack_slim, (unsigned)((m + 255) / 256), 256, 0, st, pargs)) return pr;
+            HIP_TRY(H->MemcpyAsync((unsigned char*)out + (size_t)lo * slim_bytes, dsl, (size_t)m * slim_bytes, hipMemcpyDeviceToHost, st));
+        } else if (out) HIP_TRY(H->MemcpyAsync(out + lo, dout, (size_t)m * sizeof(hare_xevent), hipMemcpyDeviceToHost, st));
         if (occluded) HIP_TRY(H->MemcpyAsync(occluded + lo, docc, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         if (flags & HARE_SHOOT_WRITEBACK_ORIGIN)
             HIP_TRY(H->MemcpyAsync(rays + lo, dr, (size_t)m * sizeof(hare_ray), hipMemcpyDeviceToHost, st));
@@ -1418,8 +1441,12 @@ int hare_shoot_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_
     auto shard = [&](int k) {
         const int64_t lo = (int64_t)((__int128)n * k / G), hi = (int64_t)((__int128)n * (k + 1) / G);
         memset(&parts[k], 0, sizeof parts[k]);
+        // with HARE_SHOOT_SLIM_EVENTS `out` is an array of 16- or 32-byte records, not of X_Events
+        const size_t rec = !(flags & HARE_SHOOT_SLIM_EVENTS) ? sizeof(hare_xevent)
+                                                              : (kind == HARE_KIND_VOXEL ? sizeof(hare_slim_event) : sizeof(hare_slim_event_uv));
+        hare_xevent* o_k = out ? reinterpret_cast<hare_xevent*>(reinterpret_cast<unsigned char*>(out) + (size_t)lo * rec) : nullptr;
         rcs[k] = hare_shoot_batch(scenes[k], kind, top_index, hi - lo, rays ? rays + lo : nullptr, excl1 ? excl1 + lo : nullptr,
-                                  excl2 ? excl2 + lo : nullptr, flags, out ? out + lo : nullptr, &parts[k]);
+                                  excl2 ? excl2 + lo : nullptr, flags, o_k, &parts[k]);
         if (rcs[k] != HARE_OK) errs[k] = hare_last_error();     // thread-local: carry it to the caller's thread
     };
     std::vector<std::thread> workers;
@@ -1487,6 +1514,69 @@ const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t to
     return choose_kernel(*s, s->module, kind, (size_t)top_index, n, sanitize_flags(*s, flags)).name;
 }
 
+// Slim records back to X_Events (include/hare_hip.h).  Same arithmetic as the kernels: hare_math.h is compiled for the host with
+// -ffp-contract=off, so o + d * t and AABB.Intersect's origin move give the bits the device gave.
+int hare_expand_events(const hare_scene* s, int32_t kind, int64_t n, const hare_ray* rays, const void* slim, hare_xevent* out)
+{
+    if (!s || n < 0 || (n > 0 && (!rays || !slim || !out)) || kind < HARE_KIND_VOXEL || kind > HARE_KIND_KDTREE) {
+        set_error("hare_expand_events: bad arguments");
+        return HARE_E_INVALID;
+    }
+    if (kind == HARE_KIND_VOXEL && !s->vox.built) {
+        set_error("hare_expand_events: voxel grid not built");
+        return HARE_E_STATE;
+    }
+    GUARD_BEGIN
+    auto body = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            hare_xevent e;
+            memset(&e, 0, sizeof e);
+            e.poly_id = -1;
+            const hare_ray& r = rays[i];
+            if (kind == HARE_KIND_VOXEL) {
+                const hare_slim_event& q = static_cast<const hare_slim_event*>(slim)[i];
+                if (q.hit == 1) {
+                    e.t = q.t;
+                    e.x = r.x + r.dx * q.t; e.y = r.y + r.dy * q.t; e.z = r.z + r.dz * q.t;      // Polygons.cs:652
+                    e.poly_id = q.poly_id;
+                    e.hit = 1;
+                } else if (q.hit == 2) {      // the origin was moved: redo AABB.Intersect (AABB_Main.cs:173-260), then both sums
+                    V3 o = {r.x, r.y, r.z};
+                    const V3 d = {r.dx, r.dy, r.dz};
+                    double t_start = 0;
+                    (void)aabb_clip_move(s->vox.omin, s->vox.omax, o, d, t_start);
+                    e.t = q.t + t_start;                                                           // Voxel_Grid.cs:707
+                    e.x = o.x + d.x * q.t; e.y = o.y + d.y * q.t; e.z = o.z + d.z * q.t;
+                    e.poly_id = q.poly_id;
+                    e.hit = 1;
+                }
+            } else {
+                const hare_slim_event_uv& q = static_cast<const hare_slim_event_uv*>(slim)[i];
+                if (q.hit != 0) {
+                    e.t = q.t; e.u = q.u; e.v = q.v;
+                    e.x = r.x + r.dx * q.t; e.y = r.y + r.dy * q.t; e.z = r.z + r.dz * q.t;
+                    e.poly_id = q.poly_id;
+                    e.hit = 1;
+                }
+            }
+            out[i] = e;
+        }
+    };
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::thread::hardware_concurrency(), 16, n / 65536}));
+    std::vector<std::thread> th;
+    for (int64_t k = 1; k < nt; ++k) {
+        try {
+            th.emplace_back(body, n * k / nt, n * (k + 1) / nt);
+        } catch (...) {
+            body(n * k / nt, n * (k + 1) / nt);
+        }
+    }
+    body(0, n / nt);
+    for (auto& t : th) t.join();
+    return HARE_OK;
+    GUARD_END
+}
+
 // Diagnostics / A-B switches of one scene (SceneOptions, scene.h).  Not thread-safe against shoots in flight on the scene.
 int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
 {
@@ -1538,8 +1628,8 @@ int hare_occluded_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t
         if (rc) return rc;
     }
     // with events: the closest-hit cast + one compare per ray; without: the flags-only kernels, whose walk ends at t_max
-    return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags, d_events, d_counters, (hipStream_t)stream, d_tmax,
-                             d_occluded);
+    return shoot_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, flags & ~HARE_SHOOT_SLIM_EVENTS, d_events, d_counters,
+                             (hipStream_t)stream, d_tmax, d_occluded);
     GUARD_END
 }
 
@@ -1555,7 +1645,8 @@ int hare_occluded_batch(hare_scene* s, int32_t kind, int32_t top_index, int64_t 
         set_error("hare_occluded_batch: bad arguments");
         return HARE_E_INVALID;
     }
-    return batch_impl(s, kind, top_index, n, rays, excl1, excl2, flags & ~HARE_SHOOT_WRITEBACK_ORIGIN, events, ctr, tmax, occluded);
+    return batch_impl(s, kind, top_index, n, rays, excl1, excl2, flags & ~(HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_SLIM_EVENTS), events, ctr, tmax,
+                      occluded);
 }
 
 int hare_occluded_batch_sharded(hare_scene* const* scenes, int32_t n_scenes, int32_t kind, int32_t top_index, int64_t n, hare_ray* rays,

@@ -30,6 +30,10 @@ enum : uint32_t {
     SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
     SHOOT_SIMPLE_KERNEL = 4u,     // use the one-ray-per-lane kernel instead of the persistent one (A/B, diagnostics)
     SHOOT_RETIRED_RAYS = 8u,      // bounce loop: excl1 == -2 marks a ray hare_reflect retired -> miss record, no traversal, not counted
+    SHOOT_SLIM_EVENTS = 16u,      // host-buffer calls: 16 / 32-byte result records (hare_slim_event*).  To the voxel kernels it means: for a
+                                  // ray whose origin AABB.Intersect moved, leave tmin (t measured from the moved origin) in X_Event.u, which
+                                  // Voxel_Grid always returns as 0 -- hare_events_pack_slim reads it from there (t itself is tmin + t_start,
+                                  // from which tmin cannot be recovered bit for bit)
 };
 
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)

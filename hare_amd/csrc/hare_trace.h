@@ -36,7 +36,7 @@ HARE_HD void set_miss(XEventRec& e)
 // (AABB.Intersect moves the caller's Ray, F11); returns true when that happened.
 template <bool QUADS, bool COUNT>
 HARE_HD bool trace_voxel(const VoxelArgs& g, V3& o, const V3& d, int e1, int e2,
-                                            XEventRec& ev, Work& w)
+                                            XEventRec& ev, Work& w, double* tmin_local = nullptr)
 {
     const int ct = g.ct;
     const double fct = (double)ct;
@@ -109,6 +109,7 @@ HARE_HD bool trace_voxel(const VoxelArgs& g, V3& o, const V3& d, int e1, int e2,
         // :705  IsPointInBox on the CURRENT padded voxel (AABB_Main.cs:75-84)
         if (have && !(hx < lox) && !(hy < loy) && !(hz < loz) && !(hx > hix) && !(hy > hiy) && !(hz > hiz)) {
             ev.t = tmin + t_start;                                // :707
+            if (tmin_local) *tmin_local = tmin;
             ev.u = 0; ev.v = 0;
             ev.x = hx; ev.y = hy; ev.z = hz;
             ev.poly_id = pid;

@@ -162,7 +162,9 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
         const int e1 = io.excl1 ? io.excl1[i] : -1;
         const int e2 = io.excl2 ? io.excl2[i] : -1;
         live = !(e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS));   // a ray the bounce loop retired (hare_reflect); else -2 is an ordinary "none"
-        const bool moved = live && trace_voxel<QUADS, COUNT>(g, o, d, e1, e2, ev, w);
+        double tmin_local = 0;
+        const bool moved = live && trace_voxel<QUADS, COUNT>(g, o, d, e1, e2, ev, w, &tmin_local);
+        if (moved && ev.hit != 0 && (io.flags & SHOOT_SLIM_EVENTS)) ev.u = tmin_local;      // see SHOOT_SLIM_EVENTS
         if (io.out) io.out[i] = ev;
         if (io.occluded) {
             const bool occ = ev.hit != 0 && (io.tmax == nullptr || ev.t < io.tmax[i]);
@@ -337,7 +339,8 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             double t_start = 0;
             if (moved) t_start = io.out[ray].t;                  // parked there by the setup
             ev.t = tmin + t_start;                               // Voxel_Grid.cs:707
-            ev.u = 0; ev.v = 0;
+            ev.u = (moved && (io.flags & SHOOT_SLIM_EVENTS)) ? tmin : 0.0;      // 0 as the reference returns it, unless slim records are asked for
+            ev.v = 0;
             ev.x = o.x + d.x * tmin;                             // Polygons.cs:652 (same operands => same bits)
             ev.y = o.y + d.y * tmin;
             ev.z = o.z + d.z * tmin;
@@ -1101,11 +1104,14 @@ __global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, Shoo
 __global__ __launch_bounds__(256) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
 __global__ __launch_bounds__(256) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
 
+#ifndef HARE_OCCL_WAVES_PER_EU
+#define HARE_OCCL_WAVES_PER_EU 4
+#endif
 // the occlusion predicate on K1p's walk, cut short at t_max (flags only: ShootIO::occluded, ShootIO::tmax); same launch geometry
-__global__ __launch_bounds__(256) void hare_voxel_occl_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_occl_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_occl_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_occl_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256, HARE_OCCL_WAVES_PER_EU) void hare_voxel_occl_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256, HARE_OCCL_WAVES_PER_EU) void hare_voxel_occl_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256, HARE_OCCL_WAVES_PER_EU) void hare_voxel_occl_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
+__global__ __launch_bounds__(256, HARE_OCCL_WAVES_PER_EU) void hare_voxel_occl_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true, false, HARE_K1P_STEPS, HARE_K1P_CULLS, true>(g, io); }
 
 // developer profiling build of the persistent kernel (phase stamps into ShootIO::prof)
 __global__ __launch_bounds__(256) void hare_voxel_persist_prof(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false, true>(g, io); }
@@ -1261,6 +1267,29 @@ __global__ __launch_bounds__(256) void hare_events_expand(const XEventRec* ev, c
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     full[idx[i]] = ev[i];
+}
+
+// Slim result records of the host-buffer calls (HARE_SHOOT_SLIM_EVENTS, include/hare_hip.h): what an X_Event holds that the caller
+// cannot recompute.  X_Point is o + d * t by the reference's own expression (Hare_Geometry_Polygons.cs:652), so it need not cross
+// the host link; the voxel path returns u = v = 0 (Voxel_Grid.cs:696-697).  uv = 0: 16 bytes {t, poly_id, hit}; uv = 1: 32 bytes
+// {t, u, v, poly_id, hit}.  hit = 2 marks a voxel hit on a ray whose origin AABB.Intersect moved: t is then tmin, measured from
+// the moved origin (hare_expand_events re-derives the move, t = tmin + t_start and X_Point = o' + d * tmin bit for bit).
+__global__ __launch_bounds__(256) void hare_events_pack_slim(const XEventRec* ev, long long n, int uv, unsigned char* slim)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const XEventRec e = ev[i];
+    if (uv) {
+        double* q = reinterpret_cast<double*>(slim + i * 32);
+        q[0] = e.t; q[1] = e.u; q[2] = e.v;
+        q[3] = __hiloint2double(e.hit, e.poly_id);
+    } else {
+        const bool moved = e.hit != 0 && e.u != 0.0;
+        double2 r;
+        r.x = moved ? e.u : e.t;
+        r.y = __hiloint2double(moved ? 2 : e.hit, e.poly_id);
+        *reinterpret_cast<double2*>(slim + i * 16) = r;
+    }
 }
 
 // A9 occlusion predicate (harness-defined): a ray is occluded when its CLOSEST hit -- the

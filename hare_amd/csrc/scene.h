@@ -89,6 +89,7 @@ struct DeviceModule {
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr;
+    hipFunction_t events_pack_slim = nullptr;
     hipFunction_t live_count = nullptr, scan_tiles = nullptr, reflect_compact = nullptr, events_fill_miss = nullptr, events_expand = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
@@ -184,6 +185,7 @@ struct Scene {
         void* d_e2 = nullptr;
         void* d_out = nullptr;
         void* d_ctr = nullptr;
+        void* d_slim = nullptr;      // HARE_SHOOT_SLIM_EVENTS: packed result records (cap x 32 B)
         void* d_tmax = nullptr;      // occlusion queries: t_max per ray, flags per ray
         void* d_occ = nullptr;
         int64_t cap = 0;

@@ -567,7 +567,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 double t_start = 0;
                 if (xf & F_MOVED) t_start = sc[1];
                 sc[0] = tmin + t_start;
-                sc[1] = 0;
+                sc[1] = ((xf & F_MOVED) && (io.flags & SHOOT_SLIM_EVENTS)) ? tmin : 0.0;     // u: 0 as the reference returns it (see SHOOT_SLIM_EVENTS)
                 sc[2] = 0;
                 nhits++;
             }

@@ -221,29 +221,42 @@ class Spatial_Partition:
                                        d_counters or None, stream or None))
 
     def Shoot_batch(self, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
-                    writeback_origin: bool = False, count_work: bool = False, simple_kernel: bool = False):
+                    writeback_origin: bool = False, count_work: bool = False, simple_kernel: bool = False, slim: bool = False):
         """n rays [n,6] through the HIP kernel (host buffers).  Returns (events, counters dict).
-        With writeback_origin the rays array is updated in place like the reference mutates R."""
+        With writeback_origin the rays array is updated in place like the reference mutates R.
+        slim=True: the events come back as slim records (capi.SLIM_DTYPE for Voxel_Grid, SLIM_UV_DTYPE for the trees; 16 / 32
+        bytes over the host link instead of 56); expand_events(rays, records) rebuilds the X_Events bit for bit."""
         if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
             rays = np.array(rays, np.float64, order="C")
         rays = rays.reshape(-1, 6)
         n = rays.shape[0]
-        out = np.zeros(n, XEVENT_DTYPE)
+        out = np.zeros(n, self._slim_dtype() if slim else XEVENT_DTYPE)
         e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
         e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
         for e in (e1, e2):
             if e is not None and e.shape != (n,):
                 raise ValueError("poly_origin arrays must have one entry per ray")
         flags = ((capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0) | (capi.SHOOT_COUNT_WORK if count_work else 0)
-                 | (capi.SHOOT_SIMPLE_KERNEL if simple_kernel else 0))
+                 | (capi.SHOOT_SIMPLE_KERNEL if simple_kernel else 0) | (capi.SHOOT_SLIM_EVENTS if slim else 0))
         ctr = capi.Counters()
         check(lib.hare_shoot_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), flags,
                                    ptr(out), C.addressof(ctr)))
         return out, ctr.as_dict()
 
+    def _slim_dtype(self):
+        return capi.SLIM_DTYPE if self._kind == KIND_VOXEL else capi.SLIM_UV_DTYPE
+
+    def expand_events(self, rays, slim_records):
+        """hare_expand_events: slim records (of a Shoot_batch(..., slim=True) on these rays, as they were passed in) -> X_Events."""
+        rays = np.ascontiguousarray(rays, np.float64).reshape(-1, 6)
+        rec = np.ascontiguousarray(slim_records, self._slim_dtype())
+        out = np.zeros(len(rec), XEVENT_DTYPE)
+        check(lib.hare_expand_events(self._h, self._kind, len(rec), ptr(rays), ptr(rec), ptr(out)))
+        return out
+
     @staticmethod
     def Shoot_batch_sharded(partitions, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
-                            writeback_origin: bool = False):
+                            writeback_origin: bool = False, slim: bool = False):
         """One batch over several devices from one process: `partitions` are equal partitions built on different
         devices (e.g. [Voxel_Grid(model, 64, device=k) for k in range(G)]); rays are split into contiguous shards in
         that order (hare_shoot_batch_sharded).  Returns (events, summed counters), byte-identical to Shoot_batch."""
@@ -254,7 +267,7 @@ class Spatial_Partition:
             rays = np.array(rays, np.float64, order="C")
         rays = rays.reshape(-1, 6)
         n = rays.shape[0]
-        out = np.zeros(n, XEVENT_DTYPE)
+        out = np.zeros(n, parts[0]._slim_dtype() if slim else XEVENT_DTYPE)
         e1 = None if poly_origin1 is None else np.ascontiguousarray(poly_origin1, np.int32)
         e2 = None if poly_origin2 is None else np.ascontiguousarray(poly_origin2, np.int32)
         for e in (e1, e2):
@@ -263,7 +276,8 @@ class Spatial_Partition:
         handles = (C.c_void_p * len(parts))(*[p._h for p in parts])
         ctr = capi.Counters()
         check(lib.hare_shoot_batch_sharded(handles, len(parts), parts[0]._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2),
-                                           capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0, ptr(out), C.addressof(ctr)))
+                                           (capi.SHOOT_WRITEBACK_ORIGIN if writeback_origin else 0) | (capi.SHOOT_SLIM_EVENTS if slim else 0),
+                                           ptr(out), C.addressof(ctr)))
         return out, ctr.as_dict()
 
     def Bounce_batch(self, rays, bounces: int, top_index: int = 0, poly_origin1=None, poly_origin2=None, all_casts: bool = False,

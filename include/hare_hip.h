@@ -64,6 +64,9 @@ extern "C" {
                                        /* it -- and always in the host-buffer calls -- a negative poly_origin matches no      */
                                        /* polygon, as in the reference (Voxel_Grid.cs:477 compares indices only)              */
 
+#define HARE_SHOOT_SLIM_EVENTS 16u     /* hare_shoot_batch / _sharded only: `out` receives slim records (below) instead of X_Events:   */
+                                       /* 16 bytes per ray come back over the host link instead of 56                                    */
+
 /* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
  * only serve the reference's mailbox pool and are not needed here. 48 bytes. */
 typedef struct hare_ray {
@@ -79,6 +82,25 @@ typedef struct hare_xevent {
     int32_t poly_id;  /* Poly_id */
     int32_t hit;      /* Hit     */
 } hare_xevent;
+
+/* Slim result records (HARE_SHOOT_SLIM_EVENTS): what an X_Event holds that the caller cannot recompute.
+ *   X_Point is R.origin + R.direction * t by the reference's own expression (Hare_Geometry_Polygons.cs:652): evaluated by the
+ *   caller in double precision without fusing it gives the same bits; Voxel_Grid.Shoot returns u = v = 0 (Voxel_Grid.cs:696-697).
+ *   Voxel_Grid: hare_slim_event, 16 bytes.  hit = 1: t is X_Event.t and X_Point = o + d * t.  hit = 2: the ray started outside
+ *   the grid and AABB.Intersect moved its origin (AABB_Main.cs:254-257): t is measured from the MOVED origin o'; X_Event.t =
+ *   t + t_start and X_Point = o' + d * t -- hare_expand_events redoes the move and both sums bit for bit.
+ *   Octree / KDTree: hare_slim_event_uv, 32 bytes (they return u, v; rays are never moved; hit is 0 or 1).
+ * hare_expand_events turns n slim records back into full X_Events on the host (byte-identical to what the full call returns). */
+typedef struct hare_slim_event {
+    double t;
+    int32_t poly_id;  /* -1 on a miss */
+    int32_t hit;      /* 0 miss, 1 hit, 2 hit on a ray whose origin was moved (t from the moved origin) */
+} hare_slim_event;
+typedef struct hare_slim_event_uv {
+    double t, u, v;
+    int32_t poly_id;
+    int32_t hit;
+} hare_slim_event_uv;
 
 /* Batch counters.  hits is what a multi-GPU run reduces across ranks. */
 typedef struct hare_counters {
@@ -209,10 +231,16 @@ HARE_API int hare_kdtree_get_nodes(const hare_scene *s, double *boxes, double *s
  * bool Shoot(Ray R, int top_index, out X_Event Ret_event, int poly_origin1, int poly_origin2 = -1)   :33
  * for n rays at once.  excl1/excl2 (nullable) are poly_origin1/poly_origin2 per ray, -1 = none.
  * rays is read (and, with HARE_SHOOT_WRITEBACK_ORIGIN, updated like the reference mutates R).
- * Host buffers; the call copies to the scene's device, runs the kernel and copies back. */
+ * Host buffers; the call copies to the scene's device, runs the kernel and copies back.  With HARE_SHOOT_SLIM_EVENTS `out` is
+ * an array of n hare_slim_event (Voxel_Grid) or hare_slim_event_uv (Octree, KDTree) instead of n hare_xevent. */
 HARE_API int hare_shoot_batch(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, hare_ray *rays,
                      const int32_t *excl1, const int32_t *excl2, uint32_t flags, hare_xevent *out,
                      hare_counters *ctr /* nullable */);
+
+/* Slim records -> X_Events, on the calling host thread(s): `slim` is what a HARE_SHOOT_SLIM_EVENTS call on `s` wrote for `rays`
+ * (the rays as they were passed in), kind as in that call.  Needs no GPU. */
+HARE_API int hare_expand_events(const hare_scene *s, int32_t kind, int64_t n, const hare_ray *rays, const void *slim,
+                                hare_xevent *out);
 
 /* The same call over several devices of one node from ONE process (hosts without torch.distributed, e.g. the
  * .NET shim): scenes[k] is the scene on device k's ordinal of choice -- same topologies, same partition, built by

@@ -268,3 +268,51 @@ def test_bounded_octree_occlusion_on_the_hall(hall):
     occ, c = oc.Occluded_batch(rays, tmax, events=False)
     want = _want(refo, tmax)
     assert np.array_equal(occ, want) and c["hits"] == int(want.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Slim result records (HARE_SHOOT_SLIM_EVENTS): 16 / 32 bytes per ray over the host link, X_Events rebuilt bit for bit
+@pytest.mark.parametrize("kernel", [0, 1, 2])
+def test_slim_events_rebuild_the_full_records_voxel(hall, kernel):
+    m, T, To = hall
+    g = H.Voxel_Grid([T], 64)
+    g.set_option("voxel_kernel", kernel)
+    n = 300_000
+    rays = H.scenes.burst_rays(n, m.size)
+    rng = np.random.default_rng(17)
+    rays[::4, :3] += rng.normal(0, 40.0, (len(rays[::4]), 3))              # a quarter start outside the grid: AABB.Intersect moves them
+    full, c = g.Shoot_batch(rays)
+    slim, c2 = g.Shoot_batch(rays, slim=True)
+    assert slim.dtype.itemsize == 16 and c2 == c
+    assert (slim["hit"] == 2).sum() > 1000 and (slim["hit"] == 1).sum() > 1000 and (slim["hit"] == 0).sum() > 1000
+    back = g.expand_events(rays, slim)
+    assert back.tobytes() == full.tobytes()
+    # the one-line rebuild a caller can do itself for rays that start inside the grid (hit == 1): X_Point = o + d * t
+    k = slim["hit"] == 1
+    for a, col in enumerate(("x", "y", "z")):
+        assert np.array_equal(rays[k, a] + rays[k, 3 + a] * slim["t"][k], full[col][k])
+    assert np.array_equal(slim["t"][k], full["t"][k]) and np.array_equal(slim["poly_id"], full["poly_id"])
+    # the oracle agrees with the rebuilt records (so slim is pinned by the same checker)
+    ref, _ = po.VoxelGrid([To], domain=64).shoot(rays, nthreads=16)
+    assert_events_equal(back, ref, what="slim -> expanded events")
+
+
+def test_slim_events_trees_quads_and_sharding():
+    v, nv, size = soup(n_tri=800, n_quad=300, seed=4)
+    T = H.Topology(v, nv)
+    rays = soup_rays(40_000, size, seed=8)
+    for g in (H.Voxel_Grid([T], 14), H.Octree([T], 5, 8), H.KDTree([T], 8, 8)):
+        r = rays if g._kind != capi.KIND_KDTREE else rays[:8000]
+        full, c = g.Shoot_batch(r)
+        slim, c2 = g.Shoot_batch(r, slim=True)
+        assert slim.dtype.itemsize == (16 if g._kind == capi.KIND_VOXEL else 32) and c2 == c
+        assert g.expand_events(r, slim).tobytes() == full.tobytes()
+    g1, g2 = H.Octree([T], 5, 8), H.Octree([T], 5, 8)
+    full, _ = g1.Shoot_batch(rays)
+    slim, _ = H.Spatial_Partition.Shoot_batch_sharded([g1, g2], rays, slim=True)
+    assert g1.expand_events(rays, slim).tobytes() == full.tobytes()
+    m = H.scenes.shoebox()                                                 # config 1: the committed golden set's scene
+    gs = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    rr = H.scenes.random_rays(10_000, m.size)
+    full, _ = gs.Shoot_batch(rr)
+    assert gs.expand_events(rr, gs.Shoot_batch(rr, slim=True)[0]).tobytes() == full.tobytes()

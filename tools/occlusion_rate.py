@@ -41,9 +41,18 @@ for kind, g in (("voxel D=%d" % D, H.Voxel_Grid([T], D)), ("octree 8/16", H.Octr
         d_occ.zero_()
         ms_flag = timed(lambda: g.occluded_device(n, d_rays.data_ptr(), 0, d_occ.data_ptr(), d_tmax=d_tmax.data_ptr(), stream=st))
         ok_flag = np.array_equal(d_occ.cpu().numpy(), want)
-        t0 = time.perf_counter(); g.Occluded_batch(rays, tmax); h_full = time.perf_counter() - t0
-        g.Occluded_batch(rays, tmax, events=False)
-        t0 = time.perf_counter(); occ, _ = g.Occluded_batch(rays, tmax, events=False); h_flag = time.perf_counter() - t0
+        import ctypes as C
+        occ = np.zeros(n, np.int32); evh = np.zeros(n, capi.XEVENT_DTYPE); ctr = capi.Counters()
+
+        def host(events):      # the C-ABI call on preallocated host arrays, best of 3 (the first call sizes the staging buffers)
+            best = 1e9
+            for k in range(4):
+                t0 = time.perf_counter()
+                capi.check(capi.lib.hare_occluded_batch(g._h, g._kind, 0, n, rays.ctypes.data, None, None, tmax.ctypes.data, 0, occ.ctypes.data,
+                                                        evh.ctypes.data if events else None, C.addressof(ctr)))
+                if k: best = min(best, time.perf_counter() - t0)
+            return best
+        h_full = host(True); h_flag = host(False)
         print("  t_max = %4s x mfp: occluded %5.1f %% | with events %.3f ms (%5.0f Mrays/s) | flags only %.3f ms (%5.0f Mrays/s, x%.2f) | "
               "from host buffers %.0f -> %.0f Mrays/s | flags equal: %s %s %s"
               % (f, 100 * want.mean(), ms_full, n / ms_full / 1e3, ms_flag, n / ms_flag / 1e3, ms_full / ms_flag, n / h_full / 1e6, n / h_flag / 1e6,
