@@ -28,6 +28,17 @@ namespace Hare
             public int hit;
         }
 
+        /// <summary>Slim result record of a Voxel_Grid batch (HARE_SHOOT_SLIM_EVENTS; include/hare_hip.h): 16 bytes instead of 56.
+        /// hit = 1: X_Event.t = t, X_Point = R.origin + R.direction * t (Hare_Geometry_Polygons.cs:652; same bits), u = v = 0.
+        /// hit = 2: the ray started outside the grid and its origin was moved; use HareHip.hare_expand_events.</summary>
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_slim_event
+        {
+            public double t;
+            public int poly_id;
+            public int hit;
+        }
+
         [StructLayout(LayoutKind.Sequential, Pack = 8)]
         public struct hare_counters
         {
@@ -66,6 +77,7 @@ namespace Hare
             public const int HARE_KIND_VOXEL = 0, HARE_KIND_OCTREE = 1, HARE_KIND_KDTREE = 2;
             public const uint HARE_SHOOT_WRITEBACK_ORIGIN = 1;
             public const uint HARE_SHOOT_RETIRED_RAYS = 8;   // device-resident bounce loop only (hare_shoot_device)
+            public const uint HARE_SHOOT_SLIM_EVENTS = 16;   // host-buffer batches: hare_slim_event records come back (16 B per ray, not 56)
 
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr hare_last_error();
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_device_count(out int count);
@@ -91,6 +103,14 @@ namespace Hare
             public static extern unsafe int hare_shoot_batch_sharded([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
                                                                      hare_ray* rays, int* excl1, int* excl2, uint flags,
                                                                      hare_xevent* ev, hare_counters* ctr);
+            /// <summary>Voxel_Grid batch with slim result records (flags must contain HARE_SHOOT_SLIM_EVENTS).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl, EntryPoint = "hare_shoot_batch_sharded")]
+            public static extern int hare_shoot_batch_sharded_slim([In] IntPtr[] scenes, int n_scenes, int kind, int top_index, long n,
+                                                                   [In] hare_ray[] rays, int[] excl1, int[] excl2, uint flags,
+                                                                   [Out] hare_slim_event[] ev, out hare_counters ctr);
+            /// <summary>Slim records back to full X_Event records on the host, bit for bit (needs no GPU).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_expand_events(IntPtr scene, int kind, long n, [In] hare_ray[] rays, [In] hare_slim_event[] slim, [Out] hare_xevent[] ev);
             /// <summary>The device-resident specular bounce loop from host buffers (include/hare_hip.h): `bounces` casts with a
             /// reflection about Normal(Poly_id) between them; events_all is bounces x n records, cast-major; any output may be null.</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
