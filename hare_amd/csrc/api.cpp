@@ -227,6 +227,56 @@ void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<Qua
     }
 }
 
+// The pre-cull's dense records of one topology (hare_device.h, HARE_CULL32) and the frame that decodes them.
+void make_cull_records(const Topo& T, const std::vector<PolyRec>& rec, std::vector<unsigned char>& dense, CullFrame& cf)
+{
+    dense.assign(rec.size() * (size_t)kCullStride, 0);
+    memset(&cf, 0, sizeof cf);
+#if HARE_CULL32
+    // the quantisation box: the polygons' own v0 range (inside Topology.Min / Max; taken from the records so that a caller's
+    // stale bounds cannot put a corner outside)
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int32_t p = 0; p < T.P; ++p)
+        for (int a = 0; a < 3; ++a) {
+            const double v = rec[(size_t)p].v0[a];
+            if (p == 0 || v < lo[a]) lo[a] = v;
+            if (p == 0 || v > hi[a]) hi[a] = v;
+        }
+    constexpr double kQMax = 2097151.0;        // 2^21 - 1
+    float step_max = 0, ext_max = 0;
+    for (int a = 0; a < 3; ++a) {
+        cf.org[a] = lo[a];
+        const double ext = hi[a] - lo[a];
+        float st = (ext > 0 && std::isfinite(ext)) ? up(ext / kQMax) : 0.0f;     // rounded up: q never exceeds 2^21 - 1
+        cf.step[a] = st;
+        step_max = std::max(step_max, st);
+        ext_max = std::max(ext_max, up(ext));
+    }
+    // per component: quantisation <= step / 2; rebuilding tv = (float)(o - org) - q * step in FP32 adds 2^-24 (|o - org| + |tv|)
+    // <= 2^-23 (|o - org| + extent).  err0 holds the ray-independent part, cull_ray adds 2^-22 |o - org|_1.
+    cf.err0 = up(0.5 * (double)step_max + 2.3841858e-07 * (double)ext_max);
+    for (int32_t p = 0; p < T.P; ++p) {
+        const PolyRec& r = rec[(size_t)p];
+        uint64_t q[3];
+        for (int a = 0; a < 3; ++a) {
+            double v = cf.step[a] > 0 ? std::nearbyint((r.v0[a] - cf.org[a]) / (double)cf.step[a]) : 0.0;
+            if (!(v >= 0)) v = 0;                 // NaN coordinates: the edges are NaN too, the candidate is never culled
+            if (v > kQMax) v = kQMax;
+            q[a] = (uint64_t)v;
+        }
+        const uint64_t packed = q[0] | (q[1] << 21) | (q[2] << 42);
+        unsigned char* d = &dense[(size_t)p * 32];
+        memcpy(d, &packed, 8);
+        memcpy(d + 8, r.e1f, 12);
+        memcpy(d + 20, r.e2f, 12);
+    }
+#else
+    static_assert(offsetof(PolyRec, ee) == 48, "the 48-byte pre-cull record is the head of the PolyRec");
+    for (size_t p = 0; p < rec.size(); ++p) memcpy(&dense[p * 48], &rec[p], 48);
+    (void)T;
+#endif
+}
+
 int upload_polys(Scene& s, const HipApi* H)
 {
     if (s.d_polys.size() == s.topos.size()) return HARE_OK;
@@ -241,7 +291,7 @@ int upload_polys(Scene& s, const HipApi* H)
         }
         return rc;
     };
-    static_assert(offsetof(PolyRec, ee) == kCullStride, "the pre-cull reads exactly the bytes in front of PolyRec::ee");
+    s.cull_frames.assign(s.topos.size(), CullFrame());
     for (size_t m = 0; m < s.topos.size(); ++m) {
         const Topo& T = s.topos[m];
         std::vector<PolyRec> rec;
@@ -249,8 +299,8 @@ int upload_polys(Scene& s, const HipApi* H)
         make_poly_records(T, rec, quads);
         int rc = upload(H, &s.d_polys[m], rec.data(), rec.size() * sizeof(PolyRec));
         if (rc) return fail(rc);
-        std::vector<unsigned char> dense(rec.size() * (size_t)kCullStride);
-        for (size_t p = 0; p < rec.size(); ++p) memcpy(&dense[p * (size_t)kCullStride], &rec[p], (size_t)kCullStride);
+        std::vector<unsigned char> dense;
+        make_cull_records(T, rec, dense, s.cull_frames[m]);
         rc = upload(H, &s.d_cull[m], dense.data(), dense.size());
         if (rc) return fail(rc);
         if (T.has_quads) {
@@ -309,12 +359,13 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
 // slot's mutex keeps wait + launch + record together when several host threads launch on one scene.
 // args[1] must point to `io`.
 int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, ShootIO& io,
-                   void** args)
+                   void** args, bool coop_tail = false)
 {
     const unsigned idx = s.work_slot.fetch_add(1) % kLaunchSlots;
     Scene::LaunchSlot& sl = s.slots[idx];
     std::lock_guard<std::mutex> lk(sl.mu);
     io.work = reinterpret_cast<unsigned int*>(static_cast<LaunchSlotMem*>(s.d_work) + idx);
+    io.coop_tail = (coop_tail && s.opt.coop_tail) ? 1 : 0;
     if (!sl.ev) HIP_TRY(H->EventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (sl.used) HIP_TRY(H->StreamWaitEvent(st, sl.ev, 0));
     const int rc = launch(H, f, grid, block, lds, st, args);
@@ -609,6 +660,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
         g.cull = (const unsigned char*)s.d_cull[top];
+        g.cf = s.cull_frames[(size_t)top];
         g.quads = (const QuadRec*)s.d_quads[top];
         g.cells = (const CellRec*)s.d_cells[top];
         g.items = (const int32_t*)s.d_items[top];
@@ -639,7 +691,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
             if (pgrid == 0) pgrid = 1;
             io.ticket_rays = ticket_rays_for(s, n, true);
-            return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args);
+            return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }
         // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
 #ifndef HARE_OCCL_WAVES_PER_EU
@@ -679,6 +731,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         memset(&g, 0, sizeof g);
         g.polys = (const PolyRec*)s.d_polys[top];
         g.cull = (const unsigned char*)s.d_cull[top];
+        g.cf = s.cull_frames[(size_t)top];
         g.quads = (const QuadRec*)s.d_quads[top];
         g.nodes = (const OctNode*)s.d_oct_nodes;
         g.items = (const int32_t*)s.d_oct_items;
@@ -1593,6 +1646,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 256},
         {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},
         {"batch_chunks", &SceneOptions::batch_chunks, 0, 3},
+        {"coop_tail", &SceneOptions::coop_tail, 0, 1},
     };
     for (auto& t : table)
         if (strcmp(t.name, name) == 0) {

@@ -39,15 +39,26 @@ enum : uint32_t {
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)
 enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_WORDS = 8 };
 
-// The FP32 pre-cull reads bytes 0..47 of a PolyRec (v0, e1f, e2f).  Cell and leaf lists hold runs of consecutive polygon
-// ids (82 % of neighbouring entries differ by one in the bench scenes, tools/list_locality.py), so a copy of just those bytes
-// at a 48-byte stride puts the candidates a ray scans next to each other: 2.7 records per 128-byte line instead of one.
-// Measured: -4 % kernel time at C2 and C3, +12 % casts/s in the bounce loop.  The exact test still
-// reads the 128-byte record.  -DHARE_CULL_DENSE=0 builds the kernels that gather from the record heads (the A/B baseline).
-constexpr int kCullStride = 48;
-#ifndef HARE_CULL_DENSE
-#define HARE_CULL_DENSE 1
+// The FP32 pre-cull's operands (v0, e1f, e2f) live in a dense array of their own, apart from the 128-byte records the exact test
+// reads.  Cell and leaf lists hold runs of consecutive polygon ids (82 % of neighbouring entries differ by one in the bench scenes,
+// tools/list_locality.py), so the candidates a ray scans sit next to each other (round 2: -4 % kernel time at C2 and C3, +12 %
+// casts/s in the bounce loop over gathering from the record heads).
+//   HARE_CULL32 = 1 (default): 32 bytes per polygon, one 32-byte sector, TWO 16-byte gathers:
+//       word 0-1   v0 quantised to 21 bits per axis on the topology's bounding box: q = round((v0 - org) / step), x | y << 21 | z << 42
+//       word 2-7   e1f, e2f (FP32 edges as before; a quadrilateral has NaN in e1f[0]: never culled)
+//     The quantisation (<= step / 2 per axis: 21 um on a 90 m cathedral) and the FP32 arithmetic that rebuilds tv = o - v0 from it
+//     only widen the cull's margins (cull_fp32's tv_err, hare_math.h); the exact FP64 test that decides a hit still reads the
+//     128-byte record.  Audited like the cull itself (hare_cull_audit: 0 rejected hits over every ray x polygon pair).
+//   HARE_CULL32 = 0: 48 bytes, bytes 0..47 of the PolyRec (v0 as FP64 + the edges), THREE gathers -- round 2's layout, the A/B baseline.
+#ifndef HARE_CULL32
+#define HARE_CULL32 1
 #endif
+constexpr int kCullStride = HARE_CULL32 ? 32 : 48;
+struct CullFrame {             // how tv = o - v0 is rebuilt from a 32-byte record (per topology; wave-uniform kernel arguments)
+    double org[3];             // the box's min corner: o_rel = (float)(o - org)
+    float step[3];             // quantisation step per axis (0 for a flat axis)
+    float err0;                // step_max / 2 + 2^-22 * extent_max, rounded up: the ray-independent part of tv_err
+};
 
 struct VoxelArgs {
     const PolyRec* polys;
@@ -62,7 +73,8 @@ struct VoxelArgs {
     int32_t occ_cd;
     double omin[3], omax[3];   // OBox
     double vd[3];              // VoxelDims
-    const unsigned char* cull; // dense copy of every record's first kCullStride bytes (what the FP32 pre-cull reads)
+    const unsigned char* cull; // the pre-cull's dense records, kCullStride bytes per polygon
+    CullFrame cf;
 };
 
 struct OctNode {               // 64 bytes
@@ -82,18 +94,83 @@ struct OctreeArgs {
     int32_t n_nodes;
     int32_t max_depth;
     const unsigned char* cull; // as in VoxelArgs
+    CullFrame cf;
 };
 
-// Where the pre-cull's 48 bytes of polygon i live: the dense copy, or the head of the 128-byte record itself
-template <class Args>
-HARE_HD const unsigned char* cull_record(const Args& g, int i)
-{
-#if HARE_CULL_DENSE
-    return g.cull + (size_t)(unsigned)i * (size_t)kCullStride;
+// ---- the pre-cull as the kernels use it: load a candidate's record (cull_load: the gathers), prepare the ray once per task
+// (cull_ray), test (cull_test: true = the exact test is certain to miss).  One code path for K1p, K1q, K2p, K2q and the audit.
+#if defined(__HIPCC__)
+struct CullRaw {
+#if HARE_CULL32
+    uint4 w0;                  // q.lo q.hi | e1f.x e1f.y
+    float4 w1;                 // e1f.z e2f.x e2f.y e2f.z
 #else
-    return reinterpret_cast<const unsigned char*>(g.polys + i);
+    double2 c0;                // v0.x v0.y
+    uint4 r1;                  // v0.z | e1f.x e1f.y
+    float4 fb;                 // e1f.z e2f.x e2f.y e2f.z
+#endif
+};
+struct CullRay {
+#if HARE_CULL32
+    float ox, oy, oz;          // (float)(o - org)
+    float err;                 // tv_err for this ray: err0 + 2^-22 * |o - org|_1
+#else
+    double ox, oy, oz;
+#endif
+    float dfx, dfy, dfz, dm;
+};
+template <class Args>
+__device__ __forceinline__ CullRaw cull_load(const Args& g, int i)
+{
+    const unsigned char* rec = g.cull + (size_t)(unsigned)i * (size_t)kCullStride;
+    CullRaw r;
+#if HARE_CULL32
+    r.w0 = *reinterpret_cast<const uint4*>(rec);
+    r.w1 = *reinterpret_cast<const float4*>(rec + 16);
+#else
+    r.c0 = *reinterpret_cast<const double2*>(rec);
+    r.r1 = *reinterpret_cast<const uint4*>(rec + 16);
+    r.fb = *reinterpret_cast<const float4*>(rec + 32);
+#endif
+    return r;
+}
+template <class Args>
+__device__ __forceinline__ CullRay cull_ray(const Args& g, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    CullRay r;
+#if HARE_CULL32
+    r.ox = (float)(ox - g.cf.org[0]);
+    r.oy = (float)(oy - g.cf.org[1]);
+    r.oz = (float)(oz - g.cf.org[2]);
+    r.err = __builtin_fmaf(2.3841858e-07f /* 2^-22 */, fabsf(r.ox) + fabsf(r.oy) + fabsf(r.oz), g.cf.err0);
+#else
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    (void)g;
+#endif
+    r.dfx = (float)dx; r.dfy = (float)dy; r.dfz = (float)dz;
+    r.dm = fabsf(r.dfx) + fabsf(r.dfy) + fabsf(r.dfz);
+    return r;
+}
+template <class Args>
+__device__ __forceinline__ bool cull_test(const Args& g, const CullRay& r, const CullRaw& c)
+{
+#if HARE_CULL32
+    const float qx = (float)(c.w0.x & 0x1FFFFFu);
+    const float qy = (float)((c.w0.x >> 21) | ((c.w0.y & 0x3FFu) << 11));
+    const float qz = (float)(c.w0.y >> 10);
+    const float tvx = __builtin_fmaf(-qx, g.cf.step[0], r.ox);
+    const float tvy = __builtin_fmaf(-qy, g.cf.step[1], r.oy);
+    const float tvz = __builtin_fmaf(-qz, g.cf.step[2], r.oz);
+    const float e1[3] = {__uint_as_float(c.w0.z), __uint_as_float(c.w0.w), c.w1.x}, e2[3] = {c.w1.y, c.w1.z, c.w1.w};
+    return cull_fp32(tvx, tvy, tvz, r.dfx, r.dfy, r.dfz, r.dm, e1, e2, r.err);
+#else
+    (void)g;
+    const double v0z = __hiloint2double((int)c.r1.y, (int)c.r1.x);
+    const float e1[3] = {__uint_as_float(c.r1.z), __uint_as_float(c.r1.w), c.fb.x}, e2[3] = {c.fb.y, c.fb.z, c.fb.w};
+    return cull_fp32((float)(r.ox - c.c0.x), (float)(r.oy - c.c0.y), (float)(r.oz - v0z), r.dfx, r.dfy, r.dfz, r.dm, e1, e2);
 #endif
 }
+#endif
 
 struct KdNodeRec {             // 80 bytes
     double bmin[3], bmax[3];
@@ -142,10 +219,8 @@ static_assert(sizeof(OctTask) == 64, "octree task size");
 constexpr int kPoolWaves = HARE_K1Q_WAVES;
 constexpr int kPoolSlots = HARE_K1Q_SLOTS;
 constexpr int kPoolRing = kPoolSlots <= 64 ? 64 : (kPoolSlots <= 128 ? 128 : 256);   // queue capacity: the power of two >= slots
-#ifndef HARE_K1Q_RAY_LDS
-#define HARE_K1Q_RAY_LDS 0        // 1: the (moved) origin and the FP32 direction also live in LDS: no ray re-read in the cull phase
-#endif
-constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4 + (HARE_K1Q_RAY_LDS ? 3 * 8 + 3 * 4 : 0)) + 5 * kPoolRing;   // per wave: 6 (9) doubles + 7 (10) words per slot, 5 byte queues
+constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4) + 5 * kPoolRing;   // per wave: 6 doubles + 7 words per slot, 5 byte queues
+// (origin and FP32 direction in LDS as well -- no ray re-read in the cull phase -- was measured in round 2: +2.7 % at 8 waves, far behind 12 waves)
 static_assert(kPoolSlots >= 64 && kPoolSlots <= 256 && kPoolSlots % 2 == 0, "K1q slots: even, 64..256");
 static_assert(kPoolWaveBytes % 8 == 0, "K1q: per-wave LDS block keeps the doubles aligned");
 
@@ -208,6 +283,7 @@ struct ShootIO {
     // hare_*_occl_* kernels then also cut the traversal short where that cannot change the flag (kernels.hip).
     const double* tmax;        // nullable
     int32_t* occluded;         // nullable: n flags
+    int32_t coop_tail;         // 1: a drained wave traces its last rays cooperatively (voxel_coop.hip); 0: as lanes of the pool to the end
 };
 
 }  // namespace hare

@@ -188,8 +188,12 @@ HARE_HD bool poly_full(const PolyRec& p, const double* v3, const V3& o, const V3
 // record: a fourth 16-byte gather per candidate costs more in the texture-address unit than the arithmetic does in the
 // VALU.  Rounding of the edges to FP32 and of the sums below loses at most ~8 x 2^-24 relative; both factors are inflated
 // by 2^-20 twice over that.  A quadrilateral's record carries NaN in e1f[0]: every comparison fails, it is never culled.
+// `tv_err`: an additional ABSOLUTE error bound on each component of tv (the 32-byte records hold v0 quantised to 21 bits per
+// axis, hare_device.h: tv is then off by up to half a quantisation step plus its own FP32 roundings).  u = tv . (d x e2) and
+// v = d . (tv x e1) move by at most |dtv|_1 |d x e2|_inf <= 3 tv_err * 2 |d|_inf emax and |d|_1 |dtv x e1|_inf <= |d|_1 * 2 tv_err
+// emax: both within 6 * tv_err * |d|_1 * emax, which is added to M_uv (det does not involve tv).
 HARE_HD bool cull_fp32(float tvx, float tvy, float tvz, float dx, float dy, float dz, float dm /*|d|_1*/,
-                       const float* e1, const float* e2)
+                       const float* e1, const float* e2, float tv_err = 0.0f)
 {
     // Explicit fused multiply-adds (the build contracts nothing by itself): this is the filter, not the
     // reference arithmetic -- a fused term has one rounding instead of two, so the bound above still holds.
@@ -208,7 +212,7 @@ HARE_HD bool cull_fp32(float tvx, float tvy, float tvz, float dx, float dy, floa
     const float v = __builtin_fmaf(dx, qx, __builtin_fmaf(dy, qy, dz * qz));
     const float tvm = fabsf(tvx) + fabsf(tvy) + fabsf(tvz);
     const float gd = G * dm;
-    const float muv = __builtin_fmaf(gd * tvm, emax, 1e-30f);
+    const float muv = __builtin_fmaf(__builtin_fmaf(gd, tvm, 6.001f * tv_err * dm), emax, 1e-30f);
     const float md = __builtin_fmaf(gd, ee, 1e-30f);
     const float adet = fabsf(det);
     const float su = det < 0.0f ? -u : u;

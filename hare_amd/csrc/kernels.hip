@@ -308,7 +308,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     int X = 0, Y = 0, Z = 0, cell = 0;
     int dx1 = 1, dy1 = 1, dz1 = 1;   // stepX/Y/Z (Voxel_Grid.cs:589-632)
     int dcx = 0, dcy = 0, dcz = 0;   // the same steps as cell-index strides
-    float dfx = 0, dfy = 0, dfz = 0, dm = 0;   // (float)d and |d|_1 for the cull
+    CullRay cray = {};               // the ray as the pre-cull reads it ((float)d, |d|_1; origin relative to the cull frame)
     int e1 = -1, e2 = -1;
     unsigned int q = 0, qe = 0;      // q: position of the CURRENT candidate `idx` in items
     int idx = -1, nexti = -1;        // current / following candidate polygon
@@ -448,8 +448,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                             cell = (X * ct + Y) * ct + Z;
                             dx1 = d.x < 0 ? -1 : 1; dy1 = d.y < 0 ? -1 : 1; dz1 = d.z < 0 ? -1 : 1;
                             dcx = dx1 * ct * ct; dcy = dy1 * ct; dcz = dz1;
-                            dfx = (float)d.x; dfy = (float)d.y; dfz = (float)d.z;
-                            dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                            cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);      // after the clip: the origin the tests use
                             if (OCC) {
                                 occ_lim = kDblMax;                           // no t_max: only the walk's own end decides
                                 if (io.tmax) {
@@ -536,15 +535,9 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             if (skip(idx)) {                                                // Voxel_Grid.cs:477 (+ mailbox)
                 next_candidate();
             } else {
-                // first 48 bytes of the record: v0 (FP64) + e1f e2f (FP32)
-                const unsigned char* rec = cull_record(g, idx);
-                const double2 c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
-                const uint4 r1 = *reinterpret_cast<const uint4*>(rec + 16);          // v0.z | e1f.x e1f.y
-                const float4 fb = *reinterpret_cast<const float4*>(rec + 32);        // e1f.z e2f.x e2f.y e2f.z
-                const double c1x = __hiloint2double((int)r1.y, (int)r1.x);
-                const float e1f[3] = {__uint_as_float(r1.z), __uint_as_float(r1.w), fb.x}, e2f[3] = {fb.y, fb.z, fb.w};
-                const float tvx = (float)(o.x - c0.x), tvy = (float)(o.y - c0.y), tvz = (float)(o.z - c1x);
-                if (cull_fp32(tvx, tvy, tvz, dfx, dfy, dfz, dm, e1f, e2f)) {
+                // the candidate's pre-cull record (hare_device.h: two or three 16-byte gathers)
+                const CullRaw cr = cull_load(g, idx);
+                if (cull_test(g, cray, cr)) {
                     done2 = done1;       // a certain miss counts as tested
                     done1 = idx;
                     next_candidate();
@@ -624,15 +617,13 @@ __device__ __forceinline__ void audit_body(const VoxelArgs& g, const ShootIO& io
         const RayRec r = io.rays[i];
         const V3 o = {r.x, r.y, r.z};
         const V3 d = {r.dx, r.dy, r.dz};
-        const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
-        const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+        const CullRay cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
         // brute force over every polygon of the topology (n_polys in io.pad): the audit is about the
-        // filter, not the traversal
+        // filter, not the traversal -- through the very load / decode / test the production kernels use
         const int P = io.audit_polys;
         for (int k = 0; k < P; ++k) {
             const PolyRec& p = g.polys[k];
-            const bool c = cull_fp32((float)(o.x - p.v0[0]), (float)(o.y - p.v0[1]), (float)(o.z - p.v0[2]), dfx, dfy, dfz, dm,
-                                     p.e1f, p.e2f);
+            const bool c = cull_test(g, cray, cull_load(g, k));
             double t;
             const bool hit = poly_fast(p, nullptr, o, d, t);
             cands++;
@@ -760,7 +751,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     unsigned int ray = 0;
     V3 o = {0, 0, 0}, d = {0, 0, 0};
     double invDx = 0, invDy = 0, invDz = 0;
-    float dfx = 0, dfy = 0, dfz = 0, dm = 0;
+    CullRay cray = {};
     int mask = 0, lvl = -1;
     int e1 = -1, e2 = -1;
     int q = 0, qe = 0;                  // remaining candidates of the current leaf: items[q .. qe)
@@ -893,8 +884,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         invDy = fabs(d.y) > 1e-16 ? 1.0 / d.y : 1e16;
                         invDz = fabs(d.z) > 1e-16 ? 1.0 / d.z : 1e16;
                         mask = ((d.x >= 0 ? 0 : 1) << 2) | ((d.y >= 0 ? 0 : 1) << 1) | (d.z >= 0 ? 0 : 1);
-                        dfx = (float)d.x; dfy = (float)d.y; dfz = (float)d.z;
-                        dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                        cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
                         const OctNode& root = g.nodes[0];
                         double tx0 = (root.bmin[0] - o.x) * invDx, tx1 = (root.bmax[0] - o.x) * invDx;
                         double ty0 = (root.bmin[1] - o.y) * invDy, ty1 = (root.bmax[1] - o.y) * invDy;
@@ -964,20 +954,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         // Two candidates per iteration: both list entries, then both polygon records, are requested together and the culls
         // run back to back -- two culls per pair of dependent loads instead of one.  (This kernel is held to three workgroups
         // per CU by its LDS frames, so the second record in flight costs no occupancy; the voxel kernel has no such room.)
-        struct CullRec { double2 c0; uint4 r1; float4 fb; };
-        auto load_rec = [&](int i) {
-            const unsigned char* rec = cull_record(g, i);
-            CullRec r;
-            r.c0 = *reinterpret_cast<const double2*>(rec);          // v0.x v0.y
-            r.r1 = *reinterpret_cast<const uint4*>(rec + 16);       // v0.z | e1f.x e1f.y
-            r.fb = *reinterpret_cast<const float4*>(rec + 32);      // e1f.z e2f.x e2f.y e2f.z
-            return r;
-        };
-        auto culled = [&](const CullRec& r) {
-            const double c1x = __hiloint2double((int)r.r1.y, (int)r.r1.x);
-            const float e1f[3] = {__uint_as_float(r.r1.z), __uint_as_float(r.r1.w), r.fb.x}, e2f[3] = {r.fb.y, r.fb.z, r.fb.w};
-            return cull_fp32((float)(o.x - r.c0.x), (float)(o.y - r.c0.y), (float)(o.z - c1x), dfx, dfy, dfz, dm, e1f, e2f);
-        };
+        auto load_rec = [&](int i) { return cull_load(g, i); };
+        auto culled = [&](const CullRaw& r) { return cull_test(g, cray, r); };
         auto recently = [&](int i) {                                                                    // :218 (+ mailbox)
             return i == e1 || i == e2 || (HARE_K2P_MAILBOX >= 1 && i == m0) || (HARE_K2P_MAILBOX >= 2 && i == m1) ||
                    (HARE_K2P_MAILBOX >= 4 && (i == m2 || i == m3));
@@ -993,7 +971,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 if (has1) i1 = g.items[q + 1];
                 const bool sk0 = recently(i0);
                 const bool sk1 = !has1 || recently(i1) || i1 == i0;
-                CullRec ra, rb;
+                CullRaw ra, rb;
                 if (!sk0) ra = load_rec(i0);
                 if (!sk1) rb = load_rec(i1);
                 bool consumed0 = true;
@@ -1305,6 +1283,7 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 
 }  // extern "C"
 
+#include "voxel_coop.hip"
 #include "voxel_pool.hip"
 #include "octree_pool.hip"
 #include "build_kernels.hip"

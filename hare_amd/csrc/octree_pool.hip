@@ -354,8 +354,7 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
                 if (io.excl1) e1 = io.excl1[ray];                           // :218
                 if (io.excl2) e2 = io.excl2[ray];
                 const RayRec r = io.rays[ray];
-                const float dfx = (float)r.dx, dfy = (float)r.dy, dfz = (float)r.dz;
-                const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                const CullRay cray = cull_ray(g, r.x, r.y, r.z, r.dx, r.dy, r.dz);
                 bool culling = true, parked = false;
 #pragma unroll
                 for (int kp = 0; kp < HARE_K2Q_CULL_PAIRS; ++kp) {
@@ -363,20 +362,9 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
                     const unsigned qa = q + 2 < qe ? q + 2 : qe - 1, qb = q + 3 < qe ? q + 3 : qe - 1;
                     const int i2 = g.items[qa], i3 = g.items[qb];
                     const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;
-                    const unsigned char* reca = cull_record(g, ia);
-                    const unsigned char* recb = cull_record(g, ib);
-                    const double2 a0 = *reinterpret_cast<const double2*>(reca);
-                    const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);
-                    const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);
-                    const double2 b0 = *reinterpret_cast<const double2*>(recb);
-                    const uint4 b1 = *reinterpret_cast<const uint4*>(recb + 16);
-                    const float4 b2 = *reinterpret_cast<const float4*>(recb + 32);
-                    const float ae1[3] = {__uint_as_float(a1.z), __uint_as_float(a1.w), a2.x}, ae2[3] = {a2.y, a2.z, a2.w};
-                    const float be1[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), b2.x}, be2[3] = {b2.y, b2.z, b2.w};
-                    const bool ca = cull_fp32((float)(r.x - a0.x), (float)(r.y - a0.y), (float)(r.z - __hiloint2double((int)a1.y, (int)a1.x)),
-                                              dfx, dfy, dfz, dm, ae1, ae2);
-                    const bool cb = cull_fp32((float)(r.x - b0.x), (float)(r.y - b0.y), (float)(r.z - __hiloint2double((int)b1.y, (int)b1.x)),
-                                              dfx, dfy, dfz, dm, be1, be2);
+                    const CullRaw ra = cull_load(g, ia), rb = cull_load(g, ib);
+                    const bool ca = cull_test(g, cray, ra);
+                    const bool cb = cull_test(g, cray, rb);
                     // Not in the reference (its mailbox is commented out, :221-222): loose leaves overlap, so a ray meets the
                     // same polygon in several leaves; skipping one it has just tested, and candidates the conservative cull
                     // proves to be misses, cannot change any accepted hit (strict `t < closestT`)

@@ -39,6 +39,7 @@ struct SceneOptions {
     int k1p_static_rays = 0;   // static first chunk per wave (0 = the host's rule)
     int k2p_static_rays = 0;
     int batch_chunks = 0;      // chunks hare_shoot_batch pipelines a batch over (0 = the host's rule)
+    int coop_tail = 1;         // 1: a drained wave traces its last rays with all 64 lanes (voxel_coop.hip); 0: as lanes of the pool to the end (A/B)
     int tune[5] = {0, 0, 0, 0, 0};   // HARE_TUNE: steps,refill,chunk,blocks_per_cu,exact (profiling build; blocks_per_cu: K1p)
 };
 
@@ -136,7 +137,8 @@ struct Scene {
 
     // device residents (all on `device`)
     std::vector<void*> d_polys;                  // per topo: PolyRec[P]
-    std::vector<void*> d_cull;                   // per topo: first kCullStride bytes of each PolyRec, dense (hare_device.h)
+    std::vector<void*> d_cull;                   // per topo: the pre-cull's dense records, kCullStride bytes per polygon (hare_device.h)
+    std::vector<CullFrame> cull_frames;          // per topo: how those records decode
     std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
     int32_t occ_words = 0;                       // words of the occupancy bitmap the persistent kernel stages in LDS
@@ -214,6 +216,7 @@ struct Scene {
 };
 void free_host_mirror(Scene& s);             // host_trace.cpp
 void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<QuadRec>& quads);   // api.cpp
+void make_cull_records(const Topo& T, const std::vector<PolyRec>& rec, std::vector<unsigned char>& dense, CullFrame& cf);   // api.cpp
 
 // error plumbing (thread-local message)
 void set_error(const std::string& msg);

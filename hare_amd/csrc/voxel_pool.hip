@@ -52,6 +52,11 @@
 #ifndef HARE_K1Q_MAILBOX
 #define HARE_K1Q_MAILBOX 1        // skip the polygon this ray tested last
 #endif
+#ifndef HARE_K1Q_COOP_NOW
+#define HARE_K1Q_COOP_NOW 2       // tickets dry and this few rays left: the wave traces them cooperatively at once (voxel_coop.hip)
+#define HARE_K1Q_COOP_MAX 8       // ... or this few, once they have outlived the rest of the batch by
+#define HARE_K1Q_COOP_PATIENCE 48 // this many rounds (heavy rays)
+#endif
 #ifndef HARE_K1Q_REFILL_MIN
 #define HARE_K1Q_REFILL_MIN 64    // set up new rays when this many slots are free (a full wave of set-ups)
 #endif
@@ -87,18 +92,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     int32_t* const L_idx = reinterpret_cast<int32_t*>(L_qe + S);
     int32_t* const L_nexti = L_idx + S;
     int32_t* const L_d1 = L_nexti + S;
-#if HARE_K1Q_RAY_LDS
-    // doubles first (alignment): origin after the set-up's clip; then the FP32 direction
-    double* const L_ox = reinterpret_cast<double*>(L_d1 + S);
-    double* const L_oy = L_ox + S;
-    double* const L_oz = L_oy + S;
-    float* const L_dfx = reinterpret_cast<float*>(L_oz + S);
-    float* const L_dfy = L_dfx + S;
-    float* const L_dfz = L_dfy + S;
-    uint8_t* const Q_walk = reinterpret_cast<uint8_t*>(L_dfz + S);
-#else
     uint8_t* const Q_walk = reinterpret_cast<uint8_t*>(L_d1 + S);
-#endif
     uint8_t* const Q_cull = Q_walk + R;
     uint8_t* const Q_exact = Q_cull + R;
     uint8_t* const Q_pend = Q_exact + R;
@@ -143,6 +137,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     bool drained = false;
     unsigned nhits = 0, nrays = 0;
     const bool writeback = (io.flags & SHOOT_WRITEBACK_ORIGIN) != 0;
+    // the cooperative tail (voxel_coop.hip); with origin write-back the ray record holds the MOVED origin, which coop_trace would move again
+    const bool coop = io.coop_tail != 0 && !writeback;
+    unsigned tail_rounds = 0;        // rounds since the tickets ran dry
 
     auto store_miss = [&](unsigned ray) {
         XEventRec ev;
@@ -182,6 +179,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     // a wave serves ~n / (waves in the grid) rays in a few rounds each; the cap only exists so that a defect can never
     // turn into a wave that does not finish (rays it left behind would keep their scratch values and fail every parity test)
 #define HARE_K1Q_PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define HARE_K1Q_TAIL_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
     for (unsigned round = 0; round < (1u << 24); ++round) {
         // ------------------------------------------------------------------ set-up of new rays into free slots
         if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP == 0)) {
@@ -249,10 +247,6 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                             L_xyzf[slot] = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (d.x < 0 ? F_NX : 0u) | (d.y < 0 ? F_NY : 0u) |
                                            (d.z < 0 ? F_NZ : 0u) | (moved ? F_MOVED : 0u);
                             L_d1[slot] = -1;
-#if HARE_K1Q_RAY_LDS
-                            L_ox[slot] = o.x; L_oy[slot] = o.y; L_oz[slot] = o.z;
-                            L_dfx[slot] = (float)d.x; L_dfy[slot] = (float)d.y; L_dfz[slot] = (float)d.z;
-#endif
                             double* sc = reinterpret_cast<double*>(&io.out[ray]);      // the ray's scratch (see the header)
                             sc[0] = kDblMax;
                             if (moved) sc[1] = t_start;
@@ -277,9 +271,15 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 push(Q_free, hF, nF, freed, slot);
             }
         }
-        if (nW + nC + nE + nP == 0) {
-            if (drained) break;
-            continue;
+        {
+            const unsigned left = nW + nC + nE + nP;
+            if (drained) {
+                if (left == 0) break;
+                // down to the last rays: one or two at once; a handful when they have outlived the others by HARE_K1Q_COOP_PATIENCE
+                // rounds (heavy rays) -- from here on the whole wave traces them one after the other (voxel_coop.hip)
+                if (coop && (left <= (unsigned)HARE_K1Q_COOP_NOW || (left <= (unsigned)HARE_K1Q_COOP_MAX && tail_rounds >= (unsigned)HARE_K1Q_COOP_PATIENCE))) break;
+                ++tail_rounds;
+            } else if (left == 0) continue;
         }
         ++rounds_done;
 
@@ -359,19 +359,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 int e1 = -1, e2 = -1;
                 if (io.excl1) e1 = io.excl1[ray];                           // poly_origin1 / 2 (Voxel_Grid.cs:477); wave-uniform branches
                 if (io.excl2) e2 = io.excl2[ray];
-#if HARE_K1Q_RAY_LDS
-                const double ox = L_ox[slot], oy = L_oy[slot], oz = L_oz[slot];
-                const float dfx = L_dfx[slot], dfy = L_dfy[slot], dfz = L_dfz[slot];
-#else
                 const RayRec r = io.rays[ray];
                 double ox = r.x, oy = r.y, oz = r.z;
                 if ((xf & F_MOVED) && !writeback) {
                     const double ts = reinterpret_cast<const double*>(&io.out[ray])[1];
                     ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
                 }
-                const float dfx = (float)r.dx, dfy = (float)r.dy, dfz = (float)r.dz;
-#endif
-                const float dm = fabsf(dfx) + fabsf(dfy) + fabsf(dfz);
+                const CullRay cray = cull_ray(g, ox, oy, oz, r.dx, r.dy, r.dz);
                 bool culling = true, parked = false;
                 share_idx = idx;
 #pragma unroll
@@ -391,20 +385,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         i2 = g.items[qa]; i3 = i2;                           // q + 3 >= qe: i3 is never a candidate
                     }
                     const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;   // a finished lane may hold -1: stay inside the array
-                    const unsigned char* reca = cull_record(g, ia);
-                    const unsigned char* recb = cull_record(g, ib);
-                    const double2 a0 = *reinterpret_cast<const double2*>(reca);          // v0.x v0.y
-                    const uint4 a1 = *reinterpret_cast<const uint4*>(reca + 16);         // v0.z | e1f.x e1f.y
-                    const float4 a2 = *reinterpret_cast<const float4*>(reca + 32);       // e1f.z e2f.x e2f.y e2f.z
-                    const double2 b0 = *reinterpret_cast<const double2*>(recb);
-                    const uint4 b1 = *reinterpret_cast<const uint4*>(recb + 16);
-                    const float4 b2 = *reinterpret_cast<const float4*>(recb + 32);
-                    const float ae1[3] = {__uint_as_float(a1.z), __uint_as_float(a1.w), a2.x}, ae2[3] = {a2.y, a2.z, a2.w};
-                    const float be1[3] = {__uint_as_float(b1.z), __uint_as_float(b1.w), b2.x}, be2[3] = {b2.y, b2.z, b2.w};
-                    const bool ca = cull_fp32((float)(ox - a0.x), (float)(oy - a0.y), (float)(oz - __hiloint2double((int)a1.y, (int)a1.x)),
-                                              dfx, dfy, dfz, dm, ae1, ae2);
-                    const bool cb = cull_fp32((float)(ox - b0.x), (float)(oy - b0.y), (float)(oz - __hiloint2double((int)b1.y, (int)b1.x)),
-                                              dfx, dfy, dfz, dm, be1, be2);
+                    const CullRaw ra = cull_load(g, ia), rb = cull_load(g, ib);
+                    const bool ca = cull_test(g, cray, ra);
+                    const bool cb = cull_test(g, cray, rb);
                     // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the one this ray
                     // tested last is exact (Voxel_Grid.cs:477 + K1p's register mailbox)
                     const bool sk0 = idx == e1 || idx == e2 || (HARE_K1Q_MAILBOX && idx == done1);
@@ -594,8 +577,55 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     }
 #undef HARE_K1Q_STEP
 #undef HARE_K1Q_PHASE_FENCE
+    unsigned helped = 0;
+    if (coop && nW + nC + nE + nP > 0) {
+        // ---- the cooperative tail: what is left (at most HARE_K1Q_COOP_MAX rays, in whatever queue) is traced by the whole wave,
+        // one ray after the other, from the state the pool left it in
+        HARE_K1Q_TAIL_FENCE();
+#undef HARE_K1Q_TAIL_FENCE
+        const uint8_t* const Qs[4] = {Q_walk, Q_cull, Q_exact, Q_pend};
+        unsigned* const heads[4] = {&hW, &hC, &hE, &hP};
+        unsigned* const cnts[4] = {&nW, &nC, &nE, &nP};
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+            while (*cnts[qn] > 0) {
+                const unsigned slot = Qs[qn][*heads[qn] & SM];                     // wave-uniform: every lane reads the same queue entry
+                *heads[qn] = (*heads[qn] + 1u) & SM;
+                *cnts[qn] -= 1u;
+                const unsigned ray = L_ray[slot];
+                const uint32_t xf = L_xyzf[slot];
+                double tmin = kDblMax;
+                int pid = -1;
+                double* sc = reinterpret_cast<double*>(&io.out[ray]);              // the ray's scratch: this wave wrote it
+                if (xf & F_HIT) { tmin = sc[0]; pid = __double2loint(sc[6]); }
+                const bool hit = coop_trace<QUADS, COARSE>(g, io, locc, ray, xf, L_tmx[slot], L_tmy[slot], L_tmz[slot], tmin, pid);
+                ++helped;
+                if (lane == 0) {
+                    XEventRec ev;
+                    if (hit) {
+                        const RayRec r = io.rays[ray];
+                        double t_start = 0, ox = r.x, oy = r.y, oz = r.z;
+                        if (xf & F_MOVED) {                                        // the set-up left t_start in the scratch; o' = o + d * t_start (AABB_Main.cs:254-256)
+                            t_start = sc[1];
+                            ox = ox + r.dx * t_start; oy = oy + r.dy * t_start; oz = oz + r.dz * t_start;
+                        }
+                        ev.t = tmin + t_start;                                     // Voxel_Grid.cs:707
+                        ev.u = ((xf & F_MOVED) && (io.flags & SHOOT_SLIM_EVENTS)) ? tmin : 0.0;
+                        ev.v = 0;
+                        ev.x = ox + r.dx * tmin; ev.y = oy + r.dy * tmin; ev.z = oz + r.dz * tmin;      // Polygons.cs:652
+                        ev.poly_id = pid;
+                        ev.hit = 1;
+                        nhits++;
+                    } else {
+                        set_miss(ev);
+                    }
+                    store_event_streaming(&io.out[ray], ev);
+                }
+            }
+        }
+    }
     timeline(2, __builtin_amdgcn_s_memrealtime());
-    timeline(3, rounds_done);
+    timeline(3, rounds_done | ((unsigned long long)helped << 32));
     if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
         if (lane == 0) {
             atomicAdd(&io.prof[0], stat_lanes);

@@ -97,7 +97,7 @@ def test_developer_flag_bits_are_masked_without_HARE_DEV(hall, monkeypatch):
     plain, _ = g.Shoot_batch(rays)
     out = np.zeros(len(rays), capi.XEVENT_DTYPE)
     ctr = capi.Counters()
-    for bits in (0x2000, 0x4000, 0x8000, 0xFFFFFFF0):
+    for bits in (0x2000, 0x4000, 0x8000, 0xFFFFFFE0):          # everything but the five public bits (1, 2, 4, 8, 16)
         capi.check(capi.lib.hare_shoot_batch(g._h, 0, 0, len(rays), rays.ctypes.data, None, None, bits, out.ctypes.data,
                                              C.addressof(ctr)))
         assert out.tobytes() == plain.tobytes() and ctr.rays == len(rays)
