@@ -716,7 +716,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             io.prof = (unsigned long long*)d_ctr + CTR_WORDS;      // phase statistics land in the 17 u64 words FOLLOWING the counters block
             lds_total += 4u * 18u * 8u;                            // + the profiling build's per-wave statistics
         }
-        return launch_on_slot(s, H, kc.f, pgrid, block, lds_total, st, io, args);
+        return launch_on_slot(s, H, kc.f, pgrid, block, lds_total, st, io, args, true);
     }
     if (kind == HARE_KIND_OCTREE) {
         if (!s.oct.built || !s.d_oct_nodes) {

@@ -31,6 +31,8 @@
 
 using namespace hare;
 
+#include "voxel_coop.hip"      // coop_trace: one ray traced by a whole wave (the cooperative tail of K1p and K1q)
+
 namespace {
 
 
@@ -215,9 +217,21 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 // that is beyond t_max - t_start, and no hit below t_max is pending, nothing the rest of the walk finds can be below t_max:
 // not occluded.  (Margins: 2.5 mm instead of 2, and t_max + 1e-9 relative, so that rounding can only make the walk longer;
 // a pending hit is never acted on before the reference would confirm it, leaving the grid stays a miss: F12.)
+#ifndef HARE_K1P_COOP_NOW
+#define HARE_K1P_COOP_NOW 2        // tickets dry and this few lanes alive: the wave traces their rays cooperatively at once (voxel_coop.hip)
+#define HARE_K1P_COOP_MAX 16       // ... or this few, once they have outlived the rest of the batch by
+#define HARE_K1P_COOP_PATIENCE 24  // this many rounds (heavy rays)
+#endif
+#ifndef HARE_K1P_COOP
+#define HARE_K1P_COOP 1            // 0: build K1p without the cooperative tail (A/B)
+#endif
 template <bool QUADS, bool COARSE, bool PROF = false, int STEPS = HARE_K1P_STEPS, int CULLS = HARE_K1P_CULLS, bool OCC = false>
 __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const ShootIO& io)
 {
+    constexpr bool COOP = HARE_K1P_COOP && !OCC && !PROF;       // the occlusion and profiling builds keep every ray in its lane to the end
+    // with origin write-back the ray record holds the MOVED origin, which coop_trace would move again
+    const bool coop_on = io.coop_tail != 0 && !(io.flags & SHOOT_WRITEBACK_ORIGIN);
+    int tail_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);   // address space known: ds_read, not flat
     // PROF: developer build with cycle stamps per phase (never the timed kernel).  Its statistics live in LDS behind the
@@ -470,9 +484,19 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             }
         }
         stamp(1);
-        if (__ballot(alive) == 0) {
-            if (drained) break;
-            continue;
+        {
+            const unsigned long long am = __ballot(alive);
+            if (am == 0) {
+                if (drained) break;
+                continue;
+            }
+            // tickets dry and down to the last rays (voxel_coop.hip): one or two at once, a handful once they have outlived the
+            // rest of the batch by COOP_PATIENCE rounds -- the whole wave then traces them one after the other
+            if (COOP && drained && coop_on) {
+                const int left = __popcll(am);
+                if (left <= HARE_K1P_COOP_NOW || (left <= HARE_K1P_COOP_MAX && tail_rounds >= HARE_K1P_COOP_PATIENCE)) break;
+                ++tail_rounds;
+            }
         }
         if (PROF) bump(14, __popcll(__ballot(alive)));
 
@@ -592,6 +616,36 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
             }
         }
         stamp(4);
+    }
+    if (COOP) {
+        // ---- the cooperative tail: each ray still alive is traced by the whole wave from where its lane left it.  The lane's walk
+        // state goes through the ray's own event slot (scratch until the ray finishes, as in K1q): nothing of it stays in registers.
+        if (alive) {
+            double* sc = reinterpret_cast<double*>(&io.out[ray]);            // sc[0] holds t_start of a moved ray (the set-up put it there)
+            sc[1] = tMaxX; sc[2] = tMaxY; sc[3] = tMaxZ;
+            sc[4] = tmin;
+            const uint32_t xf = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (dx1 < 0 ? kTF_NX : 0u) | (dy1 < 0 ? kTF_NY : 0u) |
+                                (dz1 < 0 ? kTF_NZ : 0u) | (moved ? kTF_MOVED : 0u);
+            sc[5] = __hiloint2double(pid, (int)xf);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned long long left = __ballot(alive);
+        while (left) {
+            const int l = (int)__builtin_ctzll(left);
+            left &= left - 1ull;
+            const unsigned cray_ray = (unsigned)__builtin_amdgcn_readlane((int)ray, l);
+            double* sc = reinterpret_cast<double*>(&io.out[cray_ray]);
+            const double w5 = sc[5];
+            const uint32_t xf = (uint32_t)__double2loint(w5);
+            double ctmin = sc[4];
+            int cpid = __double2hiint(w5);
+            const bool hit = coop_trace<QUADS, COARSE>(g, io, locc, cray_ray, xf, sc[1], sc[2], sc[3], ctmin, cpid);
+            if (lane == l) {           // the ray's own lane finishes it (o, d, moved are its registers; t_start is read back from sc[0])
+                tmin = ctmin;
+                pid = cpid;
+                finish(hit);
+            }
+        }
     }
     if (PROF) {
         if (lane == 0 && io.prof) {
@@ -1076,11 +1130,11 @@ __global__ __launch_bounds__(256) void hare_voxel_shoot_count(VoxelArgs g, Shoot
 }
 
 // K1p: persistent Voxel_Grid.Shoot (default voxel kernel); dynamic LDS = the occupancy bitmap, one bit per voxel
-__global__ __launch_bounds__(256) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false>(g, io); }
+__global__ __launch_bounds__(256, 4) void hare_voxel_persist_tri(VoxelArgs g, ShootIO io) { voxel_persist_body<false, false>(g, io); }
+__global__ __launch_bounds__(256, 4) void hare_voxel_persist_quad(VoxelArgs g, ShootIO io) { voxel_persist_body<true, false>(g, io); }
 // same for grids above ~80^3, whose bitmap has one bit per block of 2^k voxels per axis so that it still fits 64 KB of LDS
-__global__ __launch_bounds__(256) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
-__global__ __launch_bounds__(256) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
+__global__ __launch_bounds__(256, 4) void hare_voxel_persist_tri_g(VoxelArgs g, ShootIO io) { voxel_persist_body<false, true>(g, io); }
+__global__ __launch_bounds__(256, 4) void hare_voxel_persist_quad_g(VoxelArgs g, ShootIO io) { voxel_persist_body<true, true>(g, io); }
 
 #ifndef HARE_OCCL_WAVES_PER_EU
 #define HARE_OCCL_WAVES_PER_EU 4
@@ -1283,7 +1337,6 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 
 }  // extern "C"
 
-#include "voxel_coop.hip"
 #include "voxel_pool.hip"
 #include "octree_pool.hip"
 #include "build_kernels.hip"
