@@ -316,3 +316,41 @@ def test_slim_events_trees_quads_and_sharding():
     rr = H.scenes.random_rays(10_000, m.size)
     full, _ = gs.Shoot_batch(rr)
     assert gs.expand_events(rr, gs.Shoot_batch(rr, slim=True)[0]).tobytes() == full.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The cooperative tail (voxel_coop.hip): a drained wave traces its last rays with all 64 lanes
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_cooperative_tail_is_invisible_in_the_results(hall, kernel):
+    """Rays that skim the hall's floor, walls and displaced ceiling cross a hundred occupied voxels and scan thousands of list
+    entries: the rays a wave is left with at the end of a launch, which it then traces cooperatively (64 lanes on one voxel's
+    list, chunk minima with the earlier entry winning ties).  Results with the tail on, off, and from the oracle must be the same
+    bytes -- also with exclusions, with origins outside the grid, and in a batch so small that every wave goes cooperative at once."""
+    m, T, To = hall
+    rng = np.random.default_rng(23)
+    n = 120_000
+    L = np.asarray(m.size)
+    o = rng.uniform(0.02, 0.98, (n, 3)) * L
+    d = rng.normal(size=(n, 3))
+    axis = rng.integers(0, 3, n)
+    d[np.arange(n), axis] *= 1e-3                                   # nearly parallel to a pair of walls ...
+    o[np.arange(n), axis] = np.where(rng.random(n) < 0.5, 0.004, L[axis] - 0.004) + rng.normal(0, 1e-3, n)   # ... and millimetres from one of them
+    o[::9] += rng.normal(0, 25.0, (len(o[::9]), 3))                 # some start far outside the grid
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+    e1 = rng.integers(-1, m.P, n).astype(np.int32)
+    ref, rc = po.VoxelGrid([To], domain=64).shoot(rays, excl1=e1, nthreads=16)
+    assert rc["entries"] / n > 150                                  # heavy rays indeed (the burst scans 18 entries per ray)
+    g = H.Voxel_Grid([T], 64)
+    g.set_option("voxel_kernel", kernel)
+    got = {}
+    for coop in (1, 0):
+        g.set_option("coop_tail", coop)
+        got[coop], c = g.Shoot_batch(rays, poly_origin1=e1)
+        assert_events_equal(got[coop], ref, what=f"kernel {kernel}, coop_tail {coop}")
+        assert (c["rays"], c["hits"]) == (n, rc["hits"])
+    assert got[0].tobytes() == got[1].tobytes()
+    g.set_option("coop_tail", 1)
+    for k in (1, 3, 64, 700):                                       # launches in which a wave holds only a few rays from the start
+        ev, _ = g.Shoot_batch(rays[:k], poly_origin1=e1[:k])
+        assert ev.tobytes() == ref[:k].tobytes()
