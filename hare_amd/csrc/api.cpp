@@ -443,8 +443,8 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 // in flight per CU and requests eight candidates' records per task, which is what covers miss latency --
 //  * a scene far beyond the L2 (the 986k-triangle cathedral, ~200 MB): K1q from one pool fill of the whole chip
 //    (CUs x 12 waves x 128 rays = 393 216 rays on the 256-CU MI355X; 524k: -18 ... -28 %; 262k: +12 ... +33 %);
-//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): from three fills (1 179 648 rays: -2 %
-//    there, -9 % at 1.5M, -20 % at 16M; +7 % at the 1M-ray headline, +17 ... +68 % from 65k to 524k).
+//  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): from two fills (786 432 rays) on a grid with one
+//    occupancy bit per voxel, three on a coarser bitmap (round 2, before the cooperative tails: three fills everywhere).
 // Both thresholds scale with the CU count of the device the scene lives on.
 enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctOccl,
                   KdSimple, KdCount, None };
@@ -500,8 +500,12 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
         const bool pool_fits = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= kLdsMax && s.vox.ct <= 512 && !(flags & 0x4000u);
         const int64_t fill = (int64_t)cus * kPoolWaves * kPoolSlots;          // rays in flight when every pool of the chip is full
+        // (round 3, with the cooperative tails: the resident scene's crossover came down from three fills to two on a grid with one
+        //  bit per voxel -- hall D = 64: 786k rays -8 %, 1M -1.4 %, 1.18M -6 %, 2M -17 %; 524k +9 % -- and stayed at three on a coarse
+        //  bitmap -- hall D = 128: 1M +4.6 %; profiles/r03_experiments/k1p_k1q_crossover_with_coop_tail.log)
+        const int64_t resident_from = (coarse ? 3 : 2) * fill;
         const bool pool_wanted = s.opt.voxel_kernel == 2 || (s.opt.voxel_kernel == 0 &&
-                                 n >= (voxel_scene_bytes(s, top) > (96ull << 20) ? fill : 3 * fill));
+                                 n >= (voxel_scene_bytes(s, top) > (96ull << 20) ? fill : resident_from));
         hipFunction_t DeviceModule::*pf = !coarse ? (quads ? &DeviceModule::voxel_pool_quad : &DeviceModule::voxel_pool_tri)
                                                    : (quads ? &DeviceModule::voxel_pool_quad_g : &DeviceModule::voxel_pool_tri_g);
         if (pool_wanted && pool_fits && have(pf)) {
@@ -1023,7 +1027,14 @@ static int sync_partition_to_device(hare_scene* s, int kind)
     if (rc) return rc;
     if (kind == HARE_KIND_VOXEL) return upload_voxel(*s, H);
     if (kind == HARE_KIND_OCTREE) {
-        rc = upload(H, &s->d_oct_nodes, s->oct.nodes.data(), s->oct.nodes.size() * sizeof(OctNode));
+        // the device copy of a leaf carries its first two list entries (OctNode, hare_device.h)
+        std::vector<OctNode> dev(s->oct.nodes);
+        for (OctNode& nd : dev)
+            if (nd.first_child < 0) {
+                nd.pad = nd.item_count > 0 ? s->oct.items[(size_t)nd.item_start] : -1;
+                nd.first_child = nd.item_count > 1 ? -2 - s->oct.items[(size_t)nd.item_start + 1] : -1;
+            }
+        rc = upload(H, &s->d_oct_nodes, dev.data(), dev.size() * sizeof(OctNode));
         if (rc) return rc;
         return upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
     }

@@ -79,7 +79,10 @@ struct VoxelArgs {
 
 struct OctNode {               // 64 bytes
     double bmin[3], bmax[3];
-    int32_t first_child;       // -1 leaf
+    int32_t first_child;       // interior: index of the first of eight consecutive children; leaf: negative.  On the host (builders,
+                               // hare_shoot_one, hare_octree_get_nodes) a leaf holds -1; the DEVICE copy of a leaf holds -2 - items[start + 1]
+                               // (-1 when the list has fewer than two entries) and `pad` items[start] (-1: empty list): entering a leaf
+                               // costs no list load for its first pair of candidates (as CellRec does for the grid)
     int32_t item_start;
     int32_t item_count;
     int32_t pad;

@@ -809,6 +809,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     int mask = 0, lvl = -1;
     int e1 = -1, e2 = -1;
     int q = 0, qe = 0;                  // remaining candidates of the current leaf: items[q .. qe)
+    int idx = -1, nexti = -1;           // items[q], items[q + 1], already here: a cull iteration waits for ONE round of loads, not two
     double leaf_ca = 0;                 // nodeTmin of the current leaf
     double closestT = kDblMax, bu = 0, bv = 0;
     int pid = -1;
@@ -851,6 +852,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         auto mn = [](double a, double b) { return FAST ? __builtin_fmin(a, b) : omin(a, b); };
         if (nd.first_child < 0) {
             q = nd.item_start; qe = nd.item_start + nd.item_count; leaf_ca = ca;
+            idx = nd.pad;                                  // a leaf's first two list entries travel in its node record (OctNode, hare_device.h)
+            nexti = -2 - nd.first_child;
         } else {
             double nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];     // entry / exit parameter of the low (0) and high (1) child slab
             {
@@ -949,6 +952,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         const double rmin = omax(omax(tx0, ty0), tz0), rmax = omin(omin(tx1, ty1), tz1);   // :182-183
                         if (rmax < rmin || rmax < 0) finish();               // :185 (and the identical pop test :207)
                         else visit(root, rmin, rmax, std::false_type{});
+                        // (Sending the root through the pop phase instead -- a level-0 frame with node 0 as its only child -- takes the
+                        //  root's visit out of this set-up path, where the compiler spills ~20 registers around it, and was measured:
+                        //  bit-exact, 2.88 -> 3.32 ms at 1M rays.  The spills sit here and in the kernel's prologue only, once per ray.)
                     }
                 }
             }
@@ -1020,21 +1026,29 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             if (__ballot(culling) == 0) break;
             if (culling) {
                 const bool has1 = q + 1 < qe;
-                const int i0 = g.items[q];
-                int i1 = -1;
-                if (has1) i1 = g.items[q + 1];
+                // the two entries AFTER this pair, for the next iteration: one 8-byte gather (4-byte alignment is all the hardware asks
+                // for), requested together with the pair's records -- so an iteration has one round of dependent loads, not two
+                int i2 = -1, i3 = -1;
+                if (qe - q >= 4) {
+                    const int2 w = *reinterpret_cast<const int2*>(g.items + q + 2);
+                    i2 = w.x; i3 = w.y;
+                } else if (q + 2 < qe) {
+                    i2 = g.items[q + 2];                                     // q + 3 >= qe: i3 is never a candidate
+                }
+                const int i0 = idx, i1 = has1 ? nexti : -1;
                 const bool sk0 = recently(i0);
                 const bool sk1 = !has1 || recently(i1) || i1 == i0;
                 CullRaw ra, rb;
                 if (!sk0) ra = load_rec(i0);
                 if (!sk1) rb = load_rec(i1);
+                const int q_before = q;
                 bool consumed0 = true;
                 if (!sk0) {
                     if (HARE_K2P_MAILBOX >= 4) { m3 = m2; m2 = m1; }
                     if (HARE_K2P_MAILBOX >= 2) m1 = m0;
                     if (HARE_K2P_MAILBOX >= 1) m0 = i0;
                     if (culled(ra)) ++q;
-                    else { parked = true; consumed0 = false; }           // phase B2 tests items[q]
+                    else { parked = true; consumed0 = false; }           // phase B2 tests idx (= items[q])
                 } else {
                     ++q;
                 }
@@ -1049,6 +1063,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         else parked = true;
                     }
                 }
+                const int adv = q - q_before;                                // 0, 1 or 2 entries consumed: slide the window
+                idx = adv == 2 ? i2 : (adv == 1 ? nexti : idx);
+                nexti = adv == 2 ? i3 : (adv == 1 ? i2 : nexti);
             }
         }
 
@@ -1058,12 +1075,14 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             const unsigned long long busy = __ballot(alive && !parked);
             if (pm != 0 && (__popcll(pm) >= EXACT_MIN_PARKED || busy == 0)) {
                 if (alive && parked) {
-                    const int i = g.items[q];
+                    const int i = idx;                                       // == items[q]
                     const PolyRec& p = g.polys[i];
                     const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
                     double t, u, v;
                     parked = false;
                     ++q;
+                    idx = nexti;
+                    nexti = q + 1 < qe ? g.items[q + 1] : -1;                // requested with the polygon record: not a round of its own
                     if (poly_full(p, v3, o, d, t, u, v) && t > kTMin && t < closestT) {   // :224-226
                         closestT = t; bu = u; bv = v; pid = i;
                         hit = true;

@@ -76,7 +76,7 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
     ((), "hare_voxel_persist_tri"),
     (("--kind", "octree"), "hare_octree_persist"),
     (("--bounces", "3"), "hare_voxel_persist_tri"),
-    (("--rays", "1310720"), "hare_voxel_pool_tri"),       # a launch long enough for the pool kernel (api.cpp: voxel_pool_wanted)
+    (("--rays", "1048576"), "hare_voxel_pool_tri"),       # a launch long enough for the pool kernel (api.cpp: choose_kernel)
 ])
 def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     j = _bench(*(("--rays", "32768") if "--rays" not in extra else ()), "--steps", "2", "--warmup", "1", *extra)

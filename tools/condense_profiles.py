@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_sha)
 
-SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_reflect", "hare_ctr_reduce")
+SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_reflect")
+ROUND = os.environ.get("ROUND", "r03")
 KEYS = {"c2": "hall-voxel-D64-n1048576", "c2_4M": "hall-voxel-D64-n4194304", "c3": "hall-octree-n1048576",
         "c4shard": "cathedral-voxel-D128-n2097152", "c5": "cathedral-voxel-D128-n1048576-b8"}
 
@@ -22,6 +23,24 @@ def counters(d):
     return acc
 
 
+def issue_side(cs, key):
+    """What the SQ / TA counters say about the issue side, as fractions: a wave is issuing / sits at a waitcnt
+    (of its own cycles), the texture-address units are busy (of the kernel's cycles), L1 line accesses per ray."""
+    out = {}
+    wc = cs.get("SQ_WAVE_CYCLES")
+    if wc:
+        if cs.get("SQ_ACTIVE_INST_ANY"): out["sq_active_inst_any_frac"] = round(cs["SQ_ACTIVE_INST_ANY"] / wc, 4)
+        if cs.get("SQ_WAIT_ANY"): out["sq_wait_any_frac"] = round(cs["SQ_WAIT_ANY"] / wc, 4)
+    if cs.get("TA_TA_BUSY_sum") and cs.get("GRBM_GUI_ACTIVE"):
+        out["ta_busy_frac"] = round(cs["TA_TA_BUSY_sum"] / 256.0 / (cs["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    try:
+        n = int([p for p in key.split("-") if p.startswith("n")][0][1:])
+        if cs.get("TCP_TOTAL_CACHE_ACCESSES_sum"): out["l1_accesses_per_ray"] = round(cs["TCP_TOTAL_CACHE_ACCESSES_sum"] / n, 1)
+    except Exception:
+        pass
+    return out
+
+
 def main(src):
     out = os.path.join(ROOT, "profiles")
     rows = [("config", "kernel", "counter", "mean_per_dispatch", "dispatches")]
@@ -30,7 +49,7 @@ def main(src):
         ks = glob.glob(os.path.join(src, tag + "_kt", "**", "*kernel_stats.csv"), recursive=True)
         if ks:
             lines = open(ks[0]).read().splitlines()
-            with open(os.path.join(out, f"r02_{tag}_kernel_stats.csv"), "w") as f:
+            with open(os.path.join(out, f"{ROUND}_{tag}_kernel_stats.csv"), "w") as f:
                 f.write("\n".join(lines[:9]) + "\n")
         per = {}
         for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "TA"):
@@ -45,6 +64,7 @@ def main(src):
                 traffic[key] = {"kernel": k, "FETCH_SIZE_KB": cs["FETCH_SIZE"], "WRITE_SIZE_KB": cs["WRITE_SIZE"],
                                 "hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                                 "SQ_INSTS_VALU": cs.get("SQ_INSTS_VALU"), "kernel_sha16": bench.kernel_source_sha(),
+                                **issue_side(cs, key),
                                 "note": "separate --pmc passes (rocprofv3); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH doubled per "
                                         "MI355X_MICROARCH.md (gfx950 tallies 128-B reads at 64 B; calibrated for wide coalesced reads, so an "
                                         "upper bound for this kernel's 16-B gathers)"}
@@ -52,8 +72,8 @@ def main(src):
         if os.path.exists(b):
             txt = [ln for ln in open(b).read().splitlines() if ln.startswith("{")]
             if txt:
-                open(os.path.join(out, f"r02_{tag}_bench.json"), "w").write(txt[-1] + "\n")
-    with open(os.path.join(out, "r02_pmc_summary.csv"), "w") as f:
+                open(os.path.join(out, f"{ROUND}_{tag}_bench.json"), "w").write(txt[-1] + "\n")
+    with open(os.path.join(out, f"{ROUND}_pmc_summary.csv"), "w") as f:
         for r in rows:
             f.write(",".join(str(x) for x in r) + "\n")
     old = {}
