@@ -86,6 +86,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_shoot_count", &m->octree_count},
         {"hare_octree_persist", &m->octree_persist},
         {"hare_octree_pool", &m->octree_pool},
+        {"hare_octree_tail", &m->octree_tail},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
@@ -358,18 +359,46 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
 // finished, which is the rule), so a 65th launch in flight waits for the first instead of sharing its ticket word.  The
 // slot's mutex keeps wait + launch + record together when several host threads launch on one scene.
 // args[1] must point to `io`.
+// `octree_tail_levels` > 0: a K2p launch -- it gets a block of hand-over records and is followed, on the same stream and inside the
+// slot's lock, by the cooperative tail kernel K2t (octree_coop.hip).
 int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, ShootIO& io,
-                   void** args, bool coop_tail = false)
+                   void** args, bool coop_tail = false, int octree_tail_levels = 0)
 {
     const unsigned idx = s.work_slot.fetch_add(1) % kLaunchSlots;
     Scene::LaunchSlot& sl = s.slots[idx];
     std::lock_guard<std::mutex> lk(sl.mu);
     io.work = reinterpret_cast<unsigned int*>(static_cast<LaunchSlotMem*>(s.d_work) + idx);
     io.coop_tail = (coop_tail && s.opt.coop_tail) ? 1 : 0;
+    io.oct_tail = nullptr;
+    const bool with_k2t = octree_tail_levels > 0 && s.opt.coop_tail && s.module->octree_tail != nullptr;
+    if (with_k2t) {
+        const size_t stride = ((size_t)kOctTailHead + 20u * (size_t)octree_tail_levels + 15u) & ~(size_t)15u;
+        const size_t need = (size_t)grid * (block / 64u) * (size_t)kOctTailMax * stride;
+        std::lock_guard<std::mutex> tl(s.oct_tail_mu);
+        if (need > s.oct_tail_slot_bytes) {
+            // a larger block per slot (first use, or a deeper tree since): launches in flight may still use the old one
+            if (s.d_oct_tail) {
+                HIP_TRY(H->DeviceSynchronize());
+                dev_free(H, s.d_oct_tail);
+            }
+            s.oct_tail_slot_bytes = 0;
+            HIP_TRY(H->Malloc(&s.d_oct_tail, (size_t)kLaunchSlots * need));
+            s.oct_tail_slot_bytes = need;
+        }
+        io.oct_tail = static_cast<unsigned char*>(s.d_oct_tail) + (size_t)idx * s.oct_tail_slot_bytes;
+        io.oct_tail_stride = (int32_t)stride;
+        io.oct_tail_levels = octree_tail_levels;
+    }
     if (!sl.ev) HIP_TRY(H->EventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (sl.used) HIP_TRY(H->StreamWaitEvent(st, sl.ev, 0));
-    const int rc = launch(H, f, grid, block, lds, st, args);
+    int rc = launch(H, f, grid, block, lds, st, args);
     if (rc) return rc;
+    if (with_k2t) {
+        // K2t: enough waves that every left-over ray of a typical launch gets one of its own; it reads the count K2p left behind
+        const unsigned tgrid = std::max(1u, std::min(grid, 4u * (unsigned)std::max(1, s.module->cu_count)));
+        rc = launch(H, s.module->octree_tail, tgrid, 256, 32u * 20u * (unsigned)octree_tail_levels, st, args);      // room for 32 groups of 8 lanes x levels x 20 B
+        if (rc) return rc;
+    }
     HIP_TRY(H->EventRecord(sl.ev, st));
     sl.used = true;
     return HARE_OK;
@@ -798,7 +827,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 32;   // an octree ray costs ~10x a voxel ray: ticket atomics never bind
             io.static_rays = static_chunk_rays(n, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
             if (s.opt.k2p_static_rays > 0) io.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
-            return launch_on_slot(s, H, kc.f, pgrid, 256, plds, st, io, args);
+            // the closest-hit kernel hands its last rays to the cooperative tail kernel (the occlusion build keeps them)
+            return launch_on_slot(s, H, kc.f, pgrid, 256, plds, st, io, args, false, kc.k == Kern::OctPersist ? g.max_depth : 0);
         }
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
         const unsigned levels = (unsigned)g.max_depth;
@@ -980,7 +1010,7 @@ void hare_scene_destroy(hare_scene* s)
         if (s->stream) (void)H->StreamSynchronize(s->stream);
         for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
             for (void*& p : *v) dev_free(H, p);
-        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work})
+        for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_oct_tail})
             dev_free(H, *p);
         free_bounce_buffers(H, *s);
         for (Scene::BatchCtx& c : s->ctx) {

@@ -250,11 +250,32 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 struct LaunchSlotMem {
     unsigned int ticket;
     unsigned int done[9];
-    unsigned int pad[6];
+    unsigned int oct_tail_count, oct_tail_next, oct_tail_done;      // K2p -> K2t hand-over (octree_coop.hip); K2t's last wave zeroes them
+    unsigned int pad[3];
     unsigned long long acc[128];
 };
 static_assert(sizeof(LaunchSlotMem) == 64 + 1024, "launch slot layout (kernels index it by word)");
 constexpr unsigned kLaunchSlots = 64;     // launches of one scene that may be in flight; a 65th waits for the first (api.cpp)
+
+// One ray a K2p wave handed to the cooperative tail kernel K2t (octree_coop.hip): the state of its depth-first walk.  A record is
+// 64 bytes of scalars followed by (levels) frames of 20 bytes, padded to 16: kOctTailHead + 20 * levels rounded up.
+struct OctTailRec {
+    uint32_t ray;
+    int32_t lvl;               // top frame (-1: none open)
+    int32_t q, qe;             // the current leaf's remaining entries items[q .. qe)
+    double leaf_ca;            // that leaf's entry parameter (nodeTmin)
+    double closestT, bu, bv;   // the hit so far
+    int32_t pid, hit;
+    double pad;
+};
+static_assert(sizeof(OctTailRec) == 64, "octree tail record head");
+constexpr int kOctTailHead = 64;
+#ifndef HARE_K2P_TAIL_MAX
+#define HARE_K2P_TAIL_MAX 16      // a drained K2p wave hands over its rays once this few are left and they have outlived the rest of
+                                  // the batch by HARE_K2P_TAIL_PATIENCE rounds (kernels.hip); swept at C3: (4, 0) 2.82 ms, (8, 64) 2.68,
+                                  // (16, 64) 2.69, (16, 96) 2.95, (32, 160) 3.07; without the hand-over 2.94
+#endif
+constexpr int kOctTailMax = HARE_K2P_TAIL_MAX;
 
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN
@@ -287,6 +308,9 @@ struct ShootIO {
     const double* tmax;        // nullable
     int32_t* occluded;         // nullable: n flags
     int32_t coop_tail;         // 1: a drained wave traces its last rays cooperatively (voxel_coop.hip); 0: as lanes of the pool to the end
+    unsigned char* oct_tail;   // K2p / K2t: this launch's hand-over records (waves of the K2p grid x kOctTailMax), null = every lane finishes its own
+    int32_t oct_tail_stride;   // bytes per record
+    int32_t oct_tail_levels;   // frames per record (= the levels K2p keeps in LDS)
 };
 
 }  // namespace hare

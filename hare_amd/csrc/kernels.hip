@@ -32,6 +32,7 @@
 using namespace hare;
 
 #include "voxel_coop.hip"      // coop_trace: one ray traced by a whole wave (the cooperative tail of K1p and K1q)
+#include "octree_coop.hip"     // coop_octree: the same for Octree.Shoot (kernel K2t behind K2p)
 
 namespace {
 
@@ -761,9 +762,13 @@ __device__ __forceinline__ double omin(double a, double b) { return (a < b || a 
 // t_max.  The reference pops the FAR children first and returns early as soon as a hit lies in front of the current leaf's
 // entry ("Octree - alt.cs":233), so a far leaf can end the query with a hit beyond t_max (not occluded) that a
 // walk without that leaf would replace by a nearer one (occluded): the flag would differ from the reference's closest hit.
+#ifndef HARE_K2P_TAIL_PATIENCE
+#define HARE_K2P_TAIL_PATIENCE 64
+#endif
 template <bool OCC>
 __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
 {
+    int tail_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int nt = blockDim.x, tid = threadIdx.x;
     const int levels = g.max_depth > 0 ? g.max_depth : 1;
@@ -959,9 +964,18 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 }
             }
         }
-        if (__ballot(alive) == 0) {
-            if (drained) break;
-            continue;
+        {
+            const unsigned long long am = __ballot(alive);
+            if (am == 0) {
+                if (drained) break;
+                continue;
+            }
+            // tickets dry and down to the last few rays, which have outlived the rest of the batch by HARE_K2P_TAIL_PATIENCE rounds:
+            // they go to the cooperative tail kernel (octree_coop.hip), this wave ends
+            if (!OCC && drained && io.oct_tail != nullptr) {
+                if (__popcll(am) <= kOctTailMax && tail_rounds >= HARE_K2P_TAIL_PATIENCE) break;
+                ++tail_rounds;
+            }
         }
 
         // ------------------------------------------------------------------ phase P: one child per step
@@ -1094,8 +1108,92 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         }
     }
 
+    if (!OCC && io.oct_tail != nullptr) {
+        // ---- hand-over to K2t: every lane still alive writes its walk state -- scalars, then its frames from LDS
+        const unsigned long long am = __ballot(alive);
+        if (am) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&reinterpret_cast<LaunchSlotMem*>(io.work)->oct_tail_count, (unsigned)__popcll(am));
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (alive) {
+                unsigned char* rec = io.oct_tail + (size_t)(base + (unsigned)__popcll(am & lane_lt)) * (size_t)io.oct_tail_stride;
+                OctTailRec h;
+                h.ray = ray; h.lvl = lvl; h.q = q; h.qe = qe; h.leaf_ca = leaf_ca;
+                h.closestT = closestT; h.bu = bu; h.bv = bv; h.pid = pid; h.hit = hit ? 1 : 0; h.pad = 0;
+                *reinterpret_cast<OctTailRec*>(rec) = h;
+                double* ra = reinterpret_cast<double*>(rec + kOctTailHead);
+                double* rb = ra + io.oct_tail_levels;
+                int* rk = reinterpret_cast<int*>(rb + io.oct_tail_levels);
+                for (int k = 0; k <= lvl; ++k) { ra[k] = fa[k * nt + tid]; rb[k] = fb[k * nt + tid]; rk[k] = fpk[k * nt + tid]; }
+            }
+        }
+    }
     timeline(2);
     launch_epilogue(io, nrays, nhits, 4u);
+}
+
+// K2t: the rays K2p handed over, eight at a time per wave: one per group of kOctTailGroup lanes (octree_coop.hip).  Grid: any number of
+// 256-thread workgroups; dynamic LDS = (256 / kOctTailGroup) groups x levels x 20 bytes.
+#ifndef HARE_K2T_GROUP
+#define HARE_K2T_GROUP 64          // lanes per handed-over ray: 64 = a whole wave (8: measured, slower -- the groups of a wave diverge)
+#endif
+constexpr int kOctTailGroup = HARE_K2T_GROUP;
+__device__ __forceinline__ void octree_tail_body(const OctreeArgs& g, const ShootIO& io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int G = kOctTailGroup, NG = 256 / G;        // groups per workgroup
+    const int gl = threadIdx.x & (G - 1), grp = threadIdx.x / G;
+    const int levels = io.oct_tail_levels;
+    double* const fa = reinterpret_cast<double*>(lds) + (size_t)grp * levels;
+    double* const fb = reinterpret_cast<double*>(lds) + (size_t)(NG + grp) * levels;
+    int* const fpk = reinterpret_cast<int*>(reinterpret_cast<double*>(lds) + (size_t)2 * NG * levels) + (size_t)grp * levels;
+    LaunchSlotMem* const sm = reinterpret_cast<LaunchSlotMem*>(io.work);
+    const unsigned count = sm->oct_tail_count;            // final: K2p has ended (stream order)
+    unsigned nhits = 0;
+    for (;;) {                                            // every group draws its own tickets: a group never waits for its neighbours
+        unsigned i = 0;
+        if (gl == 0) i = atomicAdd(&sm->oct_tail_next, 1u);
+        i = (unsigned)__shfl((int)i, 0, G);
+        if (i >= count) break;
+        const unsigned char* rec = io.oct_tail + (size_t)i * (size_t)io.oct_tail_stride;
+        const OctTailRec h = *reinterpret_cast<const OctTailRec*>(rec);          // one address for the group
+        const double* ra = reinterpret_cast<const double*>(rec + kOctTailHead);
+        const double* rb = ra + levels;
+        const int* rk = reinterpret_cast<const int*>(rb + levels);
+        for (int k = gl; k <= h.lvl; k += G) { fa[k] = ra[k]; fb[k] = rb[k]; fpk[k] = rk[k]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double closestT = h.closestT, bu = h.bu, bv = h.bv;
+        int pid = h.pid;
+        bool hit = h.hit != 0;
+        coop_octree<G>(g, io, fa, fb, fpk, h.ray, h.lvl, h.q, h.qe, h.leaf_ca, closestT, bu, bv, pid, hit);
+        if (gl == 0) {
+            XEventRec ev;
+            if (hit) {
+                const RayRec r = io.rays[h.ray];
+                ev.t = closestT; ev.u = bu; ev.v = bv;
+                ev.x = r.x + r.dx * closestT; ev.y = r.y + r.dy * closestT; ev.z = r.z + r.dz * closestT;
+                ev.poly_id = pid;
+                ev.hit = 1;
+                nhits++;
+            } else {
+                set_miss(ev);
+            }
+            store_event_streaming(&io.out[h.ray], ev);
+        }
+    }
+    // the rays were counted by K2p when it set them up; their hits are counted here.  The last wave of this grid leaves the hand-over
+    // counters zeroed for the launch that uses the slot next.
+    const unsigned long long wh = wave_sum_u32(gl == 0 ? nhits : 0u);          // valid in lane 0 of the wave
+    if ((threadIdx.x & 63) == 0) {
+        if (io.ctr && wh) atomicAdd(&io.ctr[CTR_HITS], wh);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&sm->oct_tail_done, 1u) == gridDim.x * 4u - 1u) {
+            atomicExch(&sm->oct_tail_count, 0u);
+            atomicExch(&sm->oct_tail_next, 0u);
+            atomicExch(&sm->oct_tail_done, 0u);
+        }
+    }
 }
 
 
@@ -1179,6 +1277,8 @@ __global__ __launch_bounds__(256) void hare_octree_shoot_count(OctreeArgs g, Sho
 #define HARE_K2P_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persist(OctreeArgs g, ShootIO io) { octree_persist_body<false>(g, io); }
+// K2t: the cooperative tail behind K2p (octree_coop.hip)
+__global__ __launch_bounds__(256) void hare_octree_tail(OctreeArgs g, ShootIO io) { octree_tail_body(g, io); }
 // the occlusion predicate on the same walk (flags only, any-hit early out); same launch geometry
 __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true>(g, io); }
 

@@ -86,7 +86,7 @@ struct DeviceModule {
     hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t voxel_pool_tri = nullptr, voxel_pool_quad = nullptr, voxel_pool_tri_g = nullptr, voxel_pool_quad_g = nullptr;
-    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr;
+    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr;
@@ -159,6 +159,10 @@ struct Scene {
     };
     LaunchSlot slots[kLaunchSlots];
     SceneOptions opt;
+    // K2p -> K2t hand-over records (octree_coop.hip): one block per launch slot
+    void* d_oct_tail = nullptr;
+    size_t oct_tail_slot_bytes = 0;
+    std::mutex oct_tail_mu;
 
     // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
     // over), so that host threads calling on one scene run side by side instead of queueing on one mutex; `mu` guards

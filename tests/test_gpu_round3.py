@@ -354,3 +354,42 @@ def test_cooperative_tail_is_invisible_in_the_results(hall, kernel):
     for k in (1, 3, 64, 700):                                       # launches in which a wave holds only a few rays from the start
         ev, _ = g.Shoot_batch(rays[:k], poly_origin1=e1[:k])
         assert ev.tobytes() == ref[:k].tobytes()
+
+
+def test_octree_tail_kernel_is_invisible_in_the_results(hall):
+    """K2p hands the last, long-lived rays of a launch to K2t (octree_coop.hip: a wave per ray; the children of a frame on eight
+    lanes, a leaf's list replayed from per-lane results with the reference's strict-< scan and its early return).  With the hand-over
+    on, off, and from the oracle the events must be the same bytes: burst rays, surface-skimming rays (the heavy ones), exclusions,
+    a deep tree over a small crowded scene, and batches so small that everything is handed over."""
+    m, T, To = hall
+    rng = np.random.default_rng(29)
+    n = 150_000
+    L = np.asarray(m.size)
+    o = rng.uniform(0.02, 0.98, (n, 3)) * L
+    d = rng.normal(size=(n, 3))
+    axis = rng.integers(0, 3, n)
+    half = n // 2
+    d[np.arange(half), axis[:half]] *= 1e-3                          # half of them skim a wall, the floor or the ceiling
+    o[np.arange(half), axis[:half]] = np.where(rng.random(half) < 0.5, 0.004, L[axis[:half]] - 0.004)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+    rays[half:] = H.scenes.burst_rays(n - half, m.size)
+    e1 = rng.integers(-1, m.P, n).astype(np.int32)
+    oc, oo = H.Octree([T], 8, 16), po.Octree([To], 8, 16)
+    assert oc.kernel_name(n) == "hare_octree_persist"
+    ref, rc = oo.shoot(rays, excl1=e1, nthreads=16)
+    got = {}
+    for coop in (1, 0):
+        oc.set_option("coop_tail", coop)
+        got[coop], c = oc.Shoot_batch(rays, poly_origin1=e1)
+        assert_events_equal(got[coop], ref, what=f"octree, tail kernel {coop}")
+        assert (c["rays"], c["hits"]) == (n, rc["hits"])
+    assert got[0].tobytes() == got[1].tobytes()
+    oc.set_option("coop_tail", 1)
+    for k in (1, 5, 64, 900):
+        ev, c = oc.Shoot_batch(rays[:k], poly_origin1=e1[:k])
+        assert ev.tobytes() == ref[:k].tobytes() and c["hits"] == int(ref["hit"][:k].sum())
+    v, nv, size = soup(n_tri=900, n_quad=300, seed=6)                 # quadrilaterals, a tree of 7 levels with 2 polygons per leaf
+    sr = soup_rays(50_000, size, seed=14)
+    g2, o2 = H.Octree([H.Topology(v, nv)], 7, 2), po.Octree([po.Topology(v, nv)], 7, 2)
+    assert_events_equal(g2.Shoot_batch(sr)[0], o2.shoot(sr, nthreads=16)[0], what="octree 7/2 with quads, tail kernel on")
