@@ -371,21 +371,27 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     io.coop_tail = (coop_tail && s.opt.coop_tail) ? 1 : 0;
     io.oct_tail = nullptr;
     const bool with_k2t = octree_tail_levels > 0 && s.opt.coop_tail && s.module->octree_tail != nullptr;
+    std::unique_lock<std::mutex> tail_lk(s.oct_tail_mu, std::defer_lock);
+    int tail_ring = -1;
     if (with_k2t) {
         const size_t stride = ((size_t)kOctTailHead + 20u * (size_t)octree_tail_levels + 15u) & ~(size_t)15u;
         const size_t need = (size_t)grid * (block / 64u) * (size_t)kOctTailMax * stride;
-        std::lock_guard<std::mutex> tl(s.oct_tail_mu);
-        if (need > s.oct_tail_slot_bytes) {
-            // a larger block per slot (first use, or a deeper tree since): launches in flight may still use the old one
+        tail_lk.lock();                      // held until K2t is launched and the block's event recorded
+        if (need > s.oct_tail_block_bytes) {
+            // larger blocks (first use, or a deeper tree since): launches in flight may still use the old ones
             if (s.d_oct_tail) {
                 HIP_TRY(H->DeviceSynchronize());
                 dev_free(H, s.d_oct_tail);
             }
-            s.oct_tail_slot_bytes = 0;
-            HIP_TRY(H->Malloc(&s.d_oct_tail, (size_t)kLaunchSlots * need));
-            s.oct_tail_slot_bytes = need;
+            s.oct_tail_block_bytes = 0;
+            HIP_TRY(H->Malloc(&s.d_oct_tail, (size_t)Scene::kOctTailRing * need));
+            s.oct_tail_block_bytes = need;
+            for (bool& u : s.oct_tail_used) u = false;
         }
-        io.oct_tail = static_cast<unsigned char*>(s.d_oct_tail) + (size_t)idx * s.oct_tail_slot_bytes;
+        tail_ring = (int)(s.oct_tail_seq++ % (unsigned)Scene::kOctTailRing);
+        if (!s.oct_tail_ev[tail_ring]) HIP_TRY(H->EventCreateWithFlags(&s.oct_tail_ev[tail_ring], hipEventDisableTiming));
+        if (s.oct_tail_used[tail_ring]) HIP_TRY(H->StreamWaitEvent(st, s.oct_tail_ev[tail_ring], 0));
+        io.oct_tail = static_cast<unsigned char*>(s.d_oct_tail) + (size_t)tail_ring * s.oct_tail_block_bytes;
         io.oct_tail_stride = (int32_t)stride;
         io.oct_tail_levels = octree_tail_levels;
     }
@@ -398,6 +404,8 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
         const unsigned tgrid = std::max(1u, std::min(grid, 4u * (unsigned)std::max(1, s.module->cu_count)));
         rc = launch(H, s.module->octree_tail, tgrid, 256, 32u * 20u * (unsigned)octree_tail_levels, st, args);      // room for 32 groups of 8 lanes x levels x 20 B
         if (rc) return rc;
+        HIP_TRY(H->EventRecord(s.oct_tail_ev[tail_ring], st));
+        s.oct_tail_used[tail_ring] = true;
     }
     HIP_TRY(H->EventRecord(sl.ev, st));
     sl.used = true;
@@ -1024,6 +1032,8 @@ void hare_scene_destroy(hare_scene* s)
         }
         for (Scene::LaunchSlot& sl : s->slots)
             if (sl.ev) { (void)H->EventSynchronize(sl.ev); (void)H->EventDestroy(sl.ev); sl.ev = nullptr; }
+        for (hipEvent_t& e : s->oct_tail_ev)
+            if (e) { (void)H->EventSynchronize(e); (void)H->EventDestroy(e); e = nullptr; }
         if (s->stream) (void)H->StreamDestroy(s->stream);
     }
     delete s;

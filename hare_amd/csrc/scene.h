@@ -159,9 +159,14 @@ struct Scene {
     };
     LaunchSlot slots[kLaunchSlots];
     SceneOptions opt;
-    // K2p -> K2t hand-over records (octree_coop.hip): one block per launch slot
+    // K2p -> K2t hand-over records (octree_coop.hip): a ring of blocks, one per K2p launch in flight; a block comes round after
+    // kOctTailRing launches and its previous user must have finished (event), wait + launches + record under the mutex
+    static constexpr int kOctTailRing = 8;
     void* d_oct_tail = nullptr;
-    size_t oct_tail_slot_bytes = 0;
+    size_t oct_tail_block_bytes = 0;
+    unsigned oct_tail_seq = 0;
+    hipEvent_t oct_tail_ev[kOctTailRing] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool oct_tail_used[kOctTailRing] = {false, false, false, false, false, false, false, false};
     std::mutex oct_tail_mu;
 
     // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
