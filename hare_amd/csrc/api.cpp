@@ -412,14 +412,14 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     return HARE_OK;
 }
 
-// Public flag bits; the developer bits (0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
+// Public flag bits; the developer bits (0x1000 round trace, 0x2000 timeline, 0x4000 phase profile, 0x8000 cull audit: they write past the
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass on a scene whose
 // `dev` option is set (HARE_DEV=1 when the scene was created, or hare_scene_set_option), so a stray bit from a caller can
 // never reach a kernel.
 constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS | HARE_SHOOT_SLIM_EVENTS;
 uint32_t sanitize_flags(const Scene& s, uint32_t flags)
 {
-    return flags & (kPublicFlags | (s.opt.dev ? 0xE000u : 0u));
+    return flags & (kPublicFlags | (s.opt.dev ? 0xF000u : 0u));
 }
 
 // The scene's options as the environment gives them; called once per scene, from hare_scene_create (single-caller by contract).
@@ -725,7 +725,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         if (kc.k == Kern::VoxelAudit || kc.k == Kern::VoxelCount || kc.k == Kern::VoxelSimple)
             return launch(H, kc.f, grid, block, 0, st, args);
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;     // the occupancy bitmap, <= 64 KB (occ_layout)
-        if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
+        if ((flags & 0x3000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline (0x2000) / round trace (0x1000)
         if (kc.k == Kern::VoxelPool) {
             // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
             const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
@@ -788,7 +788,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             set_error("hare_shoot: octree kernel missing from code object");
             return HARE_E_STATE;
         }
-        if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
+        if ((flags & 0x3000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline (0x2000) / round trace (0x1000)
         if (kc.k == Kern::OctPool) {
             // K2q (octree_pool.hip): more rays than lanes; frames below the top one in a device scratch block per launch in flight
             const unsigned stride = 24u + 24u * (unsigned)g.max_depth;

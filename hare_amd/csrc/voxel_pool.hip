@@ -57,6 +57,9 @@
 #define HARE_K1Q_COOP_MAX 8       // ... or this few, once they have outlived the rest of the batch by
 #define HARE_K1Q_COOP_PATIENCE 48 // this many rounds (heavy rays)
 #endif
+#ifndef HARE_K1Q_WIDE_MAX
+#define HARE_K1Q_WIDE_MAX 32      // tickets dry and at most this many rays left (<= 64): the cull runs WIDE -- up to 16 lanes per ray, four candidates per
+#endif                            // lane, their list entries and records requested together (two dependent round trips per task instead of five)
 #ifndef HARE_K1Q_REFILL_MIN
 #define HARE_K1Q_REFILL_MIN 64    // set up new rays when this many slots are free (a full wave of set-ups)
 #endif
@@ -282,6 +285,15 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             } else if (left == 0) continue;
         }
         ++rounds_done;
+        if (__builtin_expect((io.flags & 0x1000u) != 0 && io.prof != nullptr, 0)) {
+            // developer round trace (flag 0x1000, tools/round_trace.py): one wave in 256 stamps every round with the clock and its queue lengths
+            const unsigned gw = blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave;
+            const unsigned long long stamp = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 34) |
+                                             ((unsigned long long)(drained ? 1u : 0u) << 32) | nW | (nC << 8) | (nE << 16) | (nP << 24);
+            if ((gw & 255u) == 5u && rounds_done < 1024u && lane == 0) io.prof[32 + 4 * 4096 + (gw >> 8) * 1024 + rounds_done] = stamp;
+            // ... and EVERY wave its first 48 rounds after the tickets ran dry (what the latest waves of a launch are doing)
+            if (drained && tail_rounds <= 48u && tail_rounds > 0u && lane == 0) io.prof[32 + 4 * 4096 + 16 * 1024 + gw * 48u + (tail_rounds - 1u)] = stamp;
+        }
 
         // ------------------------------------------------------------------ pick the phase for this round
         // Normally ONE phase per round, the one that fills the lanes best.  Once the tickets are dry and few rays are
@@ -289,6 +301,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         // pend), so that a ray advances several phases per round: at the end of a launch latency is all that counts.
         const unsigned big = nW > nC ? nW : nC;
         const bool tail = drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_TAIL;
+        // ... and once the pool is down to a few rays, a ray's candidates are spread over several lanes (the wide cull below).  Both
+        // conditions only ever go from false to true (no ray is set up after the tickets ran dry), which the wide cull relies on.
+        const bool wide = HARE_K1Q_WIDE_MAX > 0 && drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_WIDE_MAX;
         const int sel = (nE >= (unsigned)HARE_K1Q_EXACT_MIN || (big == 0 && nP == 0)) ? 0
                         : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
         HARE_K1Q_PHASE_FENCE();      // the set-up's scratch stores, before any phase reads them
@@ -344,7 +359,83 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_free, hF, nF, exited, slot);
         }
         HARE_K1Q_PHASE_FENCE();
-        if (tail ? nC > 0 : sel == 2) {
+        if (wide && nC > 0) {
+            // -------------------------------------------------------------- the WIDE pre-cull of the drain
+            // The launch ends with its longest chains, and in the drain those are list scans: a ray in a voxel with a hundred entries
+            // needs a dozen cull tasks of eight candidates, each task five dependent round trips (tools/round_trace.py: ~9 us per round,
+            // the cull queue 49 -> 23 -> 13 -> 8 -> 4 -> 3 rays).  With few rays left the lanes are free: every ray of the queue gets
+            // G = 2 .. 16 lanes, lane `sub` takes the four entries q + 4 sub .. + 3 -- list entries first, then all four records at once,
+            // two round trips -- and the group's first survivor IN LIST ORDER goes to the exact phase, exactly the candidate the
+            // sequential scan would have stopped at (the pre-cull has no state: it depends on the ray and the polygon only; skipping
+            // the polygon tested last stays exact for the rest of the ray's life, see the mailbox note below).  L_idx is written for
+            // a survivor only and L_nexti not at all: the exact phase re-reads its successor from the list while `wide` holds, and the
+            // sequential cull never runs again (`wide` is monotonic).
+            const unsigned nq = nC;                                         // <= HARE_K1Q_WIDE_MAX <= 64: the whole queue, every round
+            unsigned gsh = 0;
+            while (gsh < 4u && (nq << (gsh + 1u)) <= 64u) ++gsh;
+            const unsigned G = 1u << gsh, grp = lane >> gsh, sub = lane & (G - 1u);
+            const bool act = grp < nq;
+            const unsigned slot = Q_cull[(hC + (act ? grp : 0u)) & SM];
+            hC = (hC + nq) & SM;
+            nC = 0;
+            bool s0 = false, s1 = false, s2 = false, s3 = false;
+            int it0 = 0, it1 = 0, it2 = 0, it3 = 0;
+            unsigned q = 0, qe = 1;
+            uint32_t xf = 0;
+            if (act) {
+                const unsigned ray = L_ray[slot];
+                q = L_q[slot];
+                qe = L_qe[slot];
+                xf = L_xyzf[slot];
+                const int done1 = L_d1[slot];
+                int e1 = -1, e2 = -1;
+                if (io.excl1) e1 = io.excl1[ray];
+                if (io.excl2) e2 = io.excl2[ray];
+                const RayRec r = io.rays[ray];
+                double ox = r.x, oy = r.y, oz = r.z;
+                if ((xf & F_MOVED) && !writeback) {
+                    const double ts = reinterpret_cast<const double*>(&io.out[ray])[1];
+                    ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
+                }
+                const CullRay cray = cull_ray(g, ox, oy, oz, r.dx, r.dy, r.dz);
+                const unsigned k0 = q + 4u * sub, last = qe - 1u;           // q < qe for every ray in the cull queue
+                it0 = g.items[k0 < last ? k0 : last];
+                it1 = g.items[k0 + 1u < last ? k0 + 1u : last];
+                it2 = g.items[k0 + 2u < last ? k0 + 2u : last];
+                it3 = g.items[k0 + 3u < last ? k0 + 3u : last];
+                const CullRaw r0 = cull_load(g, it0), r1 = cull_load(g, it1), r2 = cull_load(g, it2), r3 = cull_load(g, it3);
+                auto keep = [&](unsigned k, int it, const CullRaw& rr) {
+                    return k < qe && it != e1 && it != e2 && !(HARE_K1Q_MAILBOX && it == done1) && !cull_test(g, cray, rr);
+                };
+                s0 = keep(k0, it0, r0);
+                s1 = keep(k0 + 1u, it1, r1);
+                s2 = keep(k0 + 2u, it2, r2);
+                s3 = keep(k0 + 3u, it3, r3);
+            }
+            const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1), b2 = __ballot(s2), b3 = __ballot(s3);
+            const unsigned sh = grp << gsh;
+            const unsigned gm = (1u << G) - 1u;                             // G <= 16
+            const unsigned m0 = (unsigned)(b0 >> sh) & gm, m1 = (unsigned)(b1 >> sh) & gm, m2 = (unsigned)(b2 >> sh) & gm, m3 = (unsigned)(b3 >> sh) & gm;
+            unsigned first = 0xFFFFu;                                       // the group's first survivor, as an offset from q
+            if (m0) first = 4u * (unsigned)__builtin_ctz(m0);
+            if (m1) { const unsigned f = 4u * (unsigned)__builtin_ctz(m1) + 1u; first = f < first ? f : first; }
+            if (m2) { const unsigned f = 4u * (unsigned)__builtin_ctz(m2) + 2u; first = f < first ? f : first; }
+            if (m3) { const unsigned f = 4u * (unsigned)__builtin_ctz(m3) + 3u; first = f < first ? f : first; }
+            const bool found = first != 0xFFFFu;
+            const unsigned window = (qe - q) < 4u * G ? (qe - q) : 4u * G;
+            const unsigned q_new = q + (found ? first : window);
+            if (act && found && sub == (first >> 2)) {                      // the lane that holds the survivor: the exact phase tests L_idx
+                const unsigned j = first & 3u;
+                L_idx[slot] = j == 0u ? it0 : (j == 1u ? it1 : (j == 2u ? it2 : it3));
+            }
+            const bool lead = act && sub == 0u;
+            if (lead) L_q[slot] = q_new;
+            const bool exhausted = !found && q_new >= qe;
+            push(Q_walk, hW, nW, lead && exhausted && !(xf & F_HIT), slot);
+            push(Q_cull, hC, nC, lead && !found && !exhausted, slot);
+            push(Q_exact, hE, nE, lead && found, slot);
+            push(Q_pend, hP, nP, lead && exhausted && (xf & F_HIT) != 0u, slot);
+        } else if (tail ? nC > 0 : sel == 2) {
             // -------------------------------------------------------------- FP32 pre-cull, 2 x CULL_PAIRS candidates per ray at most
             bool act;
             const unsigned slot = pop(Q_cull, hC, nC, act);
@@ -413,8 +504,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 to_pend = exhausted && (xf & F_HIT);
                 to_walk = exhausted && !(xf & F_HIT);
             }
-            if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
-                // developer statistic (tools/share_stat.py): how many DIFFERENT polygons do the lanes of one cull batch look at?
+            if (__builtin_expect((io.flags & 0x3000u) == 0x3000u && io.prof != nullptr, 0)) {
+                // developer statistic (tools/share_stat.py; both developer bits, so that the timeline alone stays cheap): how many DIFFERENT polygons do the lanes of one cull batch look at?
                 // (what a wave-shared LDS tile of polygon records could save: lanes - distinct record fetches)
                 unsigned long long left = __ballot(act);
                 unsigned distinct = 0;
@@ -446,6 +537,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 double* sc = reinterpret_cast<double*>(&io.out[ray]);
                 const unsigned qa = q + 2 < qe ? q + 2 : qe - 1;
                 const int after = g.items[qa];                              // items[q + 2]: nexti once this candidate is done
+                // items[q + 1]: in the pool's slot state, except behind the wide cull, which leaves only L_idx (the candidate) current
+                const int succ = wide ? g.items[q + 1u < qe ? q + 1u : qe - 1u] : L_nexti[slot];
                 const double tmin = sc[0];
                 const RayRec r = io.rays[ray];
                 const PolyRec& p = g.polys[i];
@@ -488,7 +581,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 L_d1[slot] = i;
                 // next_candidate()
                 ++q;
-                L_idx[slot] = L_nexti[slot];
+                L_idx[slot] = succ;
                 L_nexti[slot] = after;
                 L_q[slot] = q;
                 to_cull = q < qe;
@@ -578,6 +671,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #undef HARE_K1Q_STEP
 #undef HARE_K1Q_PHASE_FENCE
     unsigned helped = 0;
+    const unsigned long long t_coop = __builtin_amdgcn_s_memrealtime();       // developer timeline: when the pool rounds ended
     if (coop && nW + nC + nE + nP > 0) {
         // ---- the cooperative tail: what is left (at most HARE_K1Q_COOP_MAX rays, in whatever queue) is traced by the whole wave,
         // one ray after the other, from the state the pool left it in
@@ -625,8 +719,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         }
     }
     timeline(2, __builtin_amdgcn_s_memrealtime());
-    timeline(3, rounds_done | ((unsigned long long)helped << 32));
-    if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
+    timeline(3, (rounds_done & 0xFFFFu) | ((unsigned long long)(helped & 0xFFu) << 16) | (t_coop << 24));
+    if (__builtin_expect((io.flags & 0x3000u) == 0x3000u && io.prof != nullptr, 0)) {
         if (lane == 0) {
             atomicAdd(&io.prof[0], stat_lanes);
             atomicAdd(&io.prof[1], stat_distinct);

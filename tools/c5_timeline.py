@@ -32,7 +32,10 @@ for cfg in sys.argv[1:] or ["0"]:
         g.shoot_device(N, d_rays.data_ptr(), d_ev.data_ptr(), d_excl1=d_ex.data_ptr(), d_counters=buf.data_ptr(), stream=st,
                        flags=capi.SHOOT_RETIRED_RAYS | 0x2000)
         e1.record(); torch.cuda.synchronize()
-    tl = buf.cpu().numpy()[8 + 32:].reshape(W, 4).astype(np.float64)
+    raw = buf.cpu().numpy()[8 + 32:].reshape(W, 4)
+    tl = raw.astype(np.float64)
+    if kern == "pool":       # K1q packs slot 3: rounds | cooperative-tail rays << 16 | clock at the end of the pool rounds << 24
+        tl[:, 3] = (raw[:, 3].astype(np.uint64) & np.uint64(0xFFFF)).astype(np.float64)
     live = tl[:, 0] > 0
     t0 = tl[live, 0].min()
     start = (tl[:, 0] - t0) / 100.0; dry = (tl[:, 1] - t0) / 100.0; end = (tl[:, 2] - t0) / 100.0

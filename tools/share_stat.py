@@ -16,7 +16,7 @@ out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
 for name, r in (("fibonacci order", rays), ("octahedral-Morton order (10 bits/axis)", rays[np.argsort(octa_key(rays[:, 3:], 10), kind="stable")])):
     dr = torch.from_numpy(np.ascontiguousarray(r)).cuda()
     buf = torch.zeros(8 + 32 + 4 * 4096, dtype=torch.int64, device="cuda")
-    g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x2000)
+    g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x3000)
     torch.cuda.synchronize()
     lanes, distinct, batches = (int(x) for x in buf[8:11])
     print("%-42s cull batches %d, lanes/batch %.1f, distinct polygons/batch %.1f -> %.1f %% of the record fetches are repeats within the batch"

@@ -18,7 +18,8 @@ for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET v
         buf.zero_()
         g.shoot_device(N, dr.data_ptr(), out.data_ptr(), d_counters=buf.data_ptr(), stream=st, flags=0x2000)
         torch.cuda.synchronize()
-    tl = buf.cpu().numpy()[8 + 32:].reshape(W, 4).astype(np.float64)
+    raw = buf.cpu().numpy()[8 + 32:8 + 32 + 4 * W].reshape(W, 4).astype(np.uint64)
+    tl = raw.astype(np.float64)
     live = tl[:, 0] > 0
     t0 = tl[live, 0].min()
     start = (tl[:, 0] - t0) / 100.0; last = (tl[:, 1] - t0) / 100.0; end = (tl[:, 2] - t0) / 100.0   # microseconds
@@ -26,6 +27,16 @@ for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET v
     if os.environ.get("HARE_VOXEL_KERNEL") == "pool":      # K1q: one workgroup per CU; slot 1 = tickets dry, slot 3 = rounds
         dry = last
         m = live
+        # slot 3 (K1q): rounds | cooperative-tail rays << 16 | clock at the end of the pool rounds << 24 (40 bits)
+        rounds = (raw[:, 3] & np.uint64(0xFFFF)).astype(np.float64); helped = ((raw[:, 3] >> np.uint64(16)) & np.uint64(0xFF)).astype(int)
+        M40 = np.uint64((1 << 40) - 1)
+        coop0 = (((raw[:, 3] >> np.uint64(24)) - (np.uint64(int(t0)) & M40)) & M40).astype(np.float64) / 100.0
+        tl[:, 3] = rounds
+        ct = end - coop0
+        print("  pool rounds end p10/50/90/max %.0f/%.0f/%.0f/%.0f us; cooperative tail: rays per wave mean %.2f, duration mean %.1f p90 %.1f max %.1f us; "
+              "of the latest 5 %% of waves: tail duration mean %.1f us, rays %.2f"
+              % (*np.percentile(coop0[m], [10, 50, 90]), coop0[m].max(), helped[m].mean(), ct[m].mean(), np.percentile(ct[m], 90), ct[m].max(),
+                 ct[m & (end > np.percentile(end[m], 95))].mean(), helped[m & (end > np.percentile(end[m], 95))].mean()))
         print("  tickets dry p10/50/90 %.0f/%.0f/%.0f  end p10/50/90/max %.0f/%.0f/%.0f/%.0f  tail(end-dry) mean %.0f  rounds/wave mean %.0f"
               % (*np.percentile(dry[m], [10, 50, 90]), *np.percentile(end[m], [10, 50, 90]), end[m].max(), (end[m] - dry[m]).mean(), tl[m, 3].mean()))
         e = np.sort(end[live]); tot = e.max()
