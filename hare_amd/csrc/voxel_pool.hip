@@ -58,8 +58,11 @@
 #define HARE_K1Q_COOP_PATIENCE 48 // this many rounds (heavy rays)
 #endif
 #ifndef HARE_K1Q_WIDE_MAX
-#define HARE_K1Q_WIDE_MAX 32      // tickets dry and at most this many rays left (<= 64): the cull runs WIDE -- up to 16 lanes per ray, four candidates per
+#define HARE_K1Q_WIDE_MAX 64      // tickets dry and at most this many rays left (<= 64): the cull runs WIDE -- up to 16 lanes per ray, four candidates per
 #endif                            // lane, their list entries and records requested together (two dependent round trips per task instead of five)
+#ifndef HARE_K1Q_WIDE_WALK
+#define HARE_K1Q_WIDE_WALK 1      // ... and the walk looks several occupied voxels ahead, one per lane of the ray's group
+#endif
 #ifndef HARE_K1Q_REFILL_MIN
 #define HARE_K1Q_REFILL_MIN 64    // set up new rays when this many slots are free (a full wave of set-ups)
 #endif
@@ -307,7 +310,137 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         const int sel = (nE >= (unsigned)HARE_K1Q_EXACT_MIN || (big == 0 && nP == 0)) ? 0
                         : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
         HARE_K1Q_PHASE_FENCE();      // the set-up's scratch stores, before any phase reads them
-        if (tail ? nW > 0 : sel == 3) {
+        if (HARE_K1Q_WIDE_WALK && wide && nW > 0) {
+            // -------------------------------------------------------------- the WIDE walk of the drain: several occupied voxels ahead
+            // What is left at the very end of a launch are rays that cross many occupied voxels whose candidates all fail the pre-cull:
+            // walk -> cull -> walk ..., one voxel per round, three dependent round trips each (tools/round_trace.py: the latest waves
+            // of a 1M-ray launch spend 8 - 10 rounds of ~5 us on their last three or four rays; a late bounce cast in the cathedral
+            // 35 - 40 rounds).  Here every lane of a ray's group of G runs the SAME walk (identical state: no divergence inside a
+            // group) and lane `sub` keeps the sub-th occupied voxel the walk meets; the G voxels' cell records are fetched together,
+            // and each lane scans ITS voxel's list four candidates at a time until one survives the pre-cull.  The ray stops at the
+            // FIRST of these voxels (in walk order) with a survivor, at that survivor; voxels in front of it whose candidates all
+            // failed are exactly the ones the one-voxel-per-round sequence would have passed (the pre-cull has no state; the walk queue
+            // holds rays WITHOUT a pending hit, so there is no IsPointInBox rule to apply on the way).  No survivor anywhere and the
+            // grid left: miss (Voxel_Grid.cs:716-757).  Work on voxels behind the stop is wasted, nothing else.
+            const unsigned nq = nW;
+            unsigned gsh = 0;
+            while (gsh < 4u && (nq << (gsh + 1u)) <= 64u) ++gsh;
+            const unsigned G = 1u << gsh, grp = lane >> gsh, sub = lane & (G - 1u);
+            const bool act = grp < nq;
+            const unsigned slot = Q_walk[(hW + (act ? grp : 0u)) & SM];
+            hW = (hW + nq) & SM;
+            nW = 0;
+            double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0, sX = 0, sY = 0, sZ = 0;
+            int X = 0, Y = 0, Z = 0, dx1 = 1, dy1 = 1, dz1 = 1, vX = 0, vY = 0, vZ = 0;
+            uint32_t xf = 0;
+            if (act) {
+                tMaxX = L_tmx[slot]; tMaxY = L_tmy[slot]; tMaxZ = L_tmz[slot];
+                tDeltaX = L_tdx[slot]; tDeltaY = L_tdy[slot]; tDeltaZ = L_tdz[slot];
+                xf = L_xyzf[slot];
+                X = (int)(xf & 511u); Y = (int)((xf >> 9) & 511u); Z = (int)((xf >> 18) & 511u);
+                dx1 = (xf & F_NX) ? -1 : 1; dy1 = (xf & F_NY) ? -1 : 1; dz1 = (xf & F_NZ) ? -1 : 1;
+            }
+            bool walking = act, mine = false, exited = false;
+            unsigned seen = 0;
+#pragma unroll 1
+            for (int k = 0; k < HARE_K1Q_TAIL_STEPS; ++k) {
+                if (__ballot(walking) == 0) break;
+                if (walking) {
+                    HARE_K1Q_STEP();
+                    const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
+                    if (out) {
+                        exited = true;
+                        walking = false;
+                    } else if (occupied(X, Y, Z, (X * ct + Y) * ct + Z)) {
+                        if (seen == sub) { mine = true; sX = tMaxX; sY = tMaxY; sZ = tMaxZ; vX = X; vY = Y; vZ = Z; }
+                        ++seen;
+                        walking = seen < G;
+                    }
+                }
+            }
+            // the G voxels of a ray, one per lane: cell record, then its list in chunks of four (entries, then their records)
+            bool surv = false;
+            unsigned q_stop = 0, qe_stop = 0;
+            int it_stop = -1;
+            {
+                unsigned start = 0, cnt = 0;
+                int i0 = 0, i1 = 0, e1 = -1, e2 = -1, done1 = -1;
+                CullRay cray = {};
+                if (mine) {
+                    const CellRec c = g.cells[(vX * ct + vY) * ct + vZ];
+                    const unsigned ray = L_ray[slot];
+                    done1 = L_d1[slot];
+                    if (io.excl1) e1 = io.excl1[ray];
+                    if (io.excl2) e2 = io.excl2[ray];
+                    const RayRec r = io.rays[ray];
+                    double ox = r.x, oy = r.y, oz = r.z;
+                    if ((xf & F_MOVED) && !writeback) {
+                        const double ts = reinterpret_cast<const double*>(&io.out[ray])[1];
+                        ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
+                    }
+                    cray = cull_ray(g, ox, oy, oz, r.dx, r.dy, r.dz);
+                    start = c.start; cnt = c.count; i0 = c.i0; i1 = c.i1;     // cnt == 0 on a coarse bitmap: the block is occupied, this voxel is not
+                    qe_stop = start + cnt;
+                }
+                bool scanning = mine && cnt > 0u;
+                // the chunk's four list entries are requested one iteration ahead, together with the previous chunk's records: one round
+                // trip per chunk, not two (a list of one or two entries travels in the cell record)
+                int n0 = i0, n1 = cnt > 1u ? i1 : i0, n2 = i0, n3 = i0;
+                auto entries = [&](unsigned base) {
+                    const unsigned last = cnt - 1u;
+                    n0 = g.items[start + (base < last ? base : last)];
+                    n1 = g.items[start + (base + 1u < last ? base + 1u : last)];
+                    n2 = g.items[start + (base + 2u < last ? base + 2u : last)];
+                    n3 = g.items[start + (base + 3u < last ? base + 3u : last)];
+                };
+                if (scanning && cnt > 2u) entries(0u);
+#pragma unroll 1
+                for (unsigned base = 0; base < 4096u; base += 4u) {
+                    if (__ballot(scanning) == 0) break;
+                    if (scanning) {
+                        const int it0 = n0, it1 = n1, it2 = n2, it3 = n3;
+                        if (base + 4u < cnt) entries(base + 4u);
+                        const CullRaw r0 = cull_load(g, it0), r1 = cull_load(g, it1), r2 = cull_load(g, it2), r3 = cull_load(g, it3);
+                        auto keep = [&](unsigned k, int it, const CullRaw& rr) {
+                            return k < cnt && it != e1 && it != e2 && !(HARE_K1Q_MAILBOX && it == done1) && !cull_test(g, cray, rr);
+                        };
+                        const bool k0 = keep(base, it0, r0), k1 = keep(base + 1u, it1, r1), k2 = keep(base + 2u, it2, r2), k3 = keep(base + 3u, it3, r3);
+                        if (k0 | k1 | k2 | k3) {
+                            surv = true;
+                            q_stop = start + base + (k0 ? 0u : (k1 ? 1u : (k2 ? 2u : 3u)));
+                            it_stop = k0 ? it0 : (k1 ? it1 : (k2 ? it2 : it3));
+                            scanning = false;
+                        } else if (base + 4u >= cnt) {
+                            scanning = false;
+                        }
+                    }
+                }
+            }
+            const unsigned sh = grp << gsh;
+            const unsigned gm = (1u << G) - 1u;
+            const unsigned ms = (unsigned)(__ballot(surv) >> sh) & gm;
+            const bool has_stop = ms != 0u;
+            const unsigned stop_sub = has_stop ? (unsigned)__builtin_ctz(ms) : 0u;
+            const bool writer = act && has_stop && sub == stop_sub;          // the lane that holds the voxel the ray stops in
+            const bool lead = act && !has_stop && sub == 0u;                 // no stop: the ray walks on from where the walk ended, or has left the grid
+            if (writer) {
+                L_tmx[slot] = sX; L_tmy[slot] = sY; L_tmz[slot] = sZ;
+                L_xyzf[slot] = (xf & 0xF8000000u) | (uint32_t)vX | ((uint32_t)vY << 9) | ((uint32_t)vZ << 18);
+                L_q[slot] = q_stop; L_qe[slot] = qe_stop;
+                L_idx[slot] = it_stop;
+            }
+            if (lead) {
+                if (exited) {
+                    store_miss(L_ray[slot]);
+                } else {
+                    L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
+                    L_xyzf[slot] = (xf & 0xF8000000u) | (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18);
+                }
+            }
+            push(Q_walk, hW, nW, lead && !exited, slot);
+            push(Q_exact, hE, nE, writer, slot);
+            push(Q_free, hF, nF, lead && exited, slot);
+        } else if (tail ? nW > 0 : sel == 3) {
             // -------------------------------------------------------------- DDA walk over empty voxels (no hit pending)
             bool act;
             const unsigned slot = pop(Q_walk, hW, nW, act);

@@ -1,5 +1,5 @@
 export HARE_DEV=1
-for lib in default w0; do
+for lib in default ${LIBS:-w0}; do
   if [ $lib = default ]; then unset HARE_LIB; else export HARE_LIB=$PWD/hare_amd/libhare_hip_$lib.so; fi
   echo "=== $lib"
   timeout -k 10 120 python tools/c5_timeline.py 0 2>&1 | grep "==\|end p10"
