@@ -369,6 +369,7 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     std::lock_guard<std::mutex> lk(sl.mu);
     io.work = reinterpret_cast<unsigned int*>(static_cast<LaunchSlotMem*>(s.d_work) + idx);
     io.coop_tail = (coop_tail && s.opt.coop_tail) ? 1 : 0;
+    io.wide_drain = s.opt.wide_drain ? 1 : 0;
     io.oct_tail = nullptr;
     const bool with_k2t = octree_tail_levels > 0 && s.opt.coop_tail && s.module->octree_tail != nullptr;
     std::unique_lock<std::mutex> tail_lk(s.oct_tail_mu, std::defer_lock);
@@ -1698,6 +1699,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},
         {"batch_chunks", &SceneOptions::batch_chunks, 0, 3},
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},
+        {"wide_drain", &SceneOptions::wide_drain, 0, 1},
     };
     for (auto& t : table)
         if (strcmp(t.name, name) == 0) {

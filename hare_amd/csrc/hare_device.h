@@ -308,6 +308,7 @@ struct ShootIO {
     const double* tmax;        // nullable
     int32_t* occluded;         // nullable: n flags
     int32_t coop_tail;         // 1: a drained wave traces its last rays cooperatively (voxel_coop.hip); 0: as lanes of the pool to the end
+    int32_t wide_drain;        // 1: K1q spreads a ray's candidates / the voxels ahead of it over several lanes once the tickets are dry and few rays are left
     unsigned char* oct_tail;   // K2p / K2t: this launch's hand-over records (waves of the K2p grid x kOctTailMax), null = every lane finishes its own
     int32_t oct_tail_stride;   // bytes per record
     int32_t oct_tail_levels;   // frames per record (= the levels K2p keeps in LDS)

@@ -146,6 +146,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     // the cooperative tail (voxel_coop.hip); with origin write-back the ray record holds the MOVED origin, which coop_trace would move again
     const bool coop = io.coop_tail != 0 && !writeback;
     unsigned tail_rounds = 0;        // rounds since the tickets ran dry
+    const bool wide_on = io.wide_drain != 0;
 
     auto store_miss = [&](unsigned ray) {
         XEventRec ev;
@@ -306,7 +307,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         const bool tail = drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_TAIL;
         // ... and once the pool is down to a few rays, a ray's candidates are spread over several lanes (the wide cull below).  Both
         // conditions only ever go from false to true (no ray is set up after the tickets ran dry), which the wide cull relies on.
-        const bool wide = HARE_K1Q_WIDE_MAX > 0 && drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_WIDE_MAX;
+        const bool wide = HARE_K1Q_WIDE_MAX > 0 && wide_on && drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_WIDE_MAX;
         const int sel = (nE >= (unsigned)HARE_K1Q_EXACT_MIN || (big == 0 && nP == 0)) ? 0
                         : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
         HARE_K1Q_PHASE_FENCE();      // the set-up's scratch stores, before any phase reads them

@@ -172,6 +172,8 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "octree_kernel"   0: the library's rule, 1: hare_octree_persist (K2p), 2: hare_octree_pool (K2q)
  *   "ticket_rays", "k1p_static_rays", "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
+ *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per
+ *                     ray: its candidates four per lane, the occupied voxels ahead one per lane); 0: off.  Results never depend on it
  *   "dev"             1: developer flag bits of hare_shoot_* (timeline, phase profile, cull audit) pass
  * Single-caller like the build calls: not to be changed while shoots are in flight on the scene. */
 HARE_API int hare_scene_set_option(hare_scene *s, const char *name, int64_t value);

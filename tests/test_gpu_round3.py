@@ -356,6 +356,71 @@ def test_cooperative_tail_is_invisible_in_the_results(hall, kernel):
         assert ev.tobytes() == ref[:k].tobytes()
 
 
+@pytest.mark.parametrize("domain", [64, 128])
+def test_wide_drain_modes_are_invisible_in_the_results(hall, domain):
+    """K1q's drain (voxel_pool.hip): once the tickets are dry and at most 64 rays are left in a wave's pool, the pre-cull runs
+    WIDE (a ray's candidates four per lane over 1 - 16 lanes, first survivor in list order) and the walk looks several occupied
+    voxels ahead (one per lane, whole lists).  Results with the modes on, off and from the oracle must be the same bytes: on the
+    burst, on surface-skimming rays (long lists, a hundred occupied voxels), with both exclusions, with origins outside the grid
+    (moved origins: t_start), with origin write-back, on a coarse bitmap (D = 128) and in launches of every size from one ray to
+    a few per wave -- where a wave is in its drain from the first round."""
+    m, T, To = hall
+    rng = np.random.default_rng(41)
+    n = 150_000
+    L = np.asarray(m.size)
+    o = rng.uniform(0.02, 0.98, (n, 3)) * L
+    d = rng.normal(size=(n, 3))
+    axis = rng.integers(0, 3, n)
+    skim = rng.random(n) < 0.5
+    d[skim, axis[skim]] *= 2e-3
+    o[skim, axis[skim]] = np.where(rng.random(skim.sum()) < 0.5, 0.006, L[axis[skim]] - 0.006) + rng.normal(0, 2e-3, skim.sum())
+    o[::7] += rng.normal(0, 30.0, (len(o[::7]), 3))                 # origins far outside: AABB.Intersect moves them (or they miss)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+    e1 = rng.integers(-1, m.P, n).astype(np.int32)
+    e2 = rng.integers(-1, m.P, n).astype(np.int32)
+    og = po.VoxelGrid([To], domain=domain)
+    ref, rc = og.shoot(rays, excl1=e1, excl2=e2, nthreads=16)
+    g = H.Voxel_Grid([T], domain)
+    g.set_option("voxel_kernel", 2)
+    got = {}
+    for wide in (1, 0):
+        g.set_option("wide_drain", wide)
+        got[wide], c = g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)
+        assert_events_equal(got[wide], ref, what=f"D={domain}, wide_drain {wide}")
+        assert (c["rays"], c["hits"]) == (n, rc["hits"])
+    assert got[0].tobytes() == got[1].tobytes()
+    g.set_option("wide_drain", 1)
+    for k in (1, 2, 5, 33, 64, 65, 1000, 3072 * 3):                 # a wave holds a few rays from its first round on
+        ev, _ = g.Shoot_batch(rays[:k], poly_origin1=e1[:k], poly_origin2=e2[:k])
+        assert ev.tobytes() == ref[:k].tobytes(), k
+    # origin write-back: the moved origins come back in rays[], the events are the same (the cooperative tail is off then, the wide modes are not)
+    r1 = rays[:40_000].copy()
+    ev, _ = g.Shoot_batch(r1, poly_origin1=e1[:40_000], poly_origin2=e2[:40_000], writeback_origin=True)
+    refw, _, moved = og.shoot(rays[:40_000], excl1=e1[:40_000], excl2=e2[:40_000], mutate=True, nthreads=16)
+    assert_events_equal(ev, refw, what="write-back")
+    assert np.array_equal(r1, moved)
+
+
+def test_wide_drain_modes_with_quadrilaterals():
+    """The same on a soup with quadrilaterals (never culled: every quad survives the wide cull and goes to the exact phase)."""
+    from tests.helpers import soup, soup_rays
+    v, nv, size = soup(n_tri=3000, n_quad=800, seed=5)
+    rays = soup_rays(60_000, size, seed=12)
+    rng = np.random.default_rng(2)
+    e1 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+    ref, rc = po.VoxelGrid([po.Topology(v, nv)], domain=10).shoot(rays, excl1=e1, nthreads=16)
+    g = H.Voxel_Grid([H.Topology(v, nv)], 10)
+    g.set_option("voxel_kernel", 2)
+    out = {}
+    for wide in (1, 0):
+        g.set_option("wide_drain", wide)
+        out[wide], c = g.Shoot_batch(rays, poly_origin1=e1)
+        assert_events_equal(out[wide], ref, what=f"quads, wide_drain {wide}")
+        assert c["hits"] == rc["hits"]
+    assert out[0].tobytes() == out[1].tobytes()
+
+
 def test_octree_tail_kernel_is_invisible_in_the_results(hall):
     """K2p hands the last, long-lived rays of a launch to K2t (octree_coop.hip: a wave per ray; the children of a frame on eight
     lanes, a leaf's list replayed from per-lane results with the reference's strict-< scan and its early return).  With the hand-over
