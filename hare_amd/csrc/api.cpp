@@ -538,12 +538,12 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
         const bool pool_fits = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= kLdsMax && s.vox.ct <= 512 && !(flags & 0x4000u);
         const int64_t fill = (int64_t)cus * kPoolWaves * kPoolSlots;          // rays in flight when every pool of the chip is full
-        // (round 3, with the cooperative tails: the resident scene's crossover came down from three fills to two on a grid with one
-        //  bit per voxel -- hall D = 64: 786k rays -8 %, 1M -1.4 %, 1.18M -6 %, 2M -17 %; 524k +9 % -- and stayed at three on a coarse
-        //  bitmap -- hall D = 128: 1M +4.6 %; profiles/r03_experiments/k1p_k1q_crossover_with_coop_tail.log)
-        const int64_t resident_from = (coarse ? 3 : 2) * fill;
-        const bool pool_wanted = s.opt.voxel_kernel == 2 || (s.opt.voxel_kernel == 0 &&
-                                 n >= (voxel_scene_bytes(s, top) > (96ull << 20) ? fill : resident_from));
+        // K1q from ONE pool fill of the chip, whatever the scene (393 216 rays on 256 CUs).  Round 2 needed three fills on a resident
+        // scene, the cooperative tails brought that to two, the wide drain modes (voxel_pool.hip) to one: hall D = 64 K1p / K1q
+        // 262k 0.226 / 0.250 ms, 393k 0.278 / 0.264, 524k 0.326 / 0.285, 786k 0.394 / 0.339, 1M 0.483 / 0.452; hall D = 128 (coarse
+        // bitmap) 262k 0.305 / 0.297, 393k 0.396 / 0.322, 524k 0.457 / 0.348, 1M 0.564 / 0.567; cathedral 262k 0.353 / 0.404, 393k
+        // 0.498 / 0.397, 524k 0.609 / 0.439 (profiles/r03_experiments/k1p_k1q_crossover_with_wide_drain.log)
+        const bool pool_wanted = s.opt.voxel_kernel == 2 || (s.opt.voxel_kernel == 0 && n >= fill);
         hipFunction_t DeviceModule::*pf = !coarse ? (quads ? &DeviceModule::voxel_pool_quad : &DeviceModule::voxel_pool_tri)
                                                    : (quads ? &DeviceModule::voxel_pool_quad_g : &DeviceModule::voxel_pool_tri_g);
         if (pool_wanted && pool_fits && have(pf)) {

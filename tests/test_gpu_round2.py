@@ -442,15 +442,16 @@ def test_concurrent_batch_callers_on_one_scene(hall, what):
 
 
 def test_the_picker_follows_its_rule(hall):
-    """api.cpp choose_kernel: a cache-resident scene takes K1p below two pool fills of the chip (786 432 rays) and K1q from there
-    (three fills on a coarse bitmap); the per-scene option is for A/B runs (the tests above use it)."""
+    """api.cpp choose_kernel: K1p below one pool fill of the chip (393 216 rays on 256 CUs), K1q from there, whatever the scene or
+    the bitmap (round 3: the wide drain modes shortened K1q's end of launch); the per-scene option is for A/B runs."""
     _, T, _ = hall
     g = H.Voxel_Grid([T], 64)
-    want = {64: "persist", 65536: "persist", 393216: "persist", 786431: "persist", 786432: "pool", 1 << 20: "pool", 1 << 24: "pool"}
-    for n, k in want.items():      # 256 CUs x 12 waves x 128 rays = 393 216 rays fill every pool of the chip once; two fills = 786 432
+    fill = H.device_cu_count() * 12 * 128 if hasattr(H, "device_cu_count") else 393216
+    want = {64: "persist", 65536: "persist", fill - 1: "persist", fill: "pool", 786432: "pool", 1 << 20: "pool", 1 << 24: "pool"}
+    for n, k in want.items():      # 256 CUs x 12 waves x 128 rays = 393 216 rays fill every pool of the chip once
         assert g.kernel_name(n) == f"hare_voxel_{k}_tri", (n, g.kernel_name(n))
-    g128 = H.Voxel_Grid([T], 128)                        # a coarse occupancy bitmap (one bit per 2^3 voxels): three fills
-    assert g128.kernel_name(1 << 20) == "hare_voxel_persist_tri_g" and g128.kernel_name(1179648) == "hare_voxel_pool_tri_g"
+    g128 = H.Voxel_Grid([T], 128)                        # a coarse occupancy bitmap (one bit per 2^3 voxels): the same rule
+    assert g128.kernel_name(fill - 1) == "hare_voxel_persist_tri_g" and g128.kernel_name(fill) == "hare_voxel_pool_tri_g"
     g.set_option("voxel_kernel", 2)                      # the per-scene switch the A/B tests and tools use
     assert g.kernel_name(64) == "hare_voxel_pool_tri"
     g.set_option("voxel_kernel", 1)
