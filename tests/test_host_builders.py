@@ -101,6 +101,20 @@ def test_public_members_of_voxel_grid():
     assert g.VoxelCode(1, 2, 3) == 64 * 3 + 8 * 1 + 2      # XYTot*Z + VoxelCtY*X + Y (Voxel_Grid.cs:264-267)
 
 
+def test_scene_options_are_range_checked_without_a_gpu():
+    """hare_scene_set_option (include/hare_hip.h): the A/B switches the GPU tests and tools use exist on a scene built on the host,
+    refuse values outside their range and refuse unknown names -- nothing here launches a kernel."""
+    m = H.scenes.shoebox()
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    for name, good, bad in (("voxel_kernel", 2, 3), ("octree_kernel", 1, 3), ("coop_tail", 0, 2), ("wide_drain", 0, 2), ("ticket_rays", 64, 1 << 20)):
+        g.set_option(name, good)
+        with pytest.raises(H.HareError):
+            g.set_option(name, bad)
+        g.set_option(name, 1 if name in ("coop_tail", "wide_drain") else 0)
+    with pytest.raises(H.HareError):
+        g.set_option("no_such_option", 1)
+
+
 def test_octree_child_boxes_follow_from_the_parent_box():
     """The persistent octree kernel does not load child boxes: it derives the children's planes from the
     parent's stored box with BuildOctree's expressions ("Octree - alt.cs":96-111).  Check on the built tree

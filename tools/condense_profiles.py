@@ -43,6 +43,11 @@ def issue_side(cs, key):
 
 def main(src):
     out = os.path.join(ROOT, "profiles")
+    # gpurun MERGES a run's output into the local directory: files of an earlier run (other process ids in their names) would be
+    # averaged in with this one's.  Refuse a directory that holds more than one generation.
+    times = [os.path.getmtime(f) for f in glob.glob(os.path.join(src, "**", "*.csv"), recursive=True)]
+    if times and max(times) - min(times) > 3600:
+        sys.exit("condense_profiles: %s holds csv files more than an hour apart -- remove the older run's files first" % src)
     rows = [("config", "kernel", "counter", "mean_per_dispatch", "dispatches")]
     traffic = {}
     for tag, key in KEYS.items():
