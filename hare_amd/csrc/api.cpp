@@ -538,12 +538,16 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
         const bool pool_fits = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= kLdsMax && s.vox.ct <= 512 && !(flags & 0x4000u);
         const int64_t fill = (int64_t)cus * kPoolWaves * kPoolSlots;          // rays in flight when every pool of the chip is full
-        // K1q from ONE pool fill of the chip, whatever the scene (393 216 rays on 256 CUs).  Round 2 needed three fills on a resident
-        // scene, the cooperative tails brought that to two, the wide drain modes (voxel_pool.hip) to one: hall D = 64 K1p / K1q
-        // 262k 0.226 / 0.250 ms, 393k 0.278 / 0.264, 524k 0.326 / 0.285, 786k 0.394 / 0.339, 1M 0.483 / 0.452; hall D = 128 (coarse
-        // bitmap) 262k 0.305 / 0.297, 393k 0.396 / 0.322, 524k 0.457 / 0.348, 1M 0.564 / 0.567; cathedral 262k 0.353 / 0.404, 393k
-        // 0.498 / 0.397, 524k 0.609 / 0.439 (profiles/r03_experiments/k1p_k1q_crossover_with_wide_drain.log)
-        const bool pool_wanted = s.opt.voxel_kernel == 2 || (s.opt.voxel_kernel == 0 && n >= fill);
+        // K1q for every batch size.  Round 2 needed three pool fills of the chip on a resident scene before K1q won, the cooperative
+        // tails brought that to two, the wide drain modes (voxel_pool.hip) to one -- and a batch BELOW one fill is spread over all waves
+        // of the chip (ShootIO::static_rays), whose few rays each get several lanes from their second round on: K1p / K1q, ms, hall
+        // D = 64: 1k 0.135 / 0.101, 16k 0.153 / 0.121, 65k 0.187 / 0.135, 131k 0.203 / 0.154, 262k 0.224 / 0.209, 393k 0.278 / 0.264,
+        // 524k 0.326 / 0.285, 1M 0.483 / 0.452; cathedral D = 128: 1k 0.231 / 0.170, 16k 0.251 / 0.196, 65k 0.293 / 0.245, 131k
+        // 0.302 / 0.322, 262k 0.354 / 0.337, 524k 0.609 / 0.439 (profiles/r03_experiments/k1p_k1q_small_batches.log,
+        // k1p_k1q_crossover_with_wide_drain.log).  K1p serves what the pool kernel cannot: grids beyond 512 voxels a side or a bitmap
+        // that leaves no room for the pools, and the developer builds.
+        (void)fill;
+        const bool pool_wanted = s.opt.voxel_kernel == 2 || s.opt.voxel_kernel == 0;
         hipFunction_t DeviceModule::*pf = !coarse ? (quads ? &DeviceModule::voxel_pool_quad : &DeviceModule::voxel_pool_tri)
                                                    : (quads ? &DeviceModule::voxel_pool_quad_g : &DeviceModule::voxel_pool_tri_g);
         if (pool_wanted && pool_fits && have(pf)) {
@@ -730,8 +734,12 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         if (kc.k == Kern::VoxelPool) {
             // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
             const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
-            unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + 64 * kPoolWaves - 1) / (64 * kPoolWaves)));
+            // a workgroup per CU whenever the batch has a ray for every wave; the static first chunk is what the batch has for each wave,
+            // in steps of 8, at most 128 (a small batch: few rays per wave, each with several lanes from its second round on)
+            unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + kPoolWaves - 1) / kPoolWaves));
             if (pgrid == 0) pgrid = 1;
+            const int64_t per_wave = (n + (int64_t)pgrid * kPoolWaves - 1) / ((int64_t)pgrid * kPoolWaves);
+            io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(128, (per_wave + 7) / 8 * 8));
             io.ticket_rays = ticket_rays_for(s, n, true);
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }

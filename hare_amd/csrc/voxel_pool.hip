@@ -133,7 +133,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #ifndef HARE_K1Q_STATIC
 #define HARE_K1Q_STATIC 128
 #endif
-    const unsigned RAY_CHUNK = HARE_K1Q_STATIC;
+    // the host shrinks the static first chunk for batches too small to give every wave of the grid 128 rays (ShootIO::static_rays): a
+    // small batch is spread over ALL waves of the chip, which are then in their drain -- the wide modes -- from the second round on
+    const unsigned RAY_CHUNK = io.static_rays > 0 ? (unsigned)io.static_rays : (unsigned)HARE_K1Q_STATIC;
     const unsigned n_static = gridDim.x * (unsigned)kPoolWaves * RAY_CHUNK;
     unsigned chunk_id = blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave;
     if ((gridDim.x & 7u) == 0) chunk_id = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * (unsigned)kPoolWaves + (unsigned)wave;

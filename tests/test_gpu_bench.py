@@ -41,7 +41,7 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert j["x_event_parity_vs_oracle"] is True                # rank 0's shard, bit for bit
     assert j["ms_per_step_per_rank"]["max"] >= j["ms_per_step_per_rank"]["min"] > 0
     assert j["cpu_baseline"] is None                            # reported at N = 1 only
-    assert j["roofline"]["kernel"] == "hare_voxel_persist_tri" and j["roofline"]["frac"] > 0
+    assert j["roofline"]["kernel"] == "hare_voxel_pool_tri" and j["roofline"]["frac"] > 0
 
 
 def test_bench_rccl_branch_on_one_gpu_with_a_process_group_of_one():
@@ -63,7 +63,7 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
     small sizes): each carries value, roofline, cpu_baseline and the parity flag."""
     j = _bench("--rays", "32768", "--steps", "2", "--warmup", "1", "--extra-configs", "--extra-rays", "32768")
     assert set(j["configs"]) == {"c3", "c4_shard", "c5"}
-    want = {"c3": "hare_octree_persist", "c4_shard": "hare_voxel_persist_tri_g", "c5": "hare_voxel_persist_tri_g"}
+    want = {"c3": "hare_octree_persist", "c4_shard": "hare_voxel_pool_tri_g", "c5": "hare_voxel_pool_tri_g"}
     for name, sub in j["configs"].items():
         assert sub["x_event_parity_vs_oracle"] is True, name
         assert sub["value"] > 0 and sub["roofline"]["frac"] > 0 and sub["roofline"]["kernel"] == want[name]
@@ -73,10 +73,10 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
 
 
 @pytest.mark.parametrize("extra,kernel", [
-    ((), "hare_voxel_persist_tri"),
+    ((), "hare_voxel_pool_tri"),                          # the pool kernel serves every batch size (api.cpp: choose_kernel)
     (("--kind", "octree"), "hare_octree_persist"),
-    (("--bounces", "3"), "hare_voxel_persist_tri"),
-    (("--rays", "1048576"), "hare_voxel_pool_tri"),       # a launch long enough for the pool kernel (api.cpp: choose_kernel)
+    (("--bounces", "3"), "hare_voxel_pool_tri"),
+    (("--rays", "1048576"), "hare_voxel_pool_tri"),
 ])
 def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     j = _bench(*(("--rays", "32768") if "--rays" not in extra else ()), "--steps", "2", "--warmup", "1", *extra)

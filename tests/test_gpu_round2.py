@@ -442,16 +442,15 @@ def test_concurrent_batch_callers_on_one_scene(hall, what):
 
 
 def test_the_picker_follows_its_rule(hall):
-    """api.cpp choose_kernel: K1p below one pool fill of the chip (393 216 rays on 256 CUs), K1q from there, whatever the scene or
-    the bitmap (round 3: the wide drain modes shortened K1q's end of launch); the per-scene option is for A/B runs."""
+    """api.cpp choose_kernel: K1q for every batch size since round 3 (a batch below one pool fill of the chip is spread over all
+    waves, which the wide drain modes then serve with several lanes per ray); K1p for grids the pool kernel cannot take (more than
+    512 voxels a side); the per-scene option is for A/B runs."""
     _, T, _ = hall
     g = H.Voxel_Grid([T], 64)
-    fill = H.device_cu_count() * 12 * 128 if hasattr(H, "device_cu_count") else 393216
-    want = {64: "persist", 65536: "persist", fill - 1: "persist", fill: "pool", 786432: "pool", 1 << 20: "pool", 1 << 24: "pool"}
-    for n, k in want.items():      # 256 CUs x 12 waves x 128 rays = 393 216 rays fill every pool of the chip once
-        assert g.kernel_name(n) == f"hare_voxel_{k}_tri", (n, g.kernel_name(n))
+    for n in (1, 64, 65536, 393215, 393216, 1 << 20, 1 << 24):
+        assert g.kernel_name(n) == "hare_voxel_pool_tri", (n, g.kernel_name(n))
     g128 = H.Voxel_Grid([T], 128)                        # a coarse occupancy bitmap (one bit per 2^3 voxels): the same rule
-    assert g128.kernel_name(fill - 1) == "hare_voxel_persist_tri_g" and g128.kernel_name(fill) == "hare_voxel_pool_tri_g"
+    assert g128.kernel_name(1000) == "hare_voxel_pool_tri_g" and g128.kernel_name(1 << 20) == "hare_voxel_pool_tri_g"
     g.set_option("voxel_kernel", 2)                      # the per-scene switch the A/B tests and tools use
     assert g.kernel_name(64) == "hare_voxel_pool_tri"
     g.set_option("voxel_kernel", 1)

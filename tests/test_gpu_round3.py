@@ -83,15 +83,15 @@ def test_environment_overrides_need_the_opt_in(hall, monkeypatch):
     variable in a production environment changes nothing."""
     m, T, _ = hall
     monkeypatch.delenv("HARE_DEV", raising=False)
-    monkeypatch.setenv("HARE_VOXEL_KERNEL", "pool")
-    g = H.Voxel_Grid([T], 64)
-    assert g.kernel_name(1000) == "hare_voxel_persist_tri"
-    monkeypatch.setenv("HARE_DEV", "1")
-    assert g.kernel_name(1000) == "hare_voxel_persist_tri"           # not re-read by an existing scene
-    g2 = H.Voxel_Grid([T], 64)
-    assert g2.kernel_name(1000) == "hare_voxel_pool_tri"
     monkeypatch.setenv("HARE_VOXEL_KERNEL", "persist")
-    assert g2.kernel_name(1000) == "hare_voxel_pool_tri"
+    g = H.Voxel_Grid([T], 64)
+    assert g.kernel_name(1000) == "hare_voxel_pool_tri"               # the library's rule (K1q), not the stray variable
+    monkeypatch.setenv("HARE_DEV", "1")
+    assert g.kernel_name(1000) == "hare_voxel_pool_tri"               # not re-read by an existing scene
+    g2 = H.Voxel_Grid([T], 64)
+    assert g2.kernel_name(1000) == "hare_voxel_persist_tri"
+    monkeypatch.setenv("HARE_VOXEL_KERNEL", "pool")
+    assert g2.kernel_name(1000) == "hare_voxel_persist_tri"
 
 
 # ---------------------------------------------------------------------------------------------------------------
