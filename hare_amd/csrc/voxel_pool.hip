@@ -37,6 +37,9 @@
 #ifndef HARE_K1Q_CULL_PAIRS
 #define HARE_K1Q_CULL_PAIRS 4     // pairs of candidates per cull task (swept 1..8: DESIGN.md section 9)
 #endif
+#ifndef HARE_K1Q_CULL_AHEAD
+#define HARE_K1Q_CULL_AHEAD 1     // a cull task requests all its list entries, then all its records, then scans (0: pair by pair, each pair's entries from the previous pair's loads)
+#endif
 #ifndef HARE_K1Q_EXACT_MIN
 #define HARE_K1Q_EXACT_MIN 24     // run the exact phase when this many rays wait for it (or nothing else can run); swept 8..56
 #endif
@@ -595,6 +598,71 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const CullRay cray = cull_ray(g, ox, oy, oz, r.dx, r.dy, r.dz);
                 bool culling = true, parked = false;
                 share_idx = idx;
+#if HARE_K1Q_CULL_AHEAD
+                // All of the task's list entries FIRST (idx, nexti are here; the eight after them in four 8-byte gathers, their window
+                // sliding back at the end of the list so that it stays inside it), then all eight pre-cull records, then the
+                // sequential scan on the eight results: three rounds of dependent loads per task (slot state -> ray record + entries ->
+                // records) where the pair-by-pair form below had six.  The same gathers as before -- the straight-line pairs
+                // requested theirs whether or not the scan had ended -- and the same candidates, in the same order, kept or dropped by
+                // the same rules.
+                constexpr int NC = 2 * HARE_K1Q_CULL_PAIRS;
+                int E[NC + 2];
+                E[0] = idx;
+                E[1] = (q + 1u < qe && nexti >= 0) ? nexti : idx;
+                {
+                    const unsigned left = qe - q;                                // >= 1
+#pragma unroll
+                    for (int m = 0; m < NC / 2; ++m) {
+                        const unsigned k0 = 2u + 2u * (unsigned)m;              // entries k0, k0 + 1 of the task
+                        if (left >= 2u) {
+                            const unsigned a = q + k0 + 1u < qe ? q + k0 : qe - 2u;     // the pair's window, inside [q, qe)
+                            const int2 w = *reinterpret_cast<const int2*>(g.items + a);
+                            E[k0] = (q + k0 + 1u == qe) ? w.y : w.x;            // window slid back by one: the entry wanted is its second
+                            E[k0 + 1] = w.y;
+                        } else {
+                            E[k0] = idx; E[k0 + 1] = idx;
+                        }
+                    }
+                }
+                bool T[NC];
+#ifndef HARE_K1Q_CULL_BATCH
+#define HARE_K1Q_CULL_BATCH (NC % 4 == 0 ? 4 : 2)    // records requested together (8 VGPRs each): 4 measured better than 8 (registers) and 2
+#endif
+                constexpr int NB = HARE_K1Q_CULL_BATCH;
+#pragma unroll
+                for (int b0 = 0; b0 < NC; b0 += NB) {
+                    CullRaw R[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) R[k] = cull_load(g, E[b0 + k]);
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) T[b0 + k] = cull_test(g, cray, R[k]);
+                    if (NB < NC) __builtin_amdgcn_sched_barrier(0);          // keep the next batch's requests behind this batch's tests (registers)
+                }
+                unsigned consumed = 0;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {
+                    const bool valid = q + (unsigned)k < qe;
+                    const int c = E[k];
+                    const bool sk = c == e1 || c == e2 || (HARE_K1Q_MAILBOX && c == done1);   // Voxel_Grid.cs:477 + the mailbox (see below)
+                    const bool keep = culling && valid && !sk && !T[k];         // survives: it goes to the exact phase
+                    const bool step = culling && valid && !keep;                // consumed
+                    done1 = (step && !sk) ? c : done1;                          // a certain miss counts as tested
+                    consumed += step ? 1u : 0u;
+                    parked = parked || keep;
+                    culling = culling && valid && !keep;
+                }
+                q += consumed;
+                culling = culling && q < qe;
+                {
+                    int ni = E[0], nn = E[1];
+#pragma unroll
+                    for (int k = 1; k <= NC; ++k) {
+                        ni = consumed == (unsigned)k ? E[k] : ni;
+                        nn = consumed == (unsigned)k ? E[k + 1] : nn;
+                    }
+                    idx = ni; nexti = nn;
+                }
+#else
 #pragma unroll
                 for (int kp = 0; kp < HARE_K1Q_CULL_PAIRS; ++kp) {
                     // candidates idx (at q) and nexti (at q + 1): both records and the two list entries after them are
@@ -633,6 +701,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     parked = parked || keep0 || keep1;
                     culling = culling && !keep0 && !keep1 && q < qe;
                 }
+#endif
                 L_q[slot] = q; L_idx[slot] = idx; L_nexti[slot] = nexti; L_d1[slot] = done1;
                 to_exact = parked;
                 to_cull = culling;                                          // quota used up, list not exhausted
