@@ -1359,7 +1359,7 @@ int hare_shoot_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
     GUARD_END
 }
 
-// hare_shoot_batch and hare_occluded_batch: host buffers in, host buffers out, pipelined over up to three chunks.
+// hare_shoot_batch and hare_occluded_batch: host buffers in, host buffers out, pipelined over up to eight chunks.
 //   out != null, occluded == null   closest-hit events (hare_shoot_batch)
 //   out != null, occluded != null   events and the occlusion flags derived from them
 //   out == null, occluded != null   flags only: the t_max-bounded kernels; 4 bytes per ray come back instead of 56
@@ -1393,7 +1393,7 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
         hare_scene* s; Scene::BatchCtx* c;
         ~Release() { { std::lock_guard<std::mutex> lk(s->mu); c->busy = false; } s->cv.notify_one(); }
     } release{s, c};
-    constexpr int kMaxChunks = 3;
+    constexpr int kMaxChunks = 16;
     if (n > c->cap) {
         for (void** p : {&c->d_rays, &c->d_e1, &c->d_e2, &c->d_out, &c->d_tmax, &c->d_occ, &c->d_slim}) dev_free(H, *p);
         c->cap = 0;
@@ -1422,16 +1422,19 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
         c->occ_cap = n;
     }
     if (!c->d_ctr) HIP_TRY(H->Malloc(&c->d_ctr, kMaxChunks * sizeof(hare_counters)));
-    // A large batch is pipelined as up to three chunks, each on its own stream and driven by its own host thread:
-    // upload, kernel and download of different chunks overlap (both PCIe directions busy), which measured +24 % on
-    // pageable host buffers (402 -> 499 Mrays/s for 1M rays, 426 -> 537 for 4M).  More chunks lose again: small launches are inefficient.
-    int K = n >= 196608 ? kMaxChunks : 1;
+    // A large batch is pipelined as chunks, each on its own stream and driven by its own host thread: upload, kernel and download of
+    // different chunks overlap (both directions of the host link busy).  Round 2 measured three chunks as the best (402 -> 499 Mrays/s
+    // for 1M rays) because small launches were inefficient; since the pool kernel serves small launches well (round 3) five chunks are
+    // (1M rays: full records 525 -> 572 Mrays/s, 4M: 541 -> 596), and eight for the longest batches with 16-byte slim records (4M:
+    // 870 -> 985); more lose again to thread and launch overheads (profiles/r03_experiments/host_batch_chunks.log).
+    int K = n < 196608 ? 1 : (n < 393216 ? 3 : (n < 2097152 ? 5 : 8));
     if (s->opt.batch_chunks > 0) K = std::max(1, std::min(kMaxChunks, s->opt.batch_chunks));     // developer sweeps
     for (int k = 0; k < K; ++k)
         if (!c->st[k]) HIP_TRY(H->StreamCreate(&c->st[k]));
     hare_counters parts[kMaxChunks];
     memset(parts, 0, sizeof parts);
-    int rcs[kMaxChunks] = {HARE_OK, HARE_OK, HARE_OK};
+    int rcs[kMaxChunks];
+    for (int& r : rcs) r = HARE_OK;
     std::string errs[kMaxChunks];
     auto chunk_body = [&](int k, hipStream_t st) -> int {
         const int64_t lo = (int64_t)((__int128)n * k / K), m = (int64_t)((__int128)n * (k + 1) / K) - lo;
@@ -1705,7 +1708,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"ticket_rays", &SceneOptions::ticket_rays, 0, 4096},
         {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 256},
         {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},
-        {"batch_chunks", &SceneOptions::batch_chunks, 0, 3},
+        {"batch_chunks", &SceneOptions::batch_chunks, 0, 16},
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},
         {"wide_drain", &SceneOptions::wide_drain, 0, 1},
     };

@@ -191,7 +191,7 @@ struct Scene {
     };
     struct BatchCtx {
         BounceBuf bounce;
-        hipStream_t st[3] = {nullptr, nullptr, nullptr};
+        hipStream_t st[16] = {};
         void* d_rays = nullptr;
         void* d_e1 = nullptr;
         void* d_e2 = nullptr;
