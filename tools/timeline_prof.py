@@ -37,6 +37,7 @@ for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET v
               "of the latest 5 %% of waves: tail duration mean %.1f us, rays %.2f"
               % (*np.percentile(coop0[m], [10, 50, 90]), coop0[m].max(), helped[m].mean(), ct[m].mean(), np.percentile(ct[m], 90), ct[m].max(),
                  ct[m & (end > np.percentile(end[m], 95))].mean(), helped[m & (end > np.percentile(end[m], 95))].mean()))
+        print("  wave starts p10/50/90/max %.1f/%.1f/%.1f/%.1f us after the first" % (*np.percentile(start[m], [10, 50, 90]), start[m].max()))
         print("  tickets dry p10/50/90 %.0f/%.0f/%.0f  end p10/50/90/max %.0f/%.0f/%.0f/%.0f  tail(end-dry) mean %.0f  rounds/wave mean %.0f"
               % (*np.percentile(dry[m], [10, 50, 90]), *np.percentile(end[m], [10, 50, 90]), end[m].max(), (end[m] - dry[m]).mean(), tl[m, 3].mean()))
         e = np.sort(end[live]); tot = e.max()
