@@ -467,7 +467,11 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
     if (s.opt.ticket_rays > 0) return std::max(8, std::min(4096, s.opt.ticket_rays));            // developer sweeps
     // measured optimum on MI355X (tools/sweep_ticket.py): 32 rays up to ~1.5M rays, where the end of the batch dominates,
     // growing to 128 where the ~11 ns/ticket same-address atomic rate would start to bind
-    if (pool) return n < 1572864 ? 32 : (n < 6291456 ? 64 : 128);
+    // K1q: 64 rays -- one full round of set-ups -- at every size (re-swept on the final round-3 kernel, hall and cathedral, 524k ... 8M
+    // rays: 1M rays 32 / 48 / 64 / 96 / 128 rays per ticket 0.4425 / 0.4086 / 0.4018 / 0.4297 / 0.4177 ms; the kernel had become fast
+    // enough for 32-ray tickets to run into the same-address atomic rate, ~11 ns per draw; sizes that are not a multiple of 64 leave
+    // part of a set-up round empty; profiles/r03_experiments/k1q_ticket_resweep.log)
+    if (pool) return n < 12582912 ? 64 : 128;
     return n < 1572864 ? 32 : (n < 6291456 ? 64 : (n < 12582912 ? 96 : 128));
 }
 
