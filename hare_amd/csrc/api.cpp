@@ -744,6 +744,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (pgrid == 0) pgrid = 1;
             const int64_t per_wave = (n + (int64_t)pgrid * kPoolWaves - 1) / ((int64_t)pgrid * kPoolWaves);
             io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(128, (per_wave + 7) / 8 * 8));
+            if (s.opt.k1p_static_rays > 0) io.static_rays = std::max(8, std::min(1024, s.opt.k1p_static_rays / 8 * 8));   // developer sweeps (tools/k1q_ticket_sweep.py)
             io.ticket_rays = ticket_rays_for(s, n, true);
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }
@@ -1710,7 +1711,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
         {"octree_kernel", &SceneOptions::octree_kernel, 0, 2},
         {"ticket_rays", &SceneOptions::ticket_rays, 0, 4096},
-        {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 256},
+        {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 1024},
         {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},
         {"batch_chunks", &SceneOptions::batch_chunks, 0, 16},
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},

@@ -170,7 +170,7 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
  *   "octree_kernel"   0: the library's rule, 1: hare_octree_persist (K2p), 2: hare_octree_pool (K2q)
- *   "ticket_rays", "k1p_static_rays", "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
+ *   "ticket_rays", "k1p_static_rays" (both voxel kernels), "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
  *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per
  *                     ray: its candidates four per lane, the occupied voxels ahead one per lane); 0: off.  Results never depend on it

@@ -10,6 +10,7 @@ for N in [int(x) for x in os.environ.get('RAYS', '1048576,4194304').split(',')]:
     dr = torch.from_numpy(rays).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
     for t in [int(x) for x in os.environ.get('TICKETS', '0,16,24,32,48,64,96,128').split(',')]:
         g.set_option("ticket_rays", t)
+        g.set_option("k1p_static_rays", int(os.environ.get("STATIC", 0)))
         best = 1e9
         for rep in range(3):
             for _ in range(3): g.shoot_device(N, dr.data_ptr(), out.data_ptr(), stream=st)
