@@ -11,10 +11,15 @@ collective); the only exchange is the RCCL all-reduce of the hit counter after e
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Other configs: --kind octree (config 3), --scene cathedral --domain 128 --rays 2097152 (config 4 shard),
---scene cathedral --domain 128 --bounces 8 (config 5: device-resident specular bounce loop, value = casts/s).
-The default N = 1 run (the driver's command) measures the headline workload first and then, in the same process, configs
-3, 4 (one GPU's 2M-ray shard) and 5 (one GPU's 1M rays x 8 bounces) at fewer steps; they are attached to the ONE JSON line
-as "configs": {"c3": ..., "c4_shard": ..., "c5": ...}, each with its own value, roofline, cpu_baseline and parity flag
+--scene cathedral --domain 128 --bounces 8 (config 5: device-resident specular bounce loop, value = casts/s),
+--kind kdtree --scene shoebox (KDTree.Shoot, a brute-force query in the reference: one measured line, profiles/).
+The default run (the driver's command, at ANY N) measures the headline workload first and then, in the same process(es), the rest
+of BASELINE's table at fewer steps, attached to the ONE JSON line as "configs": {...}, each entry with its own value, roofline,
+parity flag and (N = 1) cpu_baseline:
+    c4, c5                   configs 4 and 5 as stated: ONE 16 777 216-ray burst / ONE 8 388 608-ray burst x 8 specular bounces into
+                             the 1M-triangle cathedral, contiguous shards over the N ranks ("scaling": "strong"), hit counters
+                             all-reduced (RCCL), max-over-ranks timing, every rank's X_Events checked against the oracle
+    c3, c4_shard, c5_shard   N = 1 only: config 3, and one GPU's share of configs 4 / 5 at N = 8 (2M rays; 1M rays x 8)
 (--no-extra-configs skips them).  --force-dist runs the torch.distributed code path (init, per-step async all-reduce of
 the counters, all-gather of the timings) even at N = 1, so that the RCCL branch can be exercised on a one-GPU box.
 
@@ -241,11 +246,17 @@ def measure(w, env):
     mesh, _ = env.mesh(H, scene)
     part, kdesc, build_s = env.partition(H, scene, kind, domain)
 
-    n = w["rays"]
     B = w["bounces"]
+    strong = bool(w.get("rays_total"))
+    if strong:        # BASELINE configs 4 / 5: ONE batch of rays_total rays, cut into contiguous shards (strong scaling)
+        n_total = int(w["rays_total"])
+        lo, hi = shard_range(n_total, rank, world)
+        n = hi - lo
+    else:             # the headline: every GPU casts its own n rays of an N*n-ray burst (weak scaling)
+        n = w["rays"]
+        n_total = n * world
+        lo, hi = shard_range(n_total, rank, world)
     kernel_name = part.kernel_name(n)
-    n_total = n * world
-    lo, hi = shard_range(n_total, rank, world)
     rays_h = H.scenes.burst_rays(n_total, mesh.size, start=lo, count=hi - lo)
     d_rays = torch.from_numpy(rays_h).cuda()
     d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
@@ -264,6 +275,9 @@ def measure(w, env):
     # the per-batch hit-count reduce runs on RCCL's stream, overlapped with the NEXT batch's kernel:
     # two counter blocks alternate, a block is reused only after its all-reduce has been waited for
     ctrs = [torch.zeros(8, dtype=torch.int64, device="cuda"), torch.zeros(8, dtype=torch.int64, device="cuda")]
+    # a block starts every step as {0, ..., 0, 1}: the kernels accumulate rays / hits into words 0 / 1 and never touch word 7
+    # (hare_counters.reserved[2]), so after the reduce word 7 is the number of ranks whose block really was summed
+    ctr_init = torch.tensor([0, 0, 0, 0, 0, 0, 0, 1], dtype=torch.int64, device="cuda")
     pending = [None, None]
     reduced = [None, None]
     state = {"k": 0, "set": 0}
@@ -297,7 +311,7 @@ def measure(w, env):
         if pending[k & 1] is not None:
             pending[k & 1].wait()
             pending[k & 1] = None
-        c.zero_()
+        c.copy_(ctr_init)
         cast_pass(c.data_ptr())
         if dist is not None:
             if backend == "nccl":
@@ -351,6 +365,7 @@ def measure(w, env):
     last = reduced[(state["k"] - 1) & 1]
     hits_total = int(last[1])
     rays_total = int(last[0])
+    ranks_seen = int(last[7])
 
     # shoot-kernel duration: HIP events around each shoot launch on the launch stream (the stream the kernel runs on)
     nrep = max(1, min(steps, 30))
@@ -433,16 +448,18 @@ def measure(w, env):
             bounce_batch = {"mcasts_s": round(bb_ctr["rays"] / best / 1e6, 1), "ms": round(best * 1e3, 3), "casts": bb_ctr["rays"],
                             "events": bb_ev}
 
-    if rank != 0:
-        return None
-
-    # ---- rank 0: oracle pass over THIS rank's rays = exact C/L/T for the roofline, the CPU baseline, a parity check
+    # ---- the checker (oracle/), after the timed region.  Rank 0 passes its WHOLE shard through the oracle: exact C/L/T for the
+    # roofline, the reference result for the parity check and (N = 1) the CPU baseline.  Every other rank checks a stated sample
+    # of ITS shard the same way, so that an N-GPU line says that every device returned the reference's X_Events.
     roofline = None
     cpu = None
     parity = None
+    parity_ranks = None
+    fields = ("hit", "poly_id", "t", "x", "y", "z", "u", "v")
     if w["cpu_baseline"]:
         from oracle import pyoracle as po
-        cores = int(os.environ.get("HARE_CPU_THREADS", "0")) or min(len(os.sched_getaffinity(0)), 32)
+        affinity = len(os.sched_getaffinity(0))
+        cores = int(os.environ.get("HARE_CPU_THREADS", "0")) or min(affinity, 256)    # the oracle takes up to 256 threads
         ot, og, ref_name = env.oracle(H, scene, kind, domain)
 
         def oracle_pass(rays, nthreads):
@@ -472,6 +489,19 @@ def measure(w, env):
                     links += int((ev["hit"] != 0).sum())
             return ev, tot, links
 
+        def device_events(m):
+            """The first m X_Events of the bench buffers themselves (B > 1: of the last cast)."""
+            if events_dev is not None:
+                return np.frombuffer(events_dev, dtype=H.capi.XEVENT_DTYPE)[:m]
+            return np.frombuffer(d_out[:m * 56].cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)
+
+    if w["cpu_baseline"] and rank != 0:
+        m = min(n, PARITY_SAMPLE_RAYS)
+        ref_s, _, _ = oracle_pass(rays_h[:m], min(cores, 32))
+        got_s = device_events(m)
+        parity = bool(all(np.array_equal(got_s[f], ref_s[f]) for f in fields))
+
+    if w["cpu_baseline"] and rank == 0:
         # full pass: exact counters for the roofline + the reference result for the parity check; timed as the CPU baseline
         best = None
         budget = time.time() + w.get("cpu_budget_s", 20.0)
@@ -492,6 +522,9 @@ def measure(w, env):
             _, c1ctr, _ = oracle_pass(rays_h[:n1], 1)
             dt1 = time.perf_counter() - c0
             cpu = {"value": round(casts / best / 1e6, 3), "unit": unit, "cores": cores, "kind": "port",
+                   # the box: cores this process may run on / logical CPUs of the host; `cores` = threads the timed passes used
+                   "affinity_cores": affinity, "host_cores": os.cpu_count(),
+                   "value_1thread": round(c1ctr["rays"] / dt1 / 1e6, 3),
                    "sample": f"{n} rays of this workload" + (f" x {B} casts ({casts} live casts)" if B > 1 else "")
                              + f", best of {reps} passes on {cores} threads; 1 thread: {c1ctr['rays'] / dt1 / 1e6:.3f} {unit} on {n1} rays. "
                              f"C restatement of Hare {ref_name} (oracle/, per-thread mailbox, no per-candidate allocation): an upper "
@@ -525,38 +558,54 @@ def measure(w, env):
         if B > 1:
             roofline["per_cast_ms"] = [round(x, 4) for x in per_cast_ms]
             roofline["live_casts_per_pass"] = casts
-        # parity spot check of the bench buffers themselves (not timed)
-        if events_dev is not None:
-            got = np.frombuffer(events_dev, dtype=H.capi.XEVENT_DTYPE)
-        else:
-            got = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)   # events of the last cast
-        fields = ("hit", "poly_id", "t", "x", "y", "z", "u", "v")
+        # parity check of the bench buffers themselves (not timed): every ray of this rank's shard, all eight fields, bit for bit
+        got = device_events(n)
         parity = bool(all(np.array_equal(got[f], ref[f]) for f in fields))
         if bounce_batch is not None:
             bb_ev = bounce_batch.pop("events")
             bounce_batch["parity_vs_oracle"] = bool(all(np.array_equal(bb_ev[f], ref[f]) for f in fields)) and bounce_batch["casts"] == casts
     if bounce_batch is not None:
         bounce_batch.pop("events", None)
+    if w["cpu_baseline"] and dist is not None:
+        # one flag per rank, gathered: the line's parity is the AND over every device
+        fl = torch.tensor([1 if parity else 0], dtype=torch.int64)
+        if backend == "nccl":
+            fl = fl.cuda()
+        got_fl = [torch.zeros_like(fl) for _ in range(world)]
+        dist.all_gather(got_fl, fl)
+        parity_ranks = [bool(int(g[0])) for g in got_fl]
+    if rank != 0:
+        del ray_sets, out_sets, d_rays, d_out, d_rays0, d_excl
+        torch.cuda.empty_cache()
+        return None
 
     ms_per_step = wall * 1e3 / steps
     value = n_total * B * steps / wall / 1e6   # casts per second
     line = {
         "metric": "Mrays/s (primary hits) into 100k-tri mesh", "value": round(value, 2), "unit": "Mrays/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{n} spherical-Fibonacci burst rays per GPU -> {mesh.name} "
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": (f"{n_total} spherical-Fibonacci burst rays in contiguous shards over {world} GPU(s)" if strong else
+                                f"{n} spherical-Fibonacci burst rays per GPU") + f" -> {mesh.name} "
                                f"({mesh.P} triangles), {kdesc}, closest hit (X_Event)"
                                + (f", x{B} specular bounces device-resident (value = casts/s)" if B > 1 else ""),
-                   "rays_per_gpu": n, "triangles": mesh.P, "partition": kdesc, "sharding": f"rays x{world}, scene replicated",
+                   "rays_per_gpu": n, "rays_total": n_total, "triangles": mesh.P, "partition": kdesc,
+                   "sharding": f"rays x{world}, scene replicated",
                    "buffer_sets": n_sets,
                    "backend": ("none" if dist is None else ("rccl" if backend == "nccl" else "gloo (rehearsal)"))},
         "ms_per_step_per_rank": {"max": round(max(walls) * 1e3 / steps, 4), "min": round(min(walls) * 1e3 / steps, 4)},
         "device_ms_per_step": round(dev_ms / steps, 4), "kernel_only_mrays_s": round(n / kern_ms / 1e3, 2),
         "end_to_end_mrays_s": None if e2e is None else round(e2e, 1),
         "hits": hits_total, "rays": rays_total, "build_s": round(build_s, 3),
-        "x_event_parity_vs_oracle": parity,
+        "x_event_parity_vs_oracle": parity if parity_ranks is None else bool(all(parity_ranks)),
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if dist is not None:
+        line["ranks_seen_in_reduce"] = ranks_seen        # from the all-reduced ray counter (RCCL at backend nccl)
+        if parity_ranks is not None:
+            line["parity_per_rank"] = parity_ranks
+            line["parity_sample"] = (f"rank 0: its whole shard ({n} rays" + (f" x {B} casts" if B > 1 else "") + "), all 8 X_Event fields "
+                                     f"bit-equal to the oracle; ranks 1..{world - 1}: the first {min(n, PARITY_SAMPLE_RAYS)} rays of their shard")
     if e2e_slim is not None:
         line["end_to_end_slim_mrays_s"] = round(e2e_slim, 1)
         line["slim_events_rebuild_identical"] = slim_ok
@@ -567,14 +616,26 @@ def measure(w, env):
     return line
 
 
-# What the default N = 1 run appends to the headline line (BASELINE.json configs 3, 4, 5 at one GPU's share)
+PARITY_SAMPLE_RAYS = 65536      # what ranks 1..N-1 pass through the oracle (rank 0: its whole shard)
+
+# What the default run appends to the headline line: the rest of BASELINE.json's table.
+#   c4 / c5     configs 4 and 5 as BASELINE states them -- ONE batch of 16 777 216 rays (8 388 608 rays x 8 specular bounces) into the
+#               1M-triangle cathedral, cut into contiguous shards over the N ranks (strong scaling; at N = 8: 2M / 1M rays per GPU).
+#               Measured at EVERY N, with the counter all-reduce, max-over-ranks timing and a parity flag per rank.
+#   c3, c4_shard, c5_shard (N = 1 only): config 3, and what ONE GPU of the 8-GPU configs gets (2M rays; 1M rays x 8), with roofline
+#               and the CPU baseline -- the per-GPU kernels' figures, comparable round to round.
 EXTRA_CONFIGS = (
-    ("c3", {"scene": "hall", "kind": "octree", "domain": 64, "rays": 1 << 20, "bounces": 1, "steps": 5, "warmup": 1}),
-    ("c4_shard", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 21, "bounces": 1, "steps": 8, "warmup": 2}),
-    ("c5", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 20, "bounces": 8, "steps": 3, "warmup": 1}),
+    ("c3", {"scene": "hall", "kind": "octree", "domain": 64, "rays": 1 << 20, "bounces": 1, "steps": 5, "warmup": 1, "only_n1": True}),
+    ("c4_shard", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 21, "bounces": 1, "steps": 8, "warmup": 2,
+                  "only_n1": True}),
+    ("c5_shard", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 20, "bounces": 8, "steps": 3, "warmup": 1,
+                  "only_n1": True, "bounce_api": "batch"}),
+    ("c4", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays_total": 1 << 24, "bounces": 1, "steps": 5, "warmup": 1}),
+    ("c5", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays_total": 1 << 23, "bounces": 8, "steps": 2, "warmup": 1}),
 )
-EXTRA_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernel_only_mrays_s", "hits", "rays", "build_s",
-              "x_event_parity_vs_oracle", "roofline", "cpu_baseline", "bounce_batch")
+EXTRA_KEYS = ("value", "unit", "n_gpus", "scaling", "steps", "warmup", "ms_per_step", "ms_per_step_per_rank", "dtype", "config",
+              "kernel_only_mrays_s", "hits", "rays", "build_s", "x_event_parity_vs_oracle", "parity_per_rank", "parity_sample",
+              "ranks_seen_in_reduce", "roofline", "cpu_baseline", "bounce_batch")
 
 
 def main() -> None:
@@ -627,23 +688,34 @@ def main() -> None:
 
     default_workload = (args.scene == "hall" and args.kind == "voxel" and args.domain == 64 and args.rays == 1 << 20 and args.bounces == 1)
     extras = (default_workload and not args.no_extra_configs) or args.extra_configs
-    if rank == 0 and world == 1 and extras and not args.no_cpu_baseline:
-        # configs 3, 4 (one GPU's shard) and 5 in the same process, driver-observed like the headline; fewer steps, one oracle pass
-        line["configs"] = {}
+    if extras and not args.no_cpu_baseline:
+        # the rest of BASELINE's table in the same process(es), driver-observed like the headline; fewer steps, one oracle pass.
+        # Every rank takes part: the strong-scaled configs 4 and 5 shard over all of them
+        configs = {}
         prev_scene = args.scene
         for name, cfg in EXTRA_CONFIGS:
+            if cfg.get("only_n1") and world > 1:
+                continue
             if cfg["scene"] != prev_scene:
                 env.drop(prev_scene)
                 prev_scene = cfg["scene"]
+            cfg = {k: v for k, v in cfg.items() if k != "only_n1"}
             if args.extra_rays > 0:
-                cfg = dict(cfg, rays=min(cfg["rays"], args.extra_rays))
-            w = dict(cfg, cpu_baseline=True, e2e=False, copy_bw=False, cpu_reps=2, cpu_budget_s=6.0,
-                     bounce_api=("batch" if cfg["bounces"] > 1 else "device"))
+                if "rays_total" in cfg:
+                    cfg["rays_total"] = min(cfg["rays_total"], args.extra_rays * world)
+                else:
+                    cfg["rays"] = min(cfg["rays"], args.extra_rays)
+            w = dict({"bounce_api": "device"}, **cfg, cpu_baseline=True, e2e=False, copy_bw=False, cpu_reps=2, cpu_budget_s=6.0)
+            if "rays_total" in cfg:
+                w["cpu_reps"] = 1
             t0 = time.time()
             sub = measure(w, env)
-            sub = {k: sub[k] for k in EXTRA_KEYS if k in sub}
-            sub["wall_s"] = round(time.time() - t0, 1)
-            line["configs"][name] = sub
+            if rank == 0:
+                sub = {k: sub[k] for k in EXTRA_KEYS if k in sub}
+                sub["wall_s"] = round(time.time() - t0, 1)
+                configs[name] = sub
+        if rank == 0:
+            line["configs"] = configs
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

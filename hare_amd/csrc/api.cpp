@@ -400,15 +400,29 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     if (sl.used) HIP_TRY(H->StreamWaitEvent(st, sl.ev, 0));
     int rc = launch(H, f, grid, block, lds, st, args);
     if (rc) return rc;
+    // From here on a kernel is enqueued that will use the slot (and the hand-over block).  If a later step fails, the slot must
+    // not come round again in the state that kernel leaves it in with nothing to wait for: drain the stream, put the slot back to
+    // the all-zero state the kernels start from, and forget the events that were never recorded.
+    auto fail_after_launch = [&](int code) {
+        const std::string msg = last_error();
+        (void)H->StreamSynchronize(st);
+        (void)H->MemsetAsync(static_cast<LaunchSlotMem*>(s.d_work) + idx, 0, sizeof(LaunchSlotMem), st);
+        (void)H->StreamSynchronize(st);
+        sl.used = false;
+        if (tail_ring >= 0) s.oct_tail_used[tail_ring] = false;
+        set_error(msg);
+        return code;
+    };
     if (with_k2t) {
-        // K2t: enough waves that every left-over ray of a typical launch gets one of its own; it reads the count K2p left behind
+        // K2t (octree_coop.hip): HARE_K2T_GROUP = 64, a whole wave per handed-over ray, four rays per workgroup; it reads the count
+        // K2p left behind.  LDS: one 20-byte frame per level for each of the workgroup's four rays
         const unsigned tgrid = std::max(1u, std::min(grid, 4u * (unsigned)std::max(1, s.module->cu_count)));
-        rc = launch(H, s.module->octree_tail, tgrid, 256, 32u * 20u * (unsigned)octree_tail_levels, st, args);      // room for 32 groups of 8 lanes x levels x 20 B
-        if (rc) return rc;
-        HIP_TRY(H->EventRecord(s.oct_tail_ev[tail_ring], st));
+        rc = launch(H, s.module->octree_tail, tgrid, 256, kOctTailGroupsPerBlock * 20u * (unsigned)octree_tail_levels, st, args);
+        if (rc) return fail_after_launch(rc);
+        if (hipError_t e = H->EventRecord(s.oct_tail_ev[tail_ring], st); e != hipSuccess) return fail_after_launch(hip_fail(H, e, "hipEventRecord"));
         s.oct_tail_used[tail_ring] = true;
     }
-    HIP_TRY(H->EventRecord(sl.ev, st));
+    if (hipError_t e = H->EventRecord(sl.ev, st); e != hipSuccess) return fail_after_launch(hip_fail(H, e, "hipEventRecord"));
     sl.used = true;
     return HARE_OK;
 }
@@ -1375,7 +1389,16 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
     // host-buffer callers get the reference's meaning of poly_origin: an index that matches no polygon (any negative
     // value) excludes nothing.  Only the device-resident bounce loop (hare_reflect_device + hare_shoot_device) may
     // retire rays, so the retire flag never passes here, nor do developer bits.
-    flags = sanitize_flags(*s, flags) & ~HARE_SHOOT_RETIRED_RAYS;
+    // (Developer bits write past the 64-byte counter block they are given: here that block is one of 16 in a staging array.)
+    flags = sanitize_flags(*s, flags) & ~HARE_SHOOT_RETIRED_RAYS & ~0xF000u;
+    if ((flags & HARE_SHOOT_SLIM_EVENTS) && (flags & HARE_SHOOT_WRITEBACK_ORIGIN) && out) {
+        // a slim record of a moved ray (hit == 2) holds t from the MOVED origin and hare_expand_events redoes the move from the
+        // ORIGINAL one; with the write-back the caller's rays[] would already hold the moved origins and the rebuilt t would
+        // silently lack t_start.  One call cannot have both.
+        set_error("hare_shoot_batch: HARE_SHOOT_SLIM_EVENTS cannot be combined with HARE_SHOOT_WRITEBACK_ORIGIN "
+                  "(hare_expand_events needs the rays as they were passed in)");
+        return HARE_E_INVALID;
+    }
     DeviceGuard dev_guard(hip_api(nullptr), s->device);
     const HipApi* H = nullptr;
     Scene::BatchCtx* c = nullptr;

@@ -276,6 +276,11 @@ constexpr int kOctTailHead = 64;
                                   // (16, 64) 2.69, (16, 96) 2.95, (32, 160) 3.07; without the hand-over 2.94
 #endif
 constexpr int kOctTailMax = HARE_K2P_TAIL_MAX;
+#ifndef HARE_K2T_GROUP
+#define HARE_K2T_GROUP 64         // K2t: lanes per handed-over ray: 64 = a whole wave (8 / 16 / 32: measured, slower -- the groups of a wave diverge)
+#endif
+constexpr int kOctTailGroup = HARE_K2T_GROUP;
+constexpr unsigned kOctTailGroupsPerBlock = 256u / (unsigned)kOctTailGroup;     // rays a 256-thread K2t workgroup walks at a time (LDS: frames for each)
 
 struct ShootIO {
     RayRec* rays;              // n; written only with SHOOT_WRITEBACK_ORIGIN

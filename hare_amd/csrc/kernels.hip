@@ -1132,12 +1132,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     launch_epilogue(io, nrays, nhits, 4u);
 }
 
-// K2t: the rays K2p handed over, eight at a time per wave: one per group of kOctTailGroup lanes (octree_coop.hip).  Grid: any number of
-// 256-thread workgroups; dynamic LDS = (256 / kOctTailGroup) groups x levels x 20 bytes.
-#ifndef HARE_K2T_GROUP
-#define HARE_K2T_GROUP 64          // lanes per handed-over ray: 64 = a whole wave (8: measured, slower -- the groups of a wave diverge)
-#endif
-constexpr int kOctTailGroup = HARE_K2T_GROUP;
+// K2t: the rays K2p handed over, one per group of kOctTailGroup lanes (hare_device.h: 64, a whole wave per ray; octree_coop.hip).
+// Grid: any number of 256-thread workgroups; dynamic LDS = kOctTailGroupsPerBlock groups x levels x 20 bytes.
 __device__ __forceinline__ void octree_tail_body(const OctreeArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];

@@ -6,10 +6,11 @@
 // when the longest chain does: at 1M rays the tickets are dry at 1.49 ms and the last wave ends at 3.0 ms (tools/timeline_oct.py).
 // A K2p wave that has drawn its last ticket and is down to its last few rays therefore stops: it writes their state -- the frames of
 // the depth-first walk and the hit so far -- to a per-launch array in device memory and ends.  K2t, launched behind K2p on the
-// same stream, walks each of those rays with a GROUP OF EIGHT LANES: the up-to-eight children of a frame are fetched and tested at
-// once, a leaf's list (7 entries on average) is pre-culled and tested in one go.  The chain of a ray gets 2-3x shorter, and every
-// CU is free by then: the left-over rays of a launch all run at the same time.  (A whole wave per ray was measured first: the
-// chain is the same, but 4 096 waves serve 4 096 rays at a time and the hand-over holds 16 000: K2t then took what K2p had saved.)
+// same stream, walks each of those rays with a group of G lanes -- as shipped G = 64, a WHOLE WAVE per ray (HARE_K2T_GROUP, hare_device.h):
+// the up-to-eight children of a frame are fetched and tested at once by eight of the lanes, a leaf's list is pre-culled and tested
+// in one go, 64 entries at a time.  Every CU is free by then: the left-over rays of a launch all run at the same time.  (Groups of 8,
+// 16 and 32 lanes -- several rays per wave -- were measured and are slower: the groups of a wave are in different loops at different
+// times, DESIGN.md section 9b.  The code below is written for any power-of-two G >= 8.)
 //
 // The walk is Octree.Shoot's ("Octree - alt.cs":159-284), in the frame form of K2p (kernels.hip):
 //   * children of a frame are examined from cursor 7 down to 0 (= popped far to near, :286-306), one at a time and in that
@@ -27,8 +28,8 @@ namespace {
 __device__ __forceinline__ double coop_min(double a, double b) { return (a < b || a != a) ? a : b; }   // NaN-propagating like Math.Min (omin of K2p)
 __device__ __forceinline__ double coop_max(double a, double b) { return (b < a || a != a) ? a : b; }
 
-// One ray from the state a K2p lane left it in, by a GROUP of G consecutive lanes (G = 8: eight rays per wave at a time; the groups of
-// a wave run independently, each lane's control flow is that of its group): frames [0 .. lvl] (fa, fb, fpk: this group's arrays), the
+// One ray from the state a K2p lane left it in, by a GROUP of G consecutive lanes (shipped: G = 64, one ray per wave; G < 64: the groups
+// of a wave run independently, each lane's control flow is that of its group): frames [0 .. lvl] (fa, fb, fpk: this group's arrays), the
 // current leaf's remaining entries items[q .. qe) with entry parameter leaf_ca, and the hit so far.  All arguments group-uniform.
 template <int G>
 __device__ __forceinline__ void coop_octree(const OctreeArgs& g, const ShootIO& io, double* fa, double* fb, int* fpk, unsigned ray, int lvl, int q,

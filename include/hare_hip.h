@@ -65,7 +65,9 @@ extern "C" {
                                        /* polygon, as in the reference (Voxel_Grid.cs:477 compares indices only)              */
 
 #define HARE_SHOOT_SLIM_EVENTS 16u     /* hare_shoot_batch / _sharded only: `out` receives slim records (below) instead of X_Events:   */
-                                       /* 16 bytes per ray come back over the host link instead of 56                                    */
+                                       /* 16 bytes per ray come back over the host link instead of 56.  Not together with                 */
+                                       /* HARE_SHOOT_WRITEBACK_ORIGIN (HARE_E_INVALID): hare_expand_events redoes the origin move from    */
+                                       /* the rays as they were passed in, which the write-back would have overwritten                   */
 
 /* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
  * only serve the reference's mailbox pool and are not needed here. 48 bytes. */

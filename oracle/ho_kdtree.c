@@ -233,7 +233,7 @@ int ho_kdtree_shoot(const ho_kdtree *k, const ho_topology *models, const ho_ray 
 
     int scap = k->max_depth + 8;
     int32_t *stack = (int32_t *)malloc((size_t)scap * sizeof(int32_t));
-    if (!stack) { ho_set_error("oracle: out of memory"); return 0; }      /* out already holds the miss record */
+    if (!stack) { ho_set_error("oracle: out of memory"); return -1; }     /* an ERROR, not a miss (out holds the miss record, not to be compared) */
     int sp = 0;
     stack[sp++] = 0;
     const double o[3] = {ray->x, ray->y, ray->z};
@@ -309,6 +309,7 @@ typedef struct kjob {
     int32_t first_id;
     ho_xevent *out;
     ho_counters ctr;
+    int failed;                 /* a ray could not be traced (allocation failure): the batch reports an error */
 } kjob;
 
 static void *kworker(void *arg)
@@ -317,9 +318,11 @@ static void *kworker(void *arg)
     int32_t P = j->models[j->top].P;
     int32_t *mb = (int32_t *)calloc((size_t)(P ? P : 1), sizeof(int32_t));
     memset(&j->ctr, 0, sizeof j->ctr);
+    if (!mb) { j->failed = 1; return NULL; }
     for (int64_t i = j->lo; i < j->hi; ++i) {
         int h = ho_kdtree_shoot(j->k, j->models, &j->rays[i], j->top, j->e1 ? j->e1[i] : -1,
                                 j->e2 ? j->e2[i] : -1, mb, j->first_id + (int32_t)i, &j->out[i], &j->ctr);
+        if (h < 0) { j->failed = 1; break; }
         j->ctr.rays++;
         j->ctr.hits += (uint64_t)h;
     }
@@ -353,8 +356,10 @@ int ho_kdtree_shoot_batch(const ho_kdtree *k, const ho_topology *models, int32_t
     }
     ho_counters tot;
     memset(&tot, 0, sizeof tot);
+    int failed = 0;
     for (int q = 0; q < nthreads; ++q) {
         if (nthreads > 1) pthread_join(th[q], NULL);
+        failed |= jobs[q].failed;
         tot.rays += jobs[q].ctr.rays;
         tot.hits += jobs[q].ctr.hits;
         tot.cells += jobs[q].ctr.cells;
@@ -364,5 +369,9 @@ int ho_kdtree_shoot_batch(const ho_kdtree *k, const ho_topology *models, int32_t
     if (ctr) *ctr = tot;
     free(jobs);
     free(th);
+    if (failed) {
+        ho_set_error("oracle kd-tree: out of memory while tracing a ray (traversal stack / mailbox); the batch's events are not valid");
+        return -1;
+    }
     return 0;
 }

@@ -244,7 +244,7 @@ int ho_octree_shoot(const ho_octree *o, const ho_topology *models, const ho_ray 
 
     int scap = 8 * (o->max_depth + 2);
     sentry *stack = (sentry *)malloc((size_t)scap * sizeof(sentry));
-    if (!stack) { ho_set_error("oracle: out of memory"); miss(out); return 0; }
+    if (!stack) { ho_set_error("oracle: out of memory"); miss(out); return -1; }      /* an ERROR, not a miss: callers must not compare this record */
     int sp = 0;
     stack[sp].node = 0;
     stack[sp].tmin = tmin;
@@ -309,10 +309,10 @@ int ho_octree_shoot(const ho_octree *o, const ho_topology *models, const ho_ray 
                 double childTmax = ho_dotnet_min(ho_dotnet_min(cTx1, cTy1), cTz1);
                 if (childTmax < childTmin || childTmax < 0 || childTmin > nodeTmax || childTmax < nodeTmin) continue;
                 if (sp == scap) {
-                    if (ho_grow((void **)&stack, (size_t)scap * 2 * sizeof(sentry))) {     /* cannot continue this ray: report the failure as a miss */
+                    if (ho_grow((void **)&stack, (size_t)scap * 2 * sizeof(sentry))) {     /* cannot continue this ray: an ERROR (-1), never a miss */
                         free(stack);
                         miss(out);
-                        return 0;
+                        return -1;
                     }
                     scap *= 2;
                 }
@@ -341,6 +341,7 @@ typedef struct ojob {
     const int32_t *e1, *e2;
     ho_xevent *out;
     ho_counters ctr;
+    int failed;                 /* a ray could not be traced (allocation failure): the batch reports an error */
 } ojob;
 
 static void *oworker(void *arg)
@@ -350,6 +351,7 @@ static void *oworker(void *arg)
     for (int64_t i = j->lo; i < j->hi; ++i) {
         int h = ho_octree_shoot(j->o, j->models, &j->rays[i], j->top, j->e1 ? j->e1[i] : -1,
                                 j->e2 ? j->e2[i] : -1, &j->out[i], &j->ctr);
+        if (h < 0) { j->failed = 1; return NULL; }
         j->ctr.rays++;
         j->ctr.hits += (uint64_t)h;
     }
@@ -381,8 +383,10 @@ int ho_octree_shoot_batch(const ho_octree *o, const ho_topology *models, int32_t
     }
     ho_counters tot;
     memset(&tot, 0, sizeof tot);
+    int failed = 0;
     for (int k = 0; k < nthreads; ++k) {
         if (nthreads > 1) pthread_join(th[k], NULL);
+        failed |= jobs[k].failed;
         tot.rays += jobs[k].ctr.rays;
         tot.hits += jobs[k].ctr.hits;
         tot.cells += jobs[k].ctr.cells;
@@ -392,5 +396,9 @@ int ho_octree_shoot_batch(const ho_octree *o, const ho_topology *models, int32_t
     if (ctr) *ctr = tot;
     free(jobs);
     free(th);
+    if (failed) {               /* the worker's message is thread-local to the worker: say it on the caller's thread */
+        ho_set_error("oracle octree: out of memory while tracing a ray (traversal stack); the batch's events are not valid");
+        return -1;
+    }
     return 0;
 }

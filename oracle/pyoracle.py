@@ -282,8 +282,10 @@ class Octree:
         ctr = Counters()
         e1 = _opt_i32(excl1, n)
         e2 = _opt_i32(excl2, n)
-        L.ho_octree_shoot_batch(self.h, self.models.arr, top_index, n, _p(rays), _p(e1), _p(e2), nthreads,
-                                _p(out), C.addressof(ctr))
+        rc = L.ho_octree_shoot_batch(self.h, self.models.arr, top_index, n, _p(rays), _p(e1), _p(e2), nthreads,
+                                     _p(out), C.addressof(ctr))
+        if rc != 0:       # the checker must never pass a failed trace off as a miss record
+            raise MemoryError((L.ho_last_error() or b"oracle octree shoot failed").decode())
         return out, ctr.as_dict()
 
 
@@ -325,8 +327,10 @@ class KDTree:
         ctr = Counters()
         e1 = _opt_i32(excl1, n)
         e2 = _opt_i32(excl2, n)
-        L.ho_kdtree_shoot_batch(self.h, self.models.arr, top_index, n, _p(rays), _p(e1), _p(e2), first_ray_id,
-                                nthreads, _p(out), C.addressof(ctr))
+        rc = L.ho_kdtree_shoot_batch(self.h, self.models.arr, top_index, n, _p(rays), _p(e1), _p(e2), first_ray_id,
+                                     nthreads, _p(out), C.addressof(ctr))
+        if rc != 0:
+            raise MemoryError((L.ho_last_error() or b"oracle kd-tree shoot failed").decode())
         return out, ctr.as_dict()
 
 

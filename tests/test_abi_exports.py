@@ -74,3 +74,22 @@ def test_shoot_without_partition_or_gpu_fails_loudly(gpu_available):
         part.Shoot_batch(rays)
     # no GPU -> HARE_E_NODEVICE; GPU but nothing built -> HARE_E_STATE.  Never a silent CPU answer.
     assert ei.value.code == (capi.HARE_E_STATE if gpu_available else capi.HARE_E_NODEVICE)
+
+
+def test_slim_events_with_origin_writeback_is_refused_before_anything_runs():
+    """HARE_SHOOT_SLIM_EVENTS | HARE_SHOOT_WRITEBACK_ORIGIN: the write-back would overwrite the caller's rays with the moved origins
+    and hare_expand_events would then rebuild t without t_start for every ray that started outside the grid -- silently.  The
+    call is refused (HARE_E_INVALID) before any device work, so this needs no GPU; the rays are untouched."""
+    m = H.scenes.shoebox()
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    rays = H.scenes.burst_rays(64, m.size)
+    rays[:, :3] += 100.0                     # origins outside the grid: exactly the rays the combination would get wrong
+    before = rays.copy()
+    with pytest.raises(H.HareError) as ei:
+        g.Shoot_batch(rays, writeback_origin=True, slim=True)
+    assert ei.value.code == capi.HARE_E_INVALID and "WRITEBACK_ORIGIN" in str(ei.value)
+    assert np.array_equal(rays, before)
+    out = np.zeros(64, capi.SLIM_DTYPE)
+    rc = capi.lib.hare_shoot_batch(g._h, capi.KIND_VOXEL, 0, 64, rays.ctypes.data, None, None,
+                                   capi.SHOOT_SLIM_EVENTS | capi.SHOOT_WRITEBACK_ORIGIN, out.ctypes.data, None)
+    assert rc == capi.HARE_E_INVALID

@@ -12,6 +12,7 @@ import pytest
 import hare_amd as H
 
 pytestmark = pytest.mark.gpu
+OCTREE_KERNEL = "hare_octree_persist"      # what hare_shoot_kernel_name reports for Octree.Shoot batches
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,12 +25,28 @@ def _bench(*args):
     return json.loads(lines[0])
 
 
-def _oracle_hits(n_total, scene="hall", domain=64):
+def _oracle_hits(n_total, scene="hall", domain=64, bounces=1):
+    """Hits summed over `bounces` casts of the n_total-ray burst (the oracle's own bounce loop: reflect, exclude the polygon left)."""
     from oracle import pyoracle as po
     mesh = H.scenes.SCENES[scene]()
     rays = H.scenes.burst_rays(n_total, mesh.size)
-    ev, _ = po.VoxelGrid([po.Topology(mesh.verts, mesh.nverts)], domain=domain).shoot(rays, nthreads=8)
-    return int(ev["hit"].sum())
+    ot = po.Topology(mesh.verts, mesh.nverts)
+    og = po.VoxelGrid([ot], domain=domain)
+    hits, excl = 0, None
+    for b in range(bounces):
+        if excl is None:
+            ev, _ = og.shoot(rays, nthreads=8)
+        else:
+            live = excl >= 0
+            ev = np.zeros(len(rays), po.XEVENT_DTYPE)
+            ev["poly_id"] = -1
+            if live.any():
+                ev[live], _ = og.shoot(rays[live], excl1=excl[live], nthreads=8)
+        hits += int(ev["hit"].sum())
+        if b + 1 < bounces:
+            rays = po.reflect_batch(ot, rays, ev)
+            excl = np.where(ev["hit"] != 0, ev["poly_id"], -2).astype(np.int32)
+    return hits
 
 
 def test_bench_two_ranks_started_by_bench_itself():
@@ -42,6 +59,28 @@ def test_bench_two_ranks_started_by_bench_itself():
     assert j["ms_per_step_per_rank"]["max"] >= j["ms_per_step_per_rank"]["min"] > 0
     assert j["cpu_baseline"] is None                            # reported at N = 1 only
     assert j["roofline"]["kernel"] == "hare_voxel_pool_tri" and j["roofline"]["frac"] > 0
+    assert j["ranks_seen_in_reduce"] == 2 and j["parity_per_rank"] == [True, True]
+
+
+def test_bench_two_ranks_print_configs_4_and_5_strong_scaled():
+    """The driver's `python bench.py --gpus N` must measure BASELINE's 8-GPU configs, not only the headline: at N > 1 the line carries
+    c4 (ONE burst into the cathedral, D = 128, cut over the ranks) and c5 (the same with 8 specular bounces), each reduced over both
+    ranks and checked against the oracle on both.  Here at 2 x 32768 rays, gloo, the two ranks sharing this box's GPU."""
+    per = 32768
+    j = _bench("--gpus", "2", "--backend", "gloo", "--rays", str(per), "--steps", "2", "--warmup", "1", "--extra-configs",
+               "--extra-rays", str(per))
+    assert set(j["configs"]) == {"c4", "c5"}
+    c4, c5 = j["configs"]["c4"], j["configs"]["c5"]
+    for c in (c4, c5):
+        assert c["n_gpus"] == 2 and c["scaling"] == "strong" and c["config"]["rays_total"] == 2 * per
+        assert c["config"]["rays_per_gpu"] == per and c["ranks_seen_in_reduce"] == 2
+        assert c["x_event_parity_vs_oracle"] is True and c["parity_per_rank"] == [True, True]
+        assert c["roofline"]["kernel"] == "hare_voxel_pool_tri_g" and c["roofline"]["frac"] > 0 and c["value"] > 0
+    assert c4["rays"] == 2 * per                                      # the full config's ray count reached the reduce
+    assert c4["hits"] == _oracle_hits(2 * per, "cathedral", 128)
+    assert "x8 specular bounces" in c5["config"]["workload"]
+    assert c5["hits"] == _oracle_hits(2 * per, "cathedral", 128, bounces=8) and c5["rays"] <= 8 * 2 * per
+    assert c5["roofline"]["live_casts_per_pass"] > per * 7           # rank 0's shard, from its oracle pass
 
 
 def test_bench_rccl_branch_on_one_gpu_with_a_process_group_of_one():
@@ -56,25 +95,31 @@ def test_bench_rccl_branch_on_one_gpu_with_a_process_group_of_one():
     assert a["x_event_parity_vs_oracle"] is True and b["x_event_parity_vs_oracle"] is True
     assert b["cpu_baseline"]["value"] > 0 and b["roofline"]["frac"] > 0
     assert b["ms_per_step_per_rank"]["max"] == b["ms_per_step_per_rank"]["min"] > 0
+    assert b["ranks_seen_in_reduce"] == 1 and b["parity_per_rank"] == [True]
 
 
 def test_bench_appends_configs_3_4_5_to_the_one_line():
-    """The driver's N = 1 command measures the headline and then configs 3, 4 (shard) and 5 in the same process (here at
-    small sizes): each carries value, roofline, cpu_baseline and the parity flag."""
+    """The driver's N = 1 command measures the headline and then configs 3, 4 and 5 in the same process (here at small sizes):
+    one GPU's share of the 8-GPU configs (c4_shard, c5_shard) and the whole configs (c4, c5: the N = 1 point of the strong-scaling
+    curve); each carries value, roofline, cpu_baseline and the parity flag."""
     j = _bench("--rays", "32768", "--steps", "2", "--warmup", "1", "--extra-configs", "--extra-rays", "32768")
-    assert set(j["configs"]) == {"c3", "c4_shard", "c5"}
-    want = {"c3": "hare_octree_persist", "c4_shard": "hare_voxel_pool_tri_g", "c5": "hare_voxel_pool_tri_g"}
+    assert set(j["configs"]) == {"c3", "c4_shard", "c5_shard", "c4", "c5"}
+    want = {"c3": OCTREE_KERNEL, "c4_shard": "hare_voxel_pool_tri_g", "c5_shard": "hare_voxel_pool_tri_g",
+            "c4": "hare_voxel_pool_tri_g", "c5": "hare_voxel_pool_tri_g"}
     for name, sub in j["configs"].items():
         assert sub["x_event_parity_vs_oracle"] is True, name
         assert sub["value"] > 0 and sub["roofline"]["frac"] > 0 and sub["roofline"]["kernel"] == want[name]
         assert sub["cpu_baseline"]["kind"] == "port" and sub["cpu_baseline"]["value"] > 0
+        assert sub["cpu_baseline"]["host_cores"] >= sub["cpu_baseline"]["cores"] >= 1
+        assert sub["scaling"] == ("strong" if name in ("c4", "c5") else "weak")
     assert j["configs"]["c5"]["roofline"]["live_casts_per_pass"] > 32768 * 7
+    assert j["configs"]["c5_shard"]["bounce_batch"]["parity_vs_oracle"] is True
     assert j["metric"].startswith("Mrays/s") and j["x_event_parity_vs_oracle"] is True     # the headline fields are untouched
 
 
 @pytest.mark.parametrize("extra,kernel", [
     ((), "hare_voxel_pool_tri"),                          # the pool kernel serves every batch size (api.cpp: choose_kernel)
-    (("--kind", "octree"), "hare_octree_persist"),
+    (("--kind", "octree"), OCTREE_KERNEL),
     (("--bounces", "3"), "hare_voxel_pool_tri"),
     (("--rays", "1048576"), "hare_voxel_pool_tri"),
 ])

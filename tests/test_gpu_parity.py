@@ -342,14 +342,16 @@ def test_degenerate_rays_match_the_oracle_bit_for_bit(domain):
 
 def test_in_process_sharding_over_scenes_is_byte_identical(hall):
     """hare_shoot_batch_sharded: one process, one scene per device, contiguous ray shards, one host thread each.
-    (This box has one GPU, so the scenes share device 0; the slicing, threading, error and counter paths are the
-    same.)  Output must equal the one-scene call byte for byte, for ragged splits and exclusions too."""
+    Scene k lives on device k % device_count(): on an 8-GPU node the four shards run on four real devices, on a one-GPU
+    box they share device 0 (the slicing, threading, error and counter paths are the same).  Output must equal the
+    one-scene call byte for byte, for ragged splits and exclusions too."""
     import ctypes as C
     from hare_amd import capi
     m, T, To = hall
     n = 300_007                                    # not divisible by 3 or 4
     rays = H.scenes.burst_rays(n, m.size)
-    grids = [H.Voxel_Grid([T], 32) for _ in range(4)]
+    ndev = H.device_count()
+    grids = [H.Voxel_Grid([T], 32, device=k % ndev) for k in range(4)]
     ref, rc = grids[0].Shoot_batch(rays)
     excl = ref["poly_id"].astype(np.int32)
     ref2, rc2 = grids[0].Shoot_batch(rays, poly_origin1=excl)

@@ -167,8 +167,8 @@ def test_bounce_batch_edges_and_sharding():
     away[:, 3:] = 1.0
     ev, c, pcs = g.Bounce_batch(away, 5, all_casts=True, per_cast=True)
     assert not ev["hit"].any() and (ev["poly_id"] == -1).all() and c["rays"] == len(away) and pcs[1]["rays"] == 0
-    # two scenes on this device standing in for two devices: byte-identical to the one-scene call
-    g2 = H.Voxel_Grid([T], 8)
+    # two scenes, the second on device 1 where the box has one (else both on this device): byte-identical to the one-scene call
+    g2 = H.Voxel_Grid([T], 8, device=1 % H.device_count())
     ref, rc = oracle_bounce_loop(po, To, o, rays, 6)
     a, ca = g.Bounce_batch(rays, 6, all_casts=True)
     b, cb = H.Spatial_Partition.Bounce_batch_sharded([g, g2], rays, 6, all_casts=True)
@@ -307,7 +307,7 @@ def test_slim_events_trees_quads_and_sharding():
         slim, c2 = g.Shoot_batch(r, slim=True)
         assert slim.dtype.itemsize == (16 if g._kind == capi.KIND_VOXEL else 32) and c2 == c
         assert g.expand_events(r, slim).tobytes() == full.tobytes()
-    g1, g2 = H.Octree([T], 5, 8), H.Octree([T], 5, 8)
+    g1, g2 = H.Octree([T], 5, 8), H.Octree([T], 5, 8, device=1 % H.device_count())
     full, _ = g1.Shoot_batch(rays)
     slim, _ = H.Spatial_Partition.Shoot_batch_sharded([g1, g2], rays, slim=True)
     assert g1.expand_events(rays, slim).tobytes() == full.tobytes()
