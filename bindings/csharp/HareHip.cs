@@ -4,7 +4,10 @@
 // assembly or on LD_LIBRARY_PATH.
 //
 // NOT COMPILED IN THE BUILD CONTAINER: no .NET toolchain exists there (DESIGN.md).  The native side
-// pins the layouts with static_asserts (api.cpp) and tests/test_abi_exports.py checks every symbol.
+// pins the layouts with static_asserts (api.cpp), tests/test_abi_exports.py checks every export, and
+// tests/test_csharp_binding.py parses THIS file against include/hare_hip.h: every DllImport (incl.
+// EntryPoint aliases) must name an export, with the header's parameter count, scalar widths and
+// pointer positions; every [StructLayout] struct must have the header's field sequence and size.
 using System;
 using System.Runtime.InteropServices;
 
@@ -39,6 +42,15 @@ namespace Hare
             public int hit;
         }
 
+        /// <summary>Slim result record of an Octree / KDTree batch (they return u, v; rays are never moved). 32 bytes.</summary>
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_slim_event_uv
+        {
+            public double t, u, v;
+            public int poly_id;
+            public int hit;
+        }
+
         [StructLayout(LayoutKind.Sequential, Pack = 8)]
         public struct hare_counters
         {
@@ -68,6 +80,13 @@ namespace Hare
             public double char_step;
             public ulong total_items;
             public int built_on_device, reserved;
+        }
+
+        [StructLayout(LayoutKind.Sequential, Pack = 8)]
+        public struct hare_tree_info
+        {
+            public int n_nodes, max_depth, max_polys, built_on_device;
+            public ulong total_items;
         }
 
         internal static class HareHip
@@ -142,6 +161,43 @@ namespace Hare
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_topology_ingest([In] double[] soup, [In] int[] nverts, int P, [Out] double[] verts_out,
                                                           [Out] int[] corner_vertex, [Out] double[] vertices_out, out int n_vertices);
+
+            // ---- the rest of include/hare_hip.h, so that every export has a managed declaration (tests/test_csharp_binding.py checks
+            // each one against the header: entry point, parameter count, scalar widths, pointer-ness, struct layouts)
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr hare_version();
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr hare_hip_runtime_path();
+            /// <summary>Polygon ctor normals (Hare_Geometry_Polygons.cs:159-171) for hosts that bypass the managed Topology.</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_polygon_normals([In] double[] verts, [In] int[] nverts, int P, [Out] double[] normals_out);
+            /// <summary>Finish_Topology bounds (Hare_Geometry_Topology.cs:148-167).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_topology_bounds([In] double[] verts, [In] int[] nverts, int P, [Out] double[] min_out, [Out] double[] max_out);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_octree_get_info(IntPtr scene, out hare_tree_info info);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_octree_get_nodes(IntPtr scene, [Out] double[] boxes, [Out] int[] first_child, [Out] int[] item_start,
+                                                           [Out] int[] item_count, [Out] int[] items);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int hare_kdtree_get_info(IntPtr scene, out hare_tree_info info);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_kdtree_get_nodes(IntPtr scene, [Out] double[] boxes, [Out] double[] split, [Out] int[] axis, [Out] int[] left,
+                                                           [Out] int[] right, [Out] int[] item_start, [Out] int[] item_count, [Out] int[] items);
+            /// <summary>Name of the gfx950 kernel a batch of n rays would launch (profiles list kernels by this name).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern IntPtr hare_shoot_kernel_name(IntPtr scene, int kind, int top_index, long n, uint flags);
+            /// <summary>The bounce loop on ONE scene (hare_bounce_batch_sharded with a single scene does the same).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_bounce_batch(IntPtr scene, int kind, int top_index, long n, [In] hare_ray[] rays, int[] excl1, int[] excl2,
+                                                       int bounces, uint flags, [Out] hare_xevent[] events_all, [Out] hare_xevent[] events_last,
+                                                       out hare_counters ctr, [Out] hare_counters[] ctr_per_cast);
+            // Device-pointer entry points, for managed hosts that hold HIP allocations (e.g. through a HIP interop layer): every
+            // pointer is a device address on the scene's device, `stream` a hipStream_t (IntPtr.Zero: the default stream).
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_shoot_device(IntPtr scene, int kind, int top_index, long n, IntPtr d_rays, IntPtr d_excl1, IntPtr d_excl2,
+                                                       uint flags, IntPtr d_out, IntPtr d_counters, IntPtr stream);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_occluded_device(IntPtr scene, int kind, int top_index, long n, IntPtr d_rays, IntPtr d_excl1, IntPtr d_excl2,
+                                                          IntPtr d_tmax, uint flags, IntPtr d_events, IntPtr d_occluded, IntPtr d_counters, IntPtr stream);
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_reflect_device(IntPtr scene, int top_index, long n, IntPtr d_rays, IntPtr d_events, IntPtr d_excl_out, IntPtr stream);
 
             public static void Check(int rc)
             {

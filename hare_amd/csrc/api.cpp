@@ -87,6 +87,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_persist", &m->octree_persist},
         {"hare_octree_pool", &m->octree_pool},
         {"hare_octree_tail", &m->octree_tail},
+        {"hare_octree_group", &m->octree_group},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
@@ -361,8 +362,10 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
 // args[1] must point to `io`.
 // `octree_tail_levels` > 0: a K2p launch -- it gets a block of hand-over records and is followed, on the same stream and inside the
 // slot's lock, by the cooperative tail kernel K2t (octree_coop.hip).
+// `group_spill_entries` > 0: a K2g launch (octree_group.hip) -- it gets a block of the same ring for the stack entries its groups
+// cannot keep in LDS (24 bytes x entries per group of eight lanes); no second kernel.
 int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, ShootIO& io,
-                   void** args, bool coop_tail = false, int octree_tail_levels = 0)
+                   void** args, bool coop_tail = false, int octree_tail_levels = 0, int group_spill_entries = 0)
 {
     const unsigned idx = s.work_slot.fetch_add(1) % kLaunchSlots;
     Scene::LaunchSlot& sl = s.slots[idx];
@@ -372,12 +375,14 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     io.wide_drain = s.opt.wide_drain ? 1 : 0;
     io.oct_tail = nullptr;
     const bool with_k2t = octree_tail_levels > 0 && s.opt.coop_tail && s.module->octree_tail != nullptr;
+    const bool with_spill = group_spill_entries > 0;
     std::unique_lock<std::mutex> tail_lk(s.oct_tail_mu, std::defer_lock);
     int tail_ring = -1;
-    if (with_k2t) {
-        const size_t stride = ((size_t)kOctTailHead + 20u * (size_t)octree_tail_levels + 15u) & ~(size_t)15u;
-        const size_t need = (size_t)grid * (block / 64u) * (size_t)kOctTailMax * stride;
-        tail_lk.lock();                      // held until K2t is launched and the block's event recorded
+    if (with_k2t || with_spill) {
+        const size_t stride = with_spill ? (size_t)group_spill_entries * 24u
+                                         : (((size_t)kOctTailHead + 20u * (size_t)octree_tail_levels + 15u) & ~(size_t)15u);
+        const size_t need = (size_t)grid * (block / 64u) * (with_spill ? (size_t)8 : (size_t)kOctTailMax) * stride;
+        tail_lk.lock();                      // held until the launch (and K2t behind it) is enqueued and the block's event recorded
         if (need > s.oct_tail_block_bytes) {
             // larger blocks (first use, or a deeper tree since): launches in flight may still use the old ones
             if (s.d_oct_tail) {
@@ -394,7 +399,7 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
         if (s.oct_tail_used[tail_ring]) HIP_TRY(H->StreamWaitEvent(st, s.oct_tail_ev[tail_ring], 0));
         io.oct_tail = static_cast<unsigned char*>(s.d_oct_tail) + (size_t)tail_ring * s.oct_tail_block_bytes;
         io.oct_tail_stride = (int32_t)stride;
-        io.oct_tail_levels = octree_tail_levels;
+        io.oct_tail_levels = with_spill ? group_spill_entries : octree_tail_levels;
     }
     if (!sl.ev) HIP_TRY(H->EventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (sl.used) HIP_TRY(H->StreamWaitEvent(st, sl.ev, 0));
@@ -419,6 +424,9 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
         const unsigned tgrid = std::max(1u, std::min(grid, 4u * (unsigned)std::max(1, s.module->cu_count)));
         rc = launch(H, s.module->octree_tail, tgrid, 256, kOctTailGroupsPerBlock * 20u * (unsigned)octree_tail_levels, st, args);
         if (rc) return fail_after_launch(rc);
+        if (hipError_t e = H->EventRecord(s.oct_tail_ev[tail_ring], st); e != hipSuccess) return fail_after_launch(hip_fail(H, e, "hipEventRecord"));
+        s.oct_tail_used[tail_ring] = true;
+    } else if (with_spill) {
         if (hipError_t e = H->EventRecord(s.oct_tail_ev[tail_ring], st); e != hipSuccess) return fail_after_launch(hip_fail(H, e, "hipEventRecord"));
         s.oct_tail_used[tail_ring] = true;
     }
@@ -446,7 +454,7 @@ void read_env_options(SceneOptions& o)
     o.dev = on(getenv("HARE_DEV"));
     if (!o.dev) return;            // everything below is a developer override: ignored unless the process opted in
     if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
-    if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
+    if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : 0));
     if (const char* t = getenv("HARE_TICKET")) o.ticket_rays = atoi(t);
     if (const char* t = getenv("HARE_K1P_STATIC_RAYS")) o.k1p_static_rays = atoi(t);
     if (const char* t = getenv("HARE_K2P_STATIC_RAYS")) o.k2p_static_rays = atoi(t);
@@ -502,7 +510,7 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 //  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): from two fills (786 432 rays) on a grid with one
 //    occupancy bit per voxel, three on a coarser bitmap (round 2, before the cooperative tails: three fills everywhere).
 // Both thresholds scale with the CU count of the device the scene lives on.
-enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctOccl,
+enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctGroup, OctOccl,
                   KdSimple, KdCount, None };
 struct KernChoice {
     Kern k = Kern::None;
@@ -595,6 +603,9 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         } else if (!simple && !huge && small_tree) {
             const bool pool_wanted = s.opt.octree_kernel == 2 || (s.opt.octree_kernel == 0 && kOctreePoolDefault && n >= 65536);
             if (pool_wanted && have(&DeviceModule::octree_pool)) { pick(Kern::OctPool, "hare_octree_pool", &DeviceModule::octree_pool); return c; }
+            // K2g (octree_group.hip): eight lanes per ray -- the production kernel for closest-hit batches of every size
+            const bool group_wanted = s.opt.octree_kernel == 3 || s.opt.octree_kernel == 0;
+            if (group_wanted && have(&DeviceModule::octree_group)) { pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group); return c; }
             if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist)) {
                 pick(Kern::OctPersist, "hare_octree_persist", &DeviceModule::octree_persist);
                 return c;
@@ -852,6 +863,22 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return rc;
         }
         void* args[] = {&g, &io};
+        if (kc.k == Kern::OctGroup) {
+            // K2g: workgroups of four waves, eight rays per wave; LDS = the groups' stacks and pending lists (hare_device.h).  A ray's
+            // stack can hold 7 x levels + 8 entries (the reference's LIFO, "Octree - alt.cs":268-272); what LDS does not hold spills
+            const unsigned glds = 4u * (unsigned)kGroupWaveBytes;
+            unsigned per_cu = std::min((unsigned)HARE_K2G_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / glds)));
+            unsigned pgrid = cus * per_cu;
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 7) / 8 + 3) / 4);            // a wave per eight rays at least
+            if (pgrid == 0) pgrid = 1;
+            io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 8;
+            // static first chunk per wave: what the batch has for every wave, at most 32 rays (four rounds of eight), at least 8
+            const int64_t per_wave = n / ((int64_t)pgrid * 4);
+            io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(32, per_wave / 2 / 8 * 8));
+            if (s.opt.k2p_static_rays > 0) io.static_rays = std::max(8, std::min(256, s.opt.k2p_static_rays / 8 * 8));   // developer sweeps
+            const int spill = std::max(0, 7 * g.max_depth + 8 - kGroupStack);
+            return launch_on_slot(s, H, kc.f, pgrid, 256, glds, st, io, args, false, 0, spill);
+        }
         if (kc.k == Kern::OctPersist || kc.k == Kern::OctOccl) {
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
@@ -1732,7 +1759,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"dev", &SceneOptions::dev, 0, 1},
         {"build_host", &SceneOptions::build_host, 0, 1},
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
-        {"octree_kernel", &SceneOptions::octree_kernel, 0, 2},
+        {"octree_kernel", &SceneOptions::octree_kernel, 0, 3},
         {"ticket_rays", &SceneOptions::ticket_rays, 0, 4096},
         {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 1024},
         {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},

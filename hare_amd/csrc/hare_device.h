@@ -241,6 +241,19 @@ constexpr int kOctPoolWaveBytes = kOctPoolSlots * (5 * 8 + 11 * 4) + 4 * kOctPoo
 static_assert(kOctPoolSlots >= 64 && kOctPoolSlots <= 256 && kOctPoolSlots % 2 == 0 && kOctPoolWaveBytes % 8 == 0, "K2q pool geometry");
 constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool kernel that may be in flight (each owns a scratch block)
 
+// K2g (octree_group.hip): eight lanes per ray, eight rays per wave.  Per group in LDS: the top kGroupStack entries of the ray's
+// stack (24 bytes: clamped interval + the node's child / list words) and kGroupPend pending survivors (16 bytes each).
+#ifndef HARE_K2G_STACK
+#define HARE_K2G_STACK 32
+#endif
+#ifndef HARE_K2G_WAVES_PER_EU
+#define HARE_K2G_WAVES_PER_EU 4
+#endif
+constexpr int kGroupStack = HARE_K2G_STACK;
+constexpr int kGroupPend = 16;
+constexpr int kGroupBytes = kGroupStack * 24 + kGroupPend * 16;
+constexpr int kGroupWaveBytes = 8 * kGroupBytes;
+
 // Scratch of ONE persistent launch in flight, in device memory (the scene keeps a ring of kLaunchSlots of them):
 //   ticket   next-ray ticket the waves draw from with atomicAdd
 //   done     waves that have finished, counted per blockIdx % 8 (the workgroups that share an XCD), and in done[8] the groups that

@@ -1454,4 +1454,7 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 
 #include "voxel_pool.hip"
 #include "octree_pool.hip"
+#include "octree_group.hip"
+// K2g: Octree.Shoot, eight lanes per ray (octree_group.hip) -- the production kernel of the octree path
+extern "C" __global__ __launch_bounds__(256, HARE_K2G_WAVES_PER_EU) void hare_octree_group(hare::OctreeArgs g, hare::ShootIO io) { octree_group_body(g, io); }
 #include "build_kernels.hip"

@@ -1,0 +1,363 @@
+// octree_group.hip -- K2g `hare_octree_group`: Octree.Shoot ("Octree - alt.cs":154-306) with a GROUP OF EIGHT LANES per ray,
+// eight rays per wave (included by kernels.hip).
+//
+// Why.  K2p gives a ray one lane: ~150 dependent steps (pop a child, fetch it, test it, at a leaf fetch list entries one pair at
+// a time, now and then an exact test) of 4 us each -- the life of a ray is 600 us, a 1M-ray launch is four generations of rays
+// deep and a third of it is the last generation draining.  Here the eight children of a node are tested by
+// the group's eight lanes AT ONCE and a leaf's list goes eight entries at a time: ~30 steps per ray instead of 150, 1/16 of the
+// rays in flight for the same throughput, and the end of a launch shrinks with the life of a ray.
+//
+// What makes that possible is that almost nothing in Octree.Shoot depends on the hits found so far:
+//   * WHICH nodes are pushed, in which order, with which clamped interval [tmin, tmax] (:245-272) depends on the ray and the boxes
+//     only; so does the first pop test (:207).  The group keeps the reference's explicit LIFO stack in LDS: entry = the clamped
+//     interval + the node's child / list words; the eight children of a popped interior node are tested by lanes 0..7 (lane k =
+//     order[k], :286-306) and the accepted ones are pushed in order[0..7], so that order[7] is popped first, as in the reference.
+//     Entries that the hit-independent pop test (:207) would drop are never pushed, nor are leaves with an empty list (popping
+//     one has no effect).
+//   * the value of RayXtri (t, u, v) for a (ray, polygon) pair depends on nothing else, and the conservative FP32 pre-cull in front
+//     of it is stateless.
+//   * the ONLY state is {hit, closestT, the best event}: it prunes (:210 `hit && closestT <= nodeTmin` -> skip the node), accepts
+//     (:225 strict <) and ends the query (:233 accepted t <= the leaf's nodeTmin).  A larger (older) closestT prunes less, never
+//     more: walking with a stale closestT visits a superset of the reference's nodes, in the reference's order.
+// So the walk runs ahead with the closestT it has: a leaf's entries are pre-culled eight at a time and the survivors are only
+// NOTED -- polygon, the leaf's nodeTmin, the leaf's visit number -- in a per-ray pending list, in walk order.  When enough are
+// pending in the wave (or a ray cannot go on without them) the exact tests of all pending survivors run together, one per lane,
+// and their results are REPLAYED in order against the state, exactly as the reference meets them:
+//     entering a new leaf (first pending survivor with a new visit number):  skipped = hit && closestT <= leafTmin      (:210)
+//     not skipped, t > 1e-10 && t < closestT:  accept;  accepted t <= leafTmin:  the query ends                        (:224-236)
+// (the skip decision is made at the leaf's first VALID survivor instead of at its pop: the state cannot change in between.)
+// A leaf the reference would have skipped or never reached was pre-culled in vain; its survivors are discarded by the replay.
+// Results are bit-identical to the sequential walk (tests: every octree test of the suite runs against this kernel).
+//
+// LDS per group: the stack's top kGStack entries (24 B each) + 16 pending survivors (16 B each); entries below the top kGStack
+// spill to a per-launch block in device memory (the scene's octree scratch ring, api.cpp), so a stack of any depth the tree
+// allows (7 x levels + 8) works, at LDS speed for all but pathological rays.
+namespace {
+
+#ifndef HARE_K2G_EXACT_MIN
+#define HARE_K2G_EXACT_MIN 12      // run the exact phase when this many survivors are pending in the wave (or a ray is blocked on its own)
+#endif
+#ifndef HARE_K2G_REFILL
+#define HARE_K2G_REFILL 2          // set up new rays when this many groups of the wave are idle
+#endif
+constexpr int kGStack = kGroupStack;                              // stack entries per ray kept in LDS (hare_device.h); deeper ones spill
+constexpr int kGPend = kGroupPend;                                // pending survivors per ray (two chunks' worth)
+constexpr int kGGroupBytes = kGroupBytes;
+constexpr int kGWaveBytes = kGroupWaveBytes;
+
+__device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const ShootIO& io)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int W = 8;                                           // lanes per ray
+    const int wl = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = wl & (W - 1);                                    // position in the group = cursor position of the child this lane tests
+    const int gshift = wl - j;
+    const unsigned jbit = 1u << j, jlt = jbit - 1u;
+    auto gballot = [&](bool p) -> unsigned { return (unsigned)(__ballot(p) >> gshift) & 255u; };
+
+    unsigned char* const gl = lds + (size_t)wave * kGWaveBytes + (size_t)(wl >> 3) * kGGroupBytes;
+    double* const sa = reinterpret_cast<double*>(gl);             // [kGStack] clamped tmin of the entry's node
+    double* const sb = sa + kGStack;                               // [kGStack] clamped tmax
+    int2* const sw = reinterpret_cast<int2*>(sb + kGStack);        // [kGStack] interior: {first_child, 0}; leaf: {-1 - item_start, item_count}
+    double* const plca = reinterpret_cast<double*>(sw + kGStack);  // [kGPend] pending survivor: its leaf's nodeTmin
+    int2* const ppw = reinterpret_cast<int2*>(plca + kGPend);      // [kGPend] {polygon, leaf visit number}
+    // entries kGStack.. of this group's stack: its block of the launch's spill area (sized by the host for 7 * levels + 8 entries)
+    const int spill_cap = io.oct_tail_levels;                      // entries per group in the spill block
+    unsigned char* const spill = io.oct_tail == nullptr ? nullptr :
+        io.oct_tail + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 8u + (size_t)(wl >> 3)) * (size_t)spill_cap * 24u;
+    auto st_store = [&](int e, double a, double b, int2 w) {
+        if (e < kGStack) { sa[e] = a; sb[e] = b; sw[e] = w; }
+        else {
+            unsigned char* p = spill + (size_t)(e - kGStack) * 24u;
+            *reinterpret_cast<double*>(p) = a; *reinterpret_cast<double*>(p + 8) = b; *reinterpret_cast<int2*>(p + 16) = w;
+        }
+    };
+    auto st_load = [&](int e, double& a, double& b, int2& w) {
+        if (e < kGStack) { a = sa[e]; b = sb[e]; w = sw[e]; }
+        else {
+            const unsigned char* p = spill + (size_t)(e - kGStack) * 24u;
+            a = *reinterpret_cast<const double*>(p); b = *reinterpret_cast<const double*>(p + 8); w = *reinterpret_cast<const int2*>(p + 16);
+        }
+    };
+    auto lds_sync = [&]() {                                        // one lane's LDS / spill writes, before other lanes of the wave read them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- rays: a static first chunk per wave, then tickets (as K1p / K2p)
+    const unsigned int n32 = (unsigned int)io.n;
+    const unsigned int waves_per_block = blockDim.x >> 6;
+    const int RAY_CHUNK = io.static_rays > 0 ? io.static_rays : 32;
+    const unsigned int n_static = gridDim.x * waves_per_block * (unsigned int)RAY_CHUNK;
+    unsigned int chunk_id = blockIdx.x * waves_per_block + (unsigned)wave;
+    if ((gridDim.x & 7u) == 0) chunk_id = ((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * waves_per_block + (unsigned)wave;   // XCD-contiguous
+    unsigned int cn = chunk_id * (unsigned int)RAY_CHUNK, ce = cn + (unsigned int)RAY_CHUNK;
+    if (cn > n32) cn = n32;
+    if (ce > n32) ce = n32;
+    bool drained = false;
+
+    // ---- per-ray state, uniform over the group's eight lanes
+    bool alive = false, hit = false, tame = true;
+    unsigned int ray = 0;
+    V3 o = {0, 0, 0}, d = {0, 0, 0};
+    double invDx = 0, invDy = 0, invDz = 0;
+    CullRay cray = {};
+    int mask = 0, e1 = -1, e2 = -1;
+    int sp = 0;                         // stack entries
+    int q = 0, qe = 0;                  // the current leaf's remaining entries items[q .. qe)
+    double lca = 0;                     // its nodeTmin
+    int visit = 0;                      // leaves visited so far (numbers the pending survivors' leaves)
+    int np = 0;                         // pending survivors
+    int cur_visit = -1;                 // replay: the leaf the last replayed survivor belonged to ...
+    bool cur_skip = false;              // ... and whether the reference skipped it (:210)
+    double closestT = kDblMax, bu = 0, bv = 0;
+    int pid = -1;
+    unsigned int nhits = 0, nrays = 0;  // counted in lane 0 of the group
+
+    auto finish = [&]() {
+        if (j == 0) {
+            XEventRec ev;
+            if (hit) {
+                ev.t = closestT; ev.u = bu; ev.v = bv;
+                ev.x = o.x + d.x * closestT; ev.y = o.y + d.y * closestT; ev.z = o.z + d.z * closestT;
+                ev.poly_id = pid;
+                ev.hit = 1;
+                nhits++;
+            } else {
+                set_miss(ev);
+            }
+            store_event_streaming(&io.out[ray], ev);
+        }
+        alive = false;
+        sp = 0; q = 0; qe = 0; np = 0;
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------------ new rays for idle groups
+        {
+            const unsigned long long idle = __ballot(!alive);
+            const int nidle = __popcll(idle) >> 3;
+            if (__builtin_expect(!drained && (nidle >= HARE_K2G_REFILL || nidle == 8), 0)) {
+                bool want = !alive;
+                while (true) {
+                    const unsigned long long wm = __ballot(want);
+                    if (wm == 0) break;
+                    if (cn >= ce) {
+                        unsigned int base = 0;
+                        const unsigned int dyn = (unsigned int)io.ticket_rays;
+                        if (wl == 0) base = atomicAdd(io.work, dyn);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        cn = base + n_static;
+                        if (cn >= n32) { drained = true; break; }
+                        ce = (n32 - cn > dyn) ? cn + dyn : n32;
+                    }
+                    const unsigned int mine = cn + ((unsigned int)__popcll(wm & ((1ull << gshift) - 1ull)) >> 3);   // idle groups in front of this one
+                    const bool got = want && mine < ce;
+                    cn += (unsigned int)__popcll(__ballot(got)) >> 3;
+                    if (got) {
+                        want = false;
+                        ray = mine;
+                        const RayRec r = io.rays[ray];             // one address per group
+                        o.x = r.x; o.y = r.y; o.z = r.z;
+                        d.x = r.dx; d.y = r.dy; d.z = r.dz;
+                        e1 = io.excl1 ? io.excl1[ray] : -1;
+                        e2 = io.excl2 ? io.excl2[ray] : -1;
+                        hit = false; alive = true;
+                        tame = fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300 && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
+                        closestT = kDblMax; pid = -1; bu = 0; bv = 0;
+                        sp = 0; q = 0; qe = 0; np = 0; visit = 0; cur_visit = -1; cur_skip = false;
+                        if (e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {
+                            finish();
+                        } else {
+                            if (j == 0) nrays++;
+                            invDx = fabs(d.x) > 1e-16 ? 1.0 / d.x : 1e16;      // "Octree - alt.cs":165-167
+                            invDy = fabs(d.y) > 1e-16 ? 1.0 / d.y : 1e16;
+                            invDz = fabs(d.z) > 1e-16 ? 1.0 / d.z : 1e16;
+                            mask = ((d.x >= 0 ? 0 : 1) << 2) | ((d.y >= 0 ? 0 : 1) << 1) | (d.z >= 0 ? 0 : 1);
+                            cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
+                            const OctNode& root = g.nodes[0];
+                            double tx0 = (root.bmin[0] - o.x) * invDx, tx1 = (root.bmax[0] - o.x) * invDx;
+                            double ty0 = (root.bmin[1] - o.y) * invDy, ty1 = (root.bmax[1] - o.y) * invDy;
+                            double tz0 = (root.bmin[2] - o.z) * invDz, tz1 = (root.bmax[2] - o.z) * invDz;
+                            if (invDx < 0) { const double s = tx0; tx0 = tx1; tx1 = s; }
+                            if (invDy < 0) { const double s = ty0; ty0 = ty1; ty1 = s; }
+                            if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
+                            const double rmin = omax(omax(tx0, ty0), tz0), rmax = omin(omin(tx1, ty1), tz1);   // :182-183
+                            if (rmax < rmin || rmax < 0) {
+                                finish();                            // :185 (and the identical pop test :207)
+                            } else {
+                                const int rfc = root.first_child;
+                                const bool rleaf = rfc < 0;
+                                if (rleaf && root.item_count == 0) {
+                                    finish();
+                                } else {
+                                    if (j == 0) { sa[0] = rmin; sb[0] = rmax; sw[0] = rleaf ? make_int2(-1 - root.item_start, root.item_count) : make_int2(rfc, 0); }
+                                    sp = 1;
+                                }
+                            }
+                        }
+                    }
+                }
+                lds_sync();
+            }
+            if (__ballot(alive) == 0) {
+                if (drained) break;
+                continue;
+            }
+        }
+
+        // ------------------------------------------------------------------ POP: the next node of every group that has no leaf in hand
+        // The group's lanes look at the top eight entries at once; entries the state prunes (:210) are dropped, the first one it
+        // does not prune is the node (an interior node: phase F below; a leaf: phase L).
+        bool interior = false;
+        int fc = 0;
+        double pa = 0, pb = 0;
+        {
+            const bool popping = alive && q == qe && sp > 0;
+            if (__ballot(popping)) {
+                double ea = 0, eb = 0;
+                int2 ew = make_int2(0, 0);
+                const int e = sp - 1 - j;
+                const bool have = popping && e >= 0;
+                if (have) st_load(e, ea, eb, ew);
+                const bool keep = have && !(hit && closestT <= ea);                       // :210 with the state of the moment
+                const unsigned km = gballot(keep);
+                const int js = km ? __builtin_ctz(km) : 7;
+                const double ta = __shfl(ea, js, W), tb = __shfl(eb, js, W);
+                const int tw0 = __shfl(ew.x, js, W), tw1 = __shfl(ew.y, js, W);
+                if (popping) {
+                    if (km == 0) {
+                        sp = sp > W ? sp - W : 0;                                         // all eight pruned
+                    } else {
+                        sp -= js + 1;
+                        if (tw0 < 0) { q = -1 - tw0; qe = q + tw1; lca = ta; ++visit; }    // a leaf: its list, its nodeTmin
+                        else { interior = true; fc = tw0; pa = ta; pb = tb; }
+                    }
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------ F: the eight children of an interior node, one per lane
+        if (__ballot(interior)) {
+            double ca = 0, cb = 0;
+            int2 cw = make_int2(0, 0);
+            bool push = false;
+            auto fstep = [&](auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                auto mx = [](double a, double b) { return FAST ? __builtin_fmax(a, b) : omax(a, b); };
+                auto mn = [](double a, double b) { return FAST ? __builtin_fmin(a, b) : omin(a, b); };
+                const OctNode& nd = g.nodes[fc + (j ^ mask)];                             // lane k examines order[k] = k ^ mask (:286-306)
+                double tx0 = (nd.bmin[0] - o.x) * invDx, tx1 = (nd.bmax[0] - o.x) * invDx;     // :253-258
+                double ty0 = (nd.bmin[1] - o.y) * invDy, ty1 = (nd.bmax[1] - o.y) * invDy;
+                double tz0 = (nd.bmin[2] - o.z) * invDz, tz1 = (nd.bmax[2] - o.z) * invDz;
+                if (invDx < 0) { const double s = tx0; tx0 = tx1; tx1 = s; }
+                if (invDy < 0) { const double s = ty0; ty0 = ty1; ty1 = s; }
+                if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
+                const double tmn = mx(mx(tx0, ty0), tz0), tmx = mn(mn(tx1, ty1), tz1);    // :265-266
+                push = !(tmx < tmn || tmx < 0 || tmn > pb || tmx < pa);                   // :268
+                ca = mx(tmn, pa);                                                         // :271
+                cb = mn(tmx, pb);
+                const int cfc = nd.first_child;
+                const bool cleaf = cfc < 0;
+                cw = cleaf ? make_int2(-1 - nd.item_start, nd.item_count) : make_int2(cfc, 0);
+                push = push && !(cb < ca || cb < 0);                                     // the pop test :207 is hit-independent: made here
+                push = push && !(cleaf && cw.y == 0);                                    // popping an empty leaf has no effect
+                push = push && !(hit && closestT <= ca);                                 // :210 true now stays true (closestT only falls)
+            };
+            // Rays whose components are all finite and far from overflow never produce a NaN here, so for them Math.Max / Math.Min
+            // are v_max_f64 / v_min_f64 (the sign of a zero result is only ever compared); anything else: NaN-propagating selects
+            const bool all_tame = __ballot(interior && !tame) == 0;
+            if (interior) {
+                if (all_tame) fstep(std::true_type{});
+                else fstep(std::false_type{});
+            }
+            const unsigned pm = gballot(interior && push);
+            if (interior) {
+                if (push) st_store(sp + __builtin_popcount(pm & jlt), ca, cb, cw);           // order[0] lowest ... order[7] on top: popped first
+                sp += __builtin_popcount(pm);
+            }
+            lds_sync();
+        }
+
+        // ------------------------------------------------------------------ L: eight entries of the leaf in hand, pre-culled; survivors noted
+        {
+            const bool scanning = alive && q < qe && np <= kGPend - W;
+            if (__ballot(scanning)) {
+                const int k = q + j;
+                const bool valid = scanning && k < qe;
+                int i = -1;
+                if (valid) i = g.items[k];
+                bool test = valid && i != e1 && i != e2;                                  // :218
+                if (test) test = !cull_test(g, cray, cull_load(g, i));
+                const unsigned sm = gballot(test);
+                if (test) {
+                    const int at = np + __builtin_popcount(sm & jlt);
+                    plca[at] = lca;
+                    ppw[at] = make_int2(i, visit);
+                }
+                if (scanning) {
+                    np += __builtin_popcount(sm);
+                    q = q + W < qe ? q + W : qe;
+                }
+                lds_sync();
+            }
+        }
+
+        // ------------------------------------------------------------------ E: exact tests of the pending survivors, replayed in order
+        {
+            const bool walk_over = alive && sp == 0 && q == qe;                            // nothing left to visit
+            if (walk_over && np == 0) finish();
+            const bool blocked = alive && np > 0 && (walk_over || np > kGPend - W);
+            const int total = __popcll(__ballot(alive && j < np));                         // min(np, 8) summed over the groups
+            if (__ballot(blocked) != 0 || total >= HARE_K2G_EXACT_MIN) {
+                const int take = np < W ? np : W;
+                const bool mine = alive && j < take;
+                double t = kDblMax, u = 0, v = 0, slca = 0;
+                int spoly = -1, svisit = -1;
+                if (mine) {
+                    const int2 w = ppw[j];
+                    spoly = w.x; svisit = w.y; slca = plca[j];
+                    const PolyRec& p = g.polys[spoly];
+                    const double* v3 = (g.quads && g.quads[spoly].nverts == 4) ? g.quads[spoly].v3 : nullptr;
+                    double tt, uu, vv;
+                    if (poly_full(p, v3, o, d, tt, uu, vv) && tt > kTMin) { t = tt; u = uu; v = vv; }      // :224
+                }
+                // replay, in list order, the survivors with a valid t (the others change nothing)
+                unsigned vm = gballot(mine && t < kDblMax);
+                bool ended = false;
+                while (__ballot(vm != 0)) {
+                    const int k = vm ? __builtin_ctz(vm) : 0;
+                    const double tk = __shfl(t, k, W), uk = __shfl(u, k, W), vk = __shfl(v, k, W), lk = __shfl(slca, k, W);
+                    const int pk = __shfl(spoly, k, W), vis = __shfl(svisit, k, W);
+                    if (vm != 0 && !ended) {
+                        if (vis != cur_visit) { cur_visit = vis; cur_skip = hit && closestT <= lk; }      // :210 at that leaf's pop
+                        if (!cur_skip && tk < closestT) {                                                 // :225
+                            closestT = tk; bu = uk; bv = vk; pid = pk; hit = true;
+                            if (closestT <= lk) ended = true;                                             // :233
+                        }
+                    }
+                    vm &= vm - 1u;
+                }
+                if (alive) {
+                    if (ended) {
+                        finish();
+                    } else {
+                        // the survivors beyond the first eight move down
+                        const int rest = np - take;
+                        double mlca = 0;
+                        int2 mw = make_int2(0, 0);
+                        if (j < rest) { mlca = plca[W + j]; mw = ppw[W + j]; }
+                        lds_sync();
+                        if (j < rest) { plca[j] = mlca; ppw[j] = mw; }
+                        np = rest;
+                        if (np == 0 && sp == 0 && q == qe) finish();
+                    }
+                }
+                lds_sync();
+            }
+        }
+    }
+    launch_epilogue(io, nrays, nhits, waves_per_block);
+}
+
+}  // namespace

@@ -167,11 +167,12 @@ HARE_API void hare_scene_destroy(hare_scene *s);
 
 /* Diagnostics and A/B switches of ONE scene, for tests, profiling and tools; production callers never need them.  A scene takes
  * its defaults from the environment ONCE, inside hare_scene_create (HARE_BUILD=host; and, only in a process that opted in with
- * HARE_DEV=1, HARE_VOXEL_KERNEL / HARE_OCTREE_KERNEL = pool|persist, HARE_TICKET, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
+ * HARE_DEV=1, HARE_VOXEL_KERNEL = pool|persist, HARE_OCTREE_KERNEL = group|persist|pool, HARE_TICKET, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
  * HARE_BATCH_CHUNKS, HARE_TUNE): no call reads the environment afterwards.  Options:
  *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
- *   "octree_kernel"   0: the library's rule, 1: hare_octree_persist (K2p), 2: hare_octree_pool (K2q)
+ *   "octree_kernel"   0: the library's rule (K2g), 1: hare_octree_persist (K2p, one lane per ray), 2: hare_octree_pool (K2q),
+ *                     3: hare_octree_group (K2g, eight lanes per ray)
  *   "ticket_rays", "k1p_static_rays" (both voxel kernels), "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
  *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per

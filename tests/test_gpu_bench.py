@@ -12,7 +12,7 @@ import pytest
 import hare_amd as H
 
 pytestmark = pytest.mark.gpu
-OCTREE_KERNEL = "hare_octree_persist"      # what hare_shoot_kernel_name reports for Octree.Shoot batches
+OCTREE_KERNEL = "hare_octree_group"      # what hare_shoot_kernel_name reports for Octree.Shoot batches
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
