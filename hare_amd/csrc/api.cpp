@@ -88,6 +88,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_pool", &m->octree_pool},
         {"hare_octree_tail", &m->octree_tail},
         {"hare_octree_group", &m->octree_group},
+        {"hare_octree_group_tail", &m->octree_group_tail},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
@@ -360,12 +361,21 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
 // finished, which is the rule), so a 65th launch in flight waits for the first instead of sharing its ticket word.  The
 // slot's mutex keeps wait + launch + record together when several host threads launch on one scene.
 // args[1] must point to `io`.
-// `octree_tail_levels` > 0: a K2p launch -- it gets a block of hand-over records and is followed, on the same stream and inside the
-// slot's lock, by the cooperative tail kernel K2t (octree_coop.hip).
-// `group_spill_entries` > 0: a K2g launch (octree_group.hip) -- it gets a block of the same ring for the stack entries its groups
-// cannot keep in LDS (24 bytes x entries per group of eight lanes); no second kernel.
+// Octree launches get a block of the scene's octree scratch ring (one block per launch in flight, event-ordered):
+//   tail_levels > 0     a K2p launch: hand-over records for the rays its waves give up (tail_max per wave), followed on the same
+//                       stream, inside the slot's lock, by the tail kernel -- K2t (octree_coop.hip: a wave per ray, the last few
+//                       rays of a wave) or K2g-tail (octree_group.hip: eight lanes per ray, ALL the rays a wave still holds when
+//                       the tickets run dry)
+//   spill_entries > 0   K2g's stack entries beyond what LDS holds (24 bytes x entries per group of eight lanes), for the K2g
+//                       launch itself or for the K2g-tail behind K2p
+struct OctScratch {
+    int tail_levels = 0;
+    int tail_max = 0, tail_patience = 0;
+    bool group_tail = false;
+    int spill_entries = 0;
+};
 int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, ShootIO& io,
-                   void** args, bool coop_tail = false, int octree_tail_levels = 0, int group_spill_entries = 0)
+                   void** args, bool coop_tail = false, const OctScratch& oc = OctScratch())
 {
     const unsigned idx = s.work_slot.fetch_add(1) % kLaunchSlots;
     Scene::LaunchSlot& sl = s.slots[idx];
@@ -374,15 +384,23 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     io.coop_tail = (coop_tail && s.opt.coop_tail) ? 1 : 0;
     io.wide_drain = s.opt.wide_drain ? 1 : 0;
     io.oct_tail = nullptr;
-    const bool with_k2t = octree_tail_levels > 0 && s.opt.coop_tail && s.module->octree_tail != nullptr;
-    const bool with_spill = group_spill_entries > 0;
+    io.oct_spill = nullptr;
+    io.oct_spill_cap = 0;
+    const hipFunction_t tail_fn = oc.group_tail ? s.module->octree_group_tail : s.module->octree_tail;
+    const bool with_tail = oc.tail_levels > 0 && s.opt.coop_tail && tail_fn != nullptr;
+    const unsigned cus = (unsigned)std::max(1, s.module->cu_count);
+    // the tail kernel's grid: K2t a wave per ray of a typical hand-over; K2g-tail a chip full of groups (waves without a record end at once)
+    const unsigned tgrid = !with_tail ? 0u : (oc.group_tail ? cus * (unsigned)HARE_K2G_WAVES_PER_EU : std::max(1u, std::min(grid, 4u * cus)));
+    const unsigned spill_groups = oc.spill_entries <= 0 ? 0u : (with_tail && oc.group_tail ? tgrid * 4u * 8u : grid * (block / 64u) * 8u);
+    const bool with_spill = spill_groups > 0 && (!oc.tail_levels || (with_tail && oc.group_tail));
     std::unique_lock<std::mutex> tail_lk(s.oct_tail_mu, std::defer_lock);
     int tail_ring = -1;
-    if (with_k2t || with_spill) {
-        const size_t stride = with_spill ? (size_t)group_spill_entries * 24u
-                                         : (((size_t)kOctTailHead + 20u * (size_t)octree_tail_levels + 15u) & ~(size_t)15u);
-        const size_t need = (size_t)grid * (block / 64u) * (with_spill ? (size_t)8 : (size_t)kOctTailMax) * stride;
-        tail_lk.lock();                      // held until the launch (and K2t behind it) is enqueued and the block's event recorded
+    if (with_tail || with_spill) {
+        const size_t stride = !with_tail ? 0 : (((size_t)kOctTailHead + 20u * (size_t)oc.tail_levels + 15u) & ~(size_t)15u);
+        const size_t rec_bytes = !with_tail ? 0 : (((size_t)grid * (block / 64u) * (size_t)oc.tail_max * stride + 255u) & ~(size_t)255u);
+        const size_t spill_bytes = with_spill ? (size_t)spill_groups * (size_t)oc.spill_entries * 24u : 0;
+        const size_t need = rec_bytes + spill_bytes;
+        tail_lk.lock();                      // held until the launch (and the tail behind it) is enqueued and the block's event recorded
         if (need > s.oct_tail_block_bytes) {
             // larger blocks (first use, or a deeper tree since): launches in flight may still use the old ones
             if (s.d_oct_tail) {
@@ -397,15 +415,24 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
         tail_ring = (int)(s.oct_tail_seq++ % (unsigned)Scene::kOctTailRing);
         if (!s.oct_tail_ev[tail_ring]) HIP_TRY(H->EventCreateWithFlags(&s.oct_tail_ev[tail_ring], hipEventDisableTiming));
         if (s.oct_tail_used[tail_ring]) HIP_TRY(H->StreamWaitEvent(st, s.oct_tail_ev[tail_ring], 0));
-        io.oct_tail = static_cast<unsigned char*>(s.d_oct_tail) + (size_t)tail_ring * s.oct_tail_block_bytes;
-        io.oct_tail_stride = (int32_t)stride;
-        io.oct_tail_levels = with_spill ? group_spill_entries : octree_tail_levels;
+        unsigned char* blockp = static_cast<unsigned char*>(s.d_oct_tail) + (size_t)tail_ring * s.oct_tail_block_bytes;
+        if (with_tail) {
+            io.oct_tail = blockp;
+            io.oct_tail_stride = (int32_t)stride;
+            io.oct_tail_levels = oc.tail_levels;
+            io.oct_tail_max = oc.tail_max;
+            io.oct_tail_patience = oc.tail_patience;
+        }
+        if (with_spill) {
+            io.oct_spill = blockp + rec_bytes;
+            io.oct_spill_cap = oc.spill_entries;
+        }
     }
     if (!sl.ev) HIP_TRY(H->EventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     if (sl.used) HIP_TRY(H->StreamWaitEvent(st, sl.ev, 0));
     int rc = launch(H, f, grid, block, lds, st, args);
     if (rc) return rc;
-    // From here on a kernel is enqueued that will use the slot (and the hand-over block).  If a later step fails, the slot must
+    // From here on a kernel is enqueued that will use the slot (and the scratch block).  If a later step fails, the slot must
     // not come round again in the state that kernel leaves it in with nothing to wait for: drain the stream, put the slot back to
     // the all-zero state the kernels start from, and forget the events that were never recorded.
     auto fail_after_launch = [&](int code) {
@@ -418,15 +445,14 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
         set_error(msg);
         return code;
     };
-    if (with_k2t) {
-        // K2t (octree_coop.hip): HARE_K2T_GROUP = 64, a whole wave per handed-over ray, four rays per workgroup; it reads the count
-        // K2p left behind.  LDS: one 20-byte frame per level for each of the workgroup's four rays
-        const unsigned tgrid = std::max(1u, std::min(grid, 4u * (unsigned)std::max(1, s.module->cu_count)));
-        rc = launch(H, s.module->octree_tail, tgrid, 256, kOctTailGroupsPerBlock * 20u * (unsigned)octree_tail_levels, st, args);
+    if (with_tail) {
+        // the tail reads the count K2p left behind.  K2t (HARE_K2T_GROUP = 64): a whole wave per handed-over ray, four rays per workgroup,
+        // LDS one 20-byte frame per level for each; K2g-tail: the groups' stacks and pending lists, as K2g
+        const unsigned tlds = oc.group_tail ? 4u * (unsigned)kGroupWaveBytes : kOctTailGroupsPerBlock * 20u * (unsigned)oc.tail_levels;
+        rc = launch(H, tail_fn, tgrid, 256, tlds, st, args);
         if (rc) return fail_after_launch(rc);
-        if (hipError_t e = H->EventRecord(s.oct_tail_ev[tail_ring], st); e != hipSuccess) return fail_after_launch(hip_fail(H, e, "hipEventRecord"));
-        s.oct_tail_used[tail_ring] = true;
-    } else if (with_spill) {
+    }
+    if (tail_ring >= 0) {
         if (hipError_t e = H->EventRecord(s.oct_tail_ev[tail_ring], st); e != hipSuccess) return fail_after_launch(hip_fail(H, e, "hipEventRecord"));
         s.oct_tail_used[tail_ring] = true;
     }
@@ -455,6 +481,9 @@ void read_env_options(SceneOptions& o)
     if (!o.dev) return;            // everything below is a developer override: ignored unless the process opted in
     if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
     if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : 0));
+    if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
+    if (const char* t = getenv("HARE_K2P_TAIL_MAX")) o.k2p_tail_max = atoi(t);
+    if (const char* t = getenv("HARE_K2P_TAIL_PATIENCE")) o.k2p_tail_patience = atoi(t);
     if (const char* t = getenv("HARE_TICKET")) o.ticket_rays = atoi(t);
     if (const char* t = getenv("HARE_K1P_STATIC_RAYS")) o.k1p_static_rays = atoi(t);
     if (const char* t = getenv("HARE_K2P_STATIC_RAYS")) o.k2p_static_rays = atoi(t);
@@ -604,8 +633,16 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             const bool pool_wanted = s.opt.octree_kernel == 2 || (s.opt.octree_kernel == 0 && kOctreePoolDefault && n >= 65536);
             if (pool_wanted && have(&DeviceModule::octree_pool)) { pick(Kern::OctPool, "hare_octree_pool", &DeviceModule::octree_pool); return c; }
             // K2g (octree_group.hip): eight lanes per ray -- the production kernel for closest-hit batches of every size
-            const bool group_wanted = s.opt.octree_kernel == 3 || s.opt.octree_kernel == 0;
-            if (group_wanted && have(&DeviceModule::octree_group)) { pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group); return c; }
+            // Octree.Shoot has two production kernels (measured on MI355X, hall, 8 levels; profiles/r04_experiments/k2_crossover.log):
+            //   K2g (octree_group.hip, eight lanes per ray): a ray lives < 100 us, so a launch has next to no drain -- 2.1x K2p at 65k rays,
+            //       1.4x at 262k, 1.1x at 524k -- but it spends 1.5x K2p's instructions per ray: steady state 330 Mrays/s against 560;
+            //   K2p (one lane per ray) + K2g-tail from 655 360 rays: 655k 298 / 299 (K2p+tail / K2g), 786k 342 / 306, 1M 396 / 312, 4M 563 / 331.
+            // Both thresholds scale with the CU count.
+            const bool fits_p = (unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist);
+            const bool group_ok = have(&DeviceModule::octree_group);
+            const int64_t group_below = (int64_t)cus * 2560;          // 655 360 rays on the 256-CU part
+            const bool group_wanted = s.opt.octree_kernel == 3 || (s.opt.octree_kernel == 0 && (n < group_below || !fits_p));
+            if (group_wanted && group_ok) { pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group); return c; }
             if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist)) {
                 pick(Kern::OctPersist, "hare_octree_persist", &DeviceModule::octree_persist);
                 return c;
@@ -862,37 +899,71 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (rc == HARE_OK) HIP_TRY(H->EventRecord(s.oct_scratch_ev[ring], st));
             return rc;
         }
-        void* args[] = {&g, &io};
-        if (kc.k == Kern::OctGroup) {
-            // K2g: workgroups of four waves, eight rays per wave; LDS = the groups' stacks and pending lists (hare_device.h).  A ray's
-            // stack can hold 7 x levels + 8 entries (the reference's LIFO, "Octree - alt.cs":268-272); what LDS does not hold spills
+        // K2g (octree_group.hip) on rays [off, off + m): workgroups of four waves, eight rays per wave; LDS = the groups' stacks and
+        // pending lists (hare_device.h).  A ray's stack can hold 7 x levels + 8 entries (the reference's LIFO, "Octree - alt.cs":268-272);
+        // what LDS does not hold spills to a block of the scene's octree scratch ring
+        auto launch_group = [&](int64_t off, int64_t m, hipStream_t stream) -> int {
+            ShootIO sub = io;
+            sub.rays = io.rays + off;
+            sub.out = io.out + off;
+            if (io.excl1) sub.excl1 = io.excl1 + off;
+            if (io.excl2) sub.excl2 = io.excl2 + off;
+            sub.n = m;
             const unsigned glds = 4u * (unsigned)kGroupWaveBytes;
             unsigned per_cu = std::min((unsigned)HARE_K2G_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / glds)));
             unsigned pgrid = cus * per_cu;
-            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 7) / 8 + 3) / 4);            // a wave per eight rays at least
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 7) / 8 + 3) / 4);            // a wave per eight rays at least
             if (pgrid == 0) pgrid = 1;
-            io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 8;
+            sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 8;    // swept 8 / 16 / 32 / 64: 8 (1M rays), flat at 4M
             // static first chunk per wave: what the batch has for every wave, at most 32 rays (four rounds of eight), at least 8
-            const int64_t per_wave = n / ((int64_t)pgrid * 4);
-            io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(32, per_wave / 2 / 8 * 8));
-            if (s.opt.k2p_static_rays > 0) io.static_rays = std::max(8, std::min(256, s.opt.k2p_static_rays / 8 * 8));   // developer sweeps
-            const int spill = std::max(0, 7 * g.max_depth + 8 - kGroupStack);
-            return launch_on_slot(s, H, kc.f, pgrid, 256, glds, st, io, args, false, 0, spill);
-        }
-        if (kc.k == Kern::OctPersist || kc.k == Kern::OctOccl) {
+            const int64_t per_wave = m / ((int64_t)pgrid * 4);
+            sub.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(32, per_wave / 2 / 8 * 8));
+            if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(8, std::min(256, s.opt.k2p_static_rays / 8 * 8));   // developer sweeps
+            OctScratch oc;
+            oc.spill_entries = std::max(0, 7 * g.max_depth + 8 - kGroupStack);
+            void* a[] = {&g, &sub};
+            return launch_on_slot(s, H, M.octree_group, pgrid, 256, glds, stream, sub, a, false, oc);
+        };
+        // K2p (+ K2t behind it) or the occlusion build on rays [off, off + m)
+        auto launch_persist = [&](hipFunction_t f, bool closest_hit, int64_t off, int64_t m, hipStream_t stream) -> int {
+            ShootIO sub = io;
+            sub.rays = io.rays + off;
+            if (io.out) sub.out = io.out + off;
+            if (io.excl1) sub.excl1 = io.excl1 + off;
+            if (io.excl2) sub.excl2 = io.excl2 + off;
+            if (io.tmax) sub.tmax = io.tmax + off;
+            if (io.occluded) sub.occluded = io.occluded + off;
+            sub.n = m;
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
             const unsigned plds = (unsigned)g.max_depth * 256u * 20u;   // 20 bytes x levels x 256 lanes per workgroup (interval + child word)
             unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = cus * per_cu;
-            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
-            io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 32;   // an octree ray costs ~10x a voxel ray: ticket atomics never bind
-            io.static_rays = static_chunk_rays(n, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
-            if (s.opt.k2p_static_rays > 0) io.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
-            // the closest-hit kernel hands its last rays to the cooperative tail kernel (the occlusion build keeps them)
-            return launch_on_slot(s, H, kc.f, pgrid, 256, plds, st, io, args, false, kc.k == Kern::OctPersist ? g.max_depth : 0);
-        }
+            sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 32;   // an octree ray costs ~10x a voxel ray: ticket atomics never bind
+            sub.static_rays = static_chunk_rays(m, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
+            if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
+            void* a[] = {&g, &sub};
+            // The closest-hit kernel hands rays to a tail kernel (the occlusion build keeps them).  Rule: K2g-tail takes EVERY ray a wave
+            // still walks when the tickets run dry (option "octree_tail" 2, the default); K2t takes a wave's last sixteen after 64 rounds (1)
+            OctScratch oc;
+            if (closest_hit && s.opt.octree_tail != 0) {
+                oc.tail_levels = g.max_depth;
+                oc.group_tail = s.opt.octree_tail == 2 && M.octree_group_tail != nullptr;
+                oc.tail_max = oc.group_tail ? 64 : kOctTailMax;
+                // K2g-tail: every ray the wave still holds 32 rounds after its tickets ran dry (swept: (64, 0) 345 Mrays/s, (64, 8) 367,
+                // (64, 24..48) 391-396, (64, 64) 377, (64, 128) 347; (24..40, x) the same within 1 %; K2t (16, 64) 384)
+                oc.tail_patience = oc.group_tail ? 32 : HARE_K2P_TAIL_PATIENCE;
+                if (s.opt.k2p_tail_max > 0) oc.tail_max = std::min(64, s.opt.k2p_tail_max);          // developer sweeps
+                if (s.opt.k2p_tail_patience >= 0) oc.tail_patience = s.opt.k2p_tail_patience;
+                if (oc.group_tail) oc.spill_entries = std::max(0, 7 * g.max_depth + 8 - kGroupStack);
+            }
+            return launch_on_slot(s, H, f, pgrid, 256, plds, stream, sub, a, false, oc);
+        };
+        if (kc.k == Kern::OctGroup) return launch_group(0, n, st);
+        if (kc.k == Kern::OctPersist || kc.k == Kern::OctOccl) return launch_persist(kc.f, kc.k == Kern::OctPersist, 0, n, st);
+        void* args[] = {&g, &io};
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
         const unsigned levels = (unsigned)g.max_depth;
         unsigned ob = 256;
@@ -1416,8 +1487,10 @@ static int batch_impl(hare_scene* s, int32_t kind, int32_t top_index, int64_t n,
     // host-buffer callers get the reference's meaning of poly_origin: an index that matches no polygon (any negative
     // value) excludes nothing.  Only the device-resident bounce loop (hare_reflect_device + hare_shoot_device) may
     // retire rays, so the retire flag never passes here, nor do developer bits.
-    // (Developer bits write past the 64-byte counter block they are given: here that block is one of 16 in a staging array.)
-    flags = sanitize_flags(*s, flags) & ~HARE_SHOOT_RETIRED_RAYS & ~0xF000u;
+    // (The developer modes 0x1000 / 0x2000 / 0x4000 write past the 64-byte counter block they are given: here that block is one of 16
+    // in a staging array, so they never pass.  The cull audit, 0x8000, stays inside the block -- words 5..7 -- and is what
+    // tests/test_gpu_parity.py::test_fp32_cull_never_rejects_a_hit runs through this call on a scene with the `dev` option.)
+    flags = sanitize_flags(*s, flags) & ~HARE_SHOOT_RETIRED_RAYS & ~0x7000u;
     if ((flags & HARE_SHOOT_SLIM_EVENTS) && (flags & HARE_SHOOT_WRITEBACK_ORIGIN) && out) {
         // a slim record of a moved ray (hit == 2) holds t from the MOVED origin and hare_expand_events redoes the move from the
         // ORIGINAL one; with the write-back the caller's rays[] would already hold the moved origins and the rebuilt t would
@@ -1760,6 +1833,9 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"build_host", &SceneOptions::build_host, 0, 1},
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
         {"octree_kernel", &SceneOptions::octree_kernel, 0, 3},
+        {"octree_tail", &SceneOptions::octree_tail, 0, 2},
+        {"k2p_tail_max", &SceneOptions::k2p_tail_max, 0, 64},
+        {"k2p_tail_patience", &SceneOptions::k2p_tail_patience, -1, 100000},
         {"ticket_rays", &SceneOptions::ticket_rays, 0, 4096},
         {"k1p_static_rays", &SceneOptions::k1p_static_rays, 0, 1024},
         {"k2p_static_rays", &SceneOptions::k2p_static_rays, 0, 256},

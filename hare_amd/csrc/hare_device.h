@@ -289,6 +289,9 @@ constexpr int kOctTailHead = 64;
                                   // (16, 64) 2.69, (16, 96) 2.95, (32, 160) 3.07; without the hand-over 2.94
 #endif
 constexpr int kOctTailMax = HARE_K2P_TAIL_MAX;
+#ifndef HARE_K2P_TAIL_PATIENCE
+#define HARE_K2P_TAIL_PATIENCE 64
+#endif
 #ifndef HARE_K2T_GROUP
 #define HARE_K2T_GROUP 64         // K2t: lanes per handed-over ray: 64 = a whole wave (8 / 16 / 32: measured, slower -- the groups of a wave diverge)
 #endif
@@ -327,9 +330,13 @@ struct ShootIO {
     int32_t* occluded;         // nullable: n flags
     int32_t coop_tail;         // 1: a drained wave traces its last rays cooperatively (voxel_coop.hip); 0: as lanes of the pool to the end
     int32_t wide_drain;        // 1: K1q spreads a ray's candidates / the voxels ahead of it over several lanes once the tickets are dry and few rays are left
-    unsigned char* oct_tail;   // K2p / K2t: this launch's hand-over records (waves of the K2p grid x kOctTailMax), null = every lane finishes its own
+    unsigned char* oct_tail;   // K2p -> K2t / K2g-tail: this launch's hand-over records (waves of the K2p grid x oct_tail_max), null = every lane finishes its own
     int32_t oct_tail_stride;   // bytes per record
     int32_t oct_tail_levels;   // frames per record (= the levels K2p keeps in LDS)
+    int32_t oct_tail_max;      // K2p: a drained wave hands its rays over once at most this many are alive (64: all of them, at once) ...
+    int32_t oct_tail_patience; // ... and they have outlived the rest of the batch by this many rounds
+    unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
+    int32_t oct_spill_cap;
 };
 
 }  // namespace hare

@@ -762,9 +762,6 @@ __device__ __forceinline__ double omin(double a, double b) { return (a < b || a 
 // t_max.  The reference pops the FAR children first and returns early as soon as a hit lies in front of the current leaf's
 // entry ("Octree - alt.cs":233), so a far leaf can end the query with a hit beyond t_max (not occluded) that a
 // walk without that leaf would replace by a nearer one (occluded): the flag would differ from the reference's closest hit.
-#ifndef HARE_K2P_TAIL_PATIENCE
-#define HARE_K2P_TAIL_PATIENCE 64
-#endif
 template <bool OCC>
 __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
 {
@@ -973,7 +970,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             // tickets dry and down to the last few rays, which have outlived the rest of the batch by HARE_K2P_TAIL_PATIENCE rounds:
             // they go to the cooperative tail kernel (octree_coop.hip), this wave ends
             if (!OCC && drained && io.oct_tail != nullptr) {
-                if (__popcll(am) <= kOctTailMax && tail_rounds >= HARE_K2P_TAIL_PATIENCE) break;
+                if (__popcll(am) <= io.oct_tail_max && tail_rounds >= io.oct_tail_patience) break;
                 ++tail_rounds;
             }
         }
@@ -1456,5 +1453,7 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 #include "octree_pool.hip"
 #include "octree_group.hip"
 // K2g: Octree.Shoot, eight lanes per ray (octree_group.hip) -- the production kernel of the octree path
-extern "C" __global__ __launch_bounds__(256, HARE_K2G_WAVES_PER_EU) void hare_octree_group(hare::OctreeArgs g, hare::ShootIO io) { octree_group_body(g, io); }
+extern "C" __global__ __launch_bounds__(256, HARE_K2G_WAVES_PER_EU) void hare_octree_group(hare::OctreeArgs g, hare::ShootIO io) { octree_group_body<false>(g, io); }
+// K2g as the tail of K2p: the rays K2p's waves were still walking when the tickets ran dry, continued from their walk state
+extern "C" __global__ __launch_bounds__(256, HARE_K2G_WAVES_PER_EU) void hare_octree_group_tail(hare::OctreeArgs g, hare::ShootIO io) { octree_group_body<true>(g, io); }
 #include "build_kernels.hip"

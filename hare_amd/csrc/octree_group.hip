@@ -45,6 +45,13 @@ constexpr int kGPend = kGroupPend;                                // pending sur
 constexpr int kGGroupBytes = kGroupBytes;
 constexpr int kGWaveBytes = kGroupWaveBytes;
 
+// TAIL = false: the rays of a batch (static first chunk per wave, then tickets).
+// TAIL = true (`hare_octree_group_tail`, launched behind K2p on its stream): the rays K2p's waves handed over when the tickets ran dry
+// (OctTailRec + frames, kernels.hip) -- ALL the rays a K2p wave was still walking, not only its last few: as lanes of K2p they would
+// take the life of a ray, ~600 us, to finish at falling occupancy; here each gets eight lanes and they are done in a third of that.
+// A K2p frame (first_child, children still to pop, interval) becomes a stack entry whose eight-bit child mask restricts the F phase
+// to those children; frames go on the stack bottom-up, so that the deepest frame's children are popped first, as K2p would have.
+template <bool TAIL>
 __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -58,13 +65,13 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
     unsigned char* const gl = lds + (size_t)wave * kGWaveBytes + (size_t)(wl >> 3) * kGGroupBytes;
     double* const sa = reinterpret_cast<double*>(gl);             // [kGStack] clamped tmin of the entry's node
     double* const sb = sa + kGStack;                               // [kGStack] clamped tmax
-    int2* const sw = reinterpret_cast<int2*>(sb + kGStack);        // [kGStack] interior: {first_child, 0}; leaf: {-1 - item_start, item_count}
+    int2* const sw = reinterpret_cast<int2*>(sb + kGStack);        // [kGStack] interior: {first_child, mask of children to examine}; leaf: {-1 - item_start, item_count}
     double* const plca = reinterpret_cast<double*>(sw + kGStack);  // [kGPend] pending survivor: its leaf's nodeTmin
     int2* const ppw = reinterpret_cast<int2*>(plca + kGPend);      // [kGPend] {polygon, leaf visit number}
     // entries kGStack.. of this group's stack: its block of the launch's spill area (sized by the host for 7 * levels + 8 entries)
-    const int spill_cap = io.oct_tail_levels;                      // entries per group in the spill block
-    unsigned char* const spill = io.oct_tail == nullptr ? nullptr :
-        io.oct_tail + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 8u + (size_t)(wl >> 3)) * (size_t)spill_cap * 24u;
+    const int spill_cap = io.oct_spill_cap;                        // entries per group in the spill block
+    unsigned char* const spill = io.oct_spill == nullptr ? nullptr :
+        io.oct_spill + ((size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 8u + (size_t)(wl >> 3)) * (size_t)spill_cap * 24u;
     auto st_store = [&](int e, double a, double b, int2 w) {
         if (e < kGStack) { sa[e] = a; sb[e] = b; sw[e] = w; }
         else {
@@ -95,6 +102,8 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
     if (cn > n32) cn = n32;
     if (ce > n32) ce = n32;
     bool drained = false;
+    LaunchSlotMem* const sm = reinterpret_cast<LaunchSlotMem*>(io.work);
+    const unsigned tail_count = TAIL ? sm->oct_tail_count : 0u;   // final: K2p has ended (stream order)
 
     // ---- per-ray state, uniform over the group's eight lanes
     bool alive = false, hit = false, tame = true;
@@ -113,6 +122,12 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
     double closestT = kDblMax, bu = 0, bv = 0;
     int pid = -1;
     unsigned int nhits = 0, nrays = 0;  // counted in lane 0 of the group
+#ifdef HARE_K2G_STATS                   // developer build: what an iteration of the loop is made of (tools/k2g_stats.py); lane 0 counts
+    unsigned long long st_iter = 0, st_f = 0, st_fg = 0, st_l = 0, st_lg = 0, st_e = 0, st_el = 0, st_pop = 0, st_popg = 0, st_ent = 0, st_alive = 0, st_valid = 0;
+#define K2G_STAT(x) x
+#else
+#define K2G_STAT(x)
+#endif
 
     auto finish = [&]() {
         if (j == 0) {
@@ -142,7 +157,17 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                 while (true) {
                     const unsigned long long wm = __ballot(want);
                     if (wm == 0) break;
-                    if (cn >= ce) {
+                    if (TAIL) {
+                        // one draw for all the groups that want a record
+                        const unsigned int k = (unsigned int)__popcll(wm) >> 3;
+                        unsigned int base = 0;
+                        if (wl == 0) base = atomicAdd(&sm->oct_tail_next, k);
+                        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                        cn = base < tail_count ? base : tail_count;
+                        ce = base + k < tail_count ? base + k : tail_count;
+                        if (cn >= ce) { drained = true; break; }
+                        if (ce - cn < k) drained = true;              // the list ends inside this draw
+                    } else if (cn >= ce) {
                         unsigned int base = 0;
                         const unsigned int dyn = (unsigned int)io.ticket_rays;
                         if (wl == 0) base = atomicAdd(io.work, dyn);
@@ -154,9 +179,16 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                     const unsigned int mine = cn + ((unsigned int)__popcll(wm & ((1ull << gshift) - 1ull)) >> 3);   // idle groups in front of this one
                     const bool got = want && mine < ce;
                     cn += (unsigned int)__popcll(__ballot(got)) >> 3;
+                    if (TAIL && !got) want = false;                    // no record left for this group
+                    const unsigned char* trec = nullptr;
+                    OctTailRec th = {};
+                    if (TAIL && got) {
+                        trec = io.oct_tail + (size_t)mine * (size_t)io.oct_tail_stride;
+                        th = *reinterpret_cast<const OctTailRec*>(trec);       // one address per group
+                    }
                     if (got) {
                         want = false;
-                        ray = mine;
+                        ray = TAIL ? th.ray : mine;
                         const RayRec r = io.rays[ray];             // one address per group
                         o.x = r.x; o.y = r.y; o.z = r.z;
                         d.x = r.dx; d.y = r.dy; d.z = r.dz;
@@ -166,15 +198,35 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                         tame = fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300 && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
                         closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                         sp = 0; q = 0; qe = 0; np = 0; visit = 0; cur_visit = -1; cur_skip = false;
-                        if (e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {
+                        if (!TAIL && e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {
                             finish();
                         } else {
-                            if (j == 0) nrays++;
+                            if (!TAIL && j == 0) nrays++;          // a handed-over ray was counted by K2p when it set it up
                             invDx = fabs(d.x) > 1e-16 ? 1.0 / d.x : 1e16;      // "Octree - alt.cs":165-167
                             invDy = fabs(d.y) > 1e-16 ? 1.0 / d.y : 1e16;
                             invDz = fabs(d.z) > 1e-16 ? 1.0 / d.z : 1e16;
                             mask = ((d.x >= 0 ? 0 : 1) << 2) | ((d.y >= 0 ? 0 : 1) << 1) | (d.z >= 0 ? 0 : 1);
                             cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
+                            if (TAIL) {
+                                // the walk state K2p left: the hit so far, the leaf in hand, the frames bottom-up
+                                closestT = th.closestT; bu = th.bu; bv = th.bv; pid = th.pid; hit = th.hit != 0;
+                                q = th.q; qe = th.qe; lca = th.leaf_ca;
+                                if (q < qe) visit = 1;
+                                const int levels = io.oct_tail_levels;
+                                const double* ra = reinterpret_cast<const double*>(trec + kOctTailHead);
+                                const double* rb = ra + levels;
+                                const int* rk = reinterpret_cast<const int*>(rb + levels);
+                                for (int base = 0; base <= th.lvl; base += W) {
+                                    const int k = base + j;
+                                    int pk = 0;
+                                    double fa_ = 0, fb_ = 0;
+                                    if (k <= th.lvl) { pk = rk[k]; fa_ = ra[k]; fb_ = rb[k]; }
+                                    const bool open = (pk & 255) != 0;                        // children still to pop
+                                    const unsigned om = gballot(open);
+                                    if (open) st_store(sp + __builtin_popcount(om & jlt), fa_, fb_, make_int2((int)((unsigned)pk >> 8), pk & 255));
+                                    sp += __builtin_popcount(om);
+                                }
+                            } else {
                             const OctNode& root = g.nodes[0];
                             double tx0 = (root.bmin[0] - o.x) * invDx, tx1 = (root.bmax[0] - o.x) * invDx;
                             double ty0 = (root.bmin[1] - o.y) * invDy, ty1 = (root.bmax[1] - o.y) * invDy;
@@ -191,9 +243,10 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                                 if (rleaf && root.item_count == 0) {
                                     finish();
                                 } else {
-                                    if (j == 0) { sa[0] = rmin; sb[0] = rmax; sw[0] = rleaf ? make_int2(-1 - root.item_start, root.item_count) : make_int2(rfc, 0); }
+                                    if (j == 0) { sa[0] = rmin; sb[0] = rmax; sw[0] = rleaf ? make_int2(-1 - root.item_start, root.item_count) : make_int2(rfc, 255); }
                                     sp = 1;
                                 }
+                            }
                             }
                         }
                     }
@@ -206,15 +259,22 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
             }
         }
 
+#ifndef HARE_K2G_REPS
+#define HARE_K2G_REPS 3            // POP / F / L rounds per pass of the loop: the refill test, the exact-phase test and the loop itself are paid once per pass
+#endif
+#pragma unroll 1
+        for (int rep = 0; rep < HARE_K2G_REPS; ++rep) {
         // ------------------------------------------------------------------ POP: the next node of every group that has no leaf in hand
         // The group's lanes look at the top eight entries at once; entries the state prunes (:210) are dropped, the first one it
         // does not prune is the node (an interior node: phase F below; a leaf: phase L).
         bool interior = false;
-        int fc = 0;
+        int fc = 0, cmask = 255;
         double pa = 0, pb = 0;
+        K2G_STAT(st_iter++; st_alive += __popcll(__ballot(alive)) >> 3;)
         {
             const bool popping = alive && q == qe && sp > 0;
             if (__ballot(popping)) {
+                K2G_STAT(st_pop++; st_popg += __popcll(__ballot(popping)) >> 3;)
                 double ea = 0, eb = 0;
                 int2 ew = make_int2(0, 0);
                 const int e = sp - 1 - j;
@@ -231,7 +291,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                     } else {
                         sp -= js + 1;
                         if (tw0 < 0) { q = -1 - tw0; qe = q + tw1; lca = ta; ++visit; }    // a leaf: its list, its nodeTmin
-                        else { interior = true; fc = tw0; pa = ta; pb = tb; }
+                        else { interior = true; fc = tw0; cmask = tw1; pa = ta; pb = tb; }
                     }
                 }
             }
@@ -239,6 +299,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
 
         // ------------------------------------------------------------------ F: the eight children of an interior node, one per lane
         if (__ballot(interior)) {
+            K2G_STAT(st_f++; st_fg += __popcll(__ballot(interior)) >> 3;)
             double ca = 0, cb = 0;
             int2 cw = make_int2(0, 0);
             bool push = false;
@@ -259,7 +320,8 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                 cb = mn(tmx, pb);
                 const int cfc = nd.first_child;
                 const bool cleaf = cfc < 0;
-                cw = cleaf ? make_int2(-1 - nd.item_start, nd.item_count) : make_int2(cfc, 0);
+                cw = cleaf ? make_int2(-1 - nd.item_start, nd.item_count) : make_int2(cfc, 255);
+                push = push && ((cmask >> j) & 1) != 0;                                 // a frame K2p had opened: only the children it had not popped yet
                 push = push && !(cb < ca || cb < 0);                                     // the pop test :207 is hit-independent: made here
                 push = push && !(cleaf && cw.y == 0);                                    // popping an empty leaf has no effect
                 push = push && !(hit && closestT <= ca);                                 // :210 true now stays true (closestT only falls)
@@ -285,6 +347,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
             if (__ballot(scanning)) {
                 const int k = q + j;
                 const bool valid = scanning && k < qe;
+                K2G_STAT(st_l++; st_lg += __popcll(__ballot(scanning)) >> 3; st_ent += __popcll(__ballot(valid));)
                 int i = -1;
                 if (valid) i = g.items[k];
                 bool test = valid && i != e1 && i != e2;                                  // :218
@@ -303,6 +366,8 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
             }
         }
 
+        }
+
         // ------------------------------------------------------------------ E: exact tests of the pending survivors, replayed in order
         {
             const bool walk_over = alive && sp == 0 && q == qe;                            // nothing left to visit
@@ -312,6 +377,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
             if (__ballot(blocked) != 0 || total >= HARE_K2G_EXACT_MIN) {
                 const int take = np < W ? np : W;
                 const bool mine = alive && j < take;
+                K2G_STAT(st_e++; st_el += __popcll(__ballot(mine));)
                 double t = kDblMax, u = 0, v = 0, slca = 0;
                 int spoly = -1, svisit = -1;
                 if (mine) {
@@ -324,6 +390,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                 }
                 // replay, in list order, the survivors with a valid t (the others change nothing)
                 unsigned vm = gballot(mine && t < kDblMax);
+                K2G_STAT(st_valid += __popcll(__ballot(mine && t < kDblMax));)
                 bool ended = false;
                 while (__ballot(vm != 0)) {
                     const int k = vm ? __builtin_ctz(vm) : 0;
@@ -356,6 +423,27 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                 lds_sync();
             }
         }
+    }
+#ifdef HARE_K2G_STATS
+    if (wl == 0 && io.prof) {           // 12 words behind the counters block (the tool sizes the buffer)
+        const unsigned long long v[12] = {st_iter, st_alive, st_pop, st_popg, st_f, st_fg, st_l, st_lg, st_ent, st_e, st_el, st_valid};
+        for (int k = 0; k < 12; ++k) atomicAdd(&io.prof[k], v[k]);
+    }
+#endif
+    if (TAIL) {
+        // the rays were counted by K2p when it set them up; their hits are counted here.  The last wave of this grid leaves the hand-over
+        // counters zeroed for the launch that uses the slot next.
+        const unsigned long long wh = wave_sum_u32(nhits);          // valid in lane 0 of the wave
+        if (wl == 0) {
+            if (io.ctr && wh) atomicAdd(&io.ctr[CTR_HITS], wh);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(&sm->oct_tail_done, 1u) == gridDim.x * waves_per_block - 1u) {
+                atomicExch(&sm->oct_tail_count, 0u);
+                atomicExch(&sm->oct_tail_next, 0u);
+                atomicExch(&sm->oct_tail_done, 0u);
+            }
+        }
+        return;
     }
     launch_epilogue(io, nrays, nhits, waves_per_block);
 }

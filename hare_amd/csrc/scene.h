@@ -34,10 +34,13 @@ struct SceneOptions {
     int dev = 0;               // HARE_DEV=1: developer flag bits (timeline, phase profile, cull audit) pass sanitize_flags
     int build_host = 0;        // HARE_BUILD=host: host builders even when a GPU is present (identical output)
     int voxel_kernel = 0;      // 0 = the library's rule, 1 = K1p (persist), 2 = K1q (pool)
-    int octree_kernel = 0;     // 0 = the library's rule (K2p), 1 = K2p (persist), 2 = K2q (pool)
+    int octree_kernel = 0;     // 0 = the library's rule (K2g below 655k rays, K2p + K2g-tail above), 1 = K2p (persist), 2 = K2q (pool), 3 = K2g (group)
     int ticket_rays = 0;       // rays per ticket of the persistent kernels (0 = the host's rule)
     int k1p_static_rays = 0;   // static first chunk per wave (0 = the host's rule)
     int k2p_static_rays = 0;
+    int octree_tail = 2;       // what finishes the rays K2p gives up: 0 nothing (every lane finishes its own), 1 K2t (a wave per ray, a wave's last 16), 2 K2g-tail (eight lanes per ray, all of them)
+    int k2p_tail_max = 0;      // developer sweeps: hand over once at most this many rays are alive in a wave (0 = the rule) ...
+    int k2p_tail_patience = -1; // ... after this many rounds (-1 = the rule)
     int batch_chunks = 0;      // chunks hare_shoot_batch pipelines a batch over (0 = the host's rule)
     int coop_tail = 1;         // 1: a drained wave traces its last rays with all 64 lanes (voxel_coop.hip); 0: as lanes of the pool to the end (A/B)
     int wide_drain = 1;        // 1: K1q's wide cull / wide walk in the drain of a launch (voxel_pool.hip); 0: the pool's ordinary phases to the end (A/B)
@@ -87,7 +90,7 @@ struct DeviceModule {
     hipFunction_t voxel_persist_tri = nullptr, voxel_persist_quad = nullptr;
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t voxel_pool_tri = nullptr, voxel_pool_quad = nullptr, voxel_pool_tri_g = nullptr, voxel_pool_quad_g = nullptr;
-    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr, octree_group = nullptr;
+    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr, octree_group = nullptr, octree_group_tail = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr;

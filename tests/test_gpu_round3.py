@@ -422,7 +422,8 @@ def test_wide_drain_modes_with_quadrilaterals():
 
 
 def test_octree_tail_kernel_is_invisible_in_the_results(hall):
-    """K2p hands the last, long-lived rays of a launch to K2t (octree_coop.hip: a wave per ray; the children of a frame on eight
+    """K2p hands the rays its waves still walk at the end of a launch to a tail kernel: K2g-tail (octree_group.hip: eight lanes per ray,
+    continued from K2p's frames -- the default) or K2t (octree_coop.hip: a wave per ray; the children of a frame on eight
     lanes, a leaf's list replayed from per-lane results with the reference's strict-< scan and its early return).  With the hand-over
     on, off, and from the oracle the events must be the same bytes: burst rays, surface-skimming rays (the heavy ones), exclusions,
     a deep tree over a small crowded scene, and batches so small that everything is handed over."""
@@ -441,21 +442,37 @@ def test_octree_tail_kernel_is_invisible_in_the_results(hall):
     rays[half:] = H.scenes.burst_rays(n - half, m.size)
     e1 = rng.integers(-1, m.P, n).astype(np.int32)
     oc, oo = H.Octree([T], 8, 16), po.Octree([To], 8, 16)
-    oc.set_option("octree_kernel", 1)                                 # K2p + K2t: the kernels this test is about
+    oc.set_option("octree_kernel", 1)                                 # K2p + its tail kernels: what this test is about
     assert oc.kernel_name(n) == "hare_octree_persist"
     ref, rc = oo.shoot(rays, excl1=e1, nthreads=16)
     got = {}
-    for coop in (1, 0):
-        oc.set_option("coop_tail", coop)
-        got[coop], c = oc.Shoot_batch(rays, poly_origin1=e1)
-        assert_events_equal(got[coop], ref, what=f"octree, tail kernel {coop}")
-        assert (c["rays"], c["hits"]) == (n, rc["hits"])
-    assert got[0].tobytes() == got[1].tobytes()
+    # no tail (every K2p lane finishes its own ray), K2t (a wave per ray: a wave's last 16 rays after 64 rounds), K2g-tail (eight lanes
+    # per ray: every ray a wave still walks 32 rounds after its tickets ran dry -- the default), and K2g-tail taking ALL rays at once
+    for tail, extra in ((0, {}), (1, {}), (2, {}), (2, {"k2p_tail_max": 64, "k2p_tail_patience": 0}), (2, {"k2p_tail_max": 7, "k2p_tail_patience": 3})):
+        oc.set_option("octree_tail", tail)
+        for k_, v_ in {"k2p_tail_max": 0, "k2p_tail_patience": -1, **extra}.items():
+            oc.set_option(k_, v_)
+        key = (tail, tuple(sorted(extra.items())))
+        got[key], c = oc.Shoot_batch(rays, poly_origin1=e1)
+        assert_events_equal(got[key], ref, what=f"octree, tail kernel {key}")
+        assert (c["rays"], c["hits"]) == (n, rc["hits"]), key
+    assert len({g_.tobytes() for g_ in got.values()}) == 1
+    oc.set_option("coop_tail", 0)                                     # the scene-wide switch turns every tail off as well
+    assert oc.Shoot_batch(rays, poly_origin1=e1)[0].tobytes() == got[(0, ())].tobytes()
     oc.set_option("coop_tail", 1)
-    for k in (1, 5, 64, 900):
-        ev, c = oc.Shoot_batch(rays[:k], poly_origin1=e1[:k])
-        assert ev.tobytes() == ref[:k].tobytes() and c["hits"] == int(ref["hit"][:k].sum())
+    for tail in (1, 2):
+        oc.set_option("octree_tail", tail)
+        oc.set_option("k2p_tail_max", 64 if tail == 2 else 0)
+        oc.set_option("k2p_tail_patience", 0 if tail == 2 else -1)
+        for k in (1, 5, 64, 900):
+            ev, c = oc.Shoot_batch(rays[:k], poly_origin1=e1[:k])
+            assert ev.tobytes() == ref[:k].tobytes() and c["hits"] == int(ref["hit"][:k].sum())
+    oc.set_option("k2p_tail_max", 0)
+    oc.set_option("k2p_tail_patience", -1)
     v, nv, size = soup(n_tri=900, n_quad=300, seed=6)                 # quadrilaterals, a tree of 7 levels with 2 polygons per leaf
     sr = soup_rays(50_000, size, seed=14)
     g2, o2 = H.Octree([H.Topology(v, nv)], 7, 2), po.Octree([po.Topology(v, nv)], 7, 2)
-    assert_events_equal(g2.Shoot_batch(sr)[0], o2.shoot(sr, nthreads=16)[0], what="octree 7/2 with quads, tail kernel on")
+    ref2 = o2.shoot(sr, nthreads=16)[0]
+    for kern in (0, 1, 3):                                            # the rule (K2g at this size), K2p + K2g-tail, K2g
+        g2.set_option("octree_kernel", kern)
+        assert_events_equal(g2.Shoot_batch(sr)[0], ref2, what=f"octree 7/2 with quads, kernel option {kern}")
