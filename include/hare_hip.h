@@ -171,8 +171,11 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  * HARE_BATCH_CHUNKS, HARE_TUNE): no call reads the environment afterwards.  Options:
  *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
- *   "octree_kernel"   0: the library's rule (K2g), 1: hare_octree_persist (K2p, one lane per ray), 2: hare_octree_pool (K2q),
- *                     3: hare_octree_group (K2g, eight lanes per ray)
+ *   "octree_kernel"   0: the library's rule (K2g below 655k rays on a 256-CU part, K2p + tail above), 1: hare_octree_persist (K2p, one lane
+ *                     per ray), 2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray)
+ *   "octree_tail"     what finishes the rays K2p's waves still walk at the end of a launch: 2 (default) hare_octree_group_tail (eight lanes per
+ *                     ray, every ray a wave holds 32 rounds after its tickets ran dry), 1 hare_octree_tail (a wave per ray, a wave's last 16), 0 nothing
+ *   "k2p_tail_max", "k2p_tail_patience"   the hand-over rule (0 / -1: the library's)
  *   "ticket_rays", "k1p_static_rays" (both voxel kernels), "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
  *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per
