@@ -311,8 +311,9 @@ def measure(w, env):
         if pending[k & 1] is not None:
             pending[k & 1].wait()
             pending[k & 1] = None
-        c.copy_(ctr_init)
-        cast_pass(c.data_ptr())
+        if dist is not None:
+            c.copy_(ctr_init)          # a block is all-reduced per step: it starts every step from {0, ..., 0, 1}
+        cast_pass(c.data_ptr())        # (one rank, no reduce: the library ACCUMULATES into the caller's counters; they run on over the timed steps)
         if dist is not None:
             if backend == "nccl":
                 pending[k & 1] = dist.all_reduce(c, async_op=True)   # RCCL: the final hit-count reduce (64 B)
@@ -342,6 +343,11 @@ def measure(w, env):
     for _ in range(warmup):
         step()
     fence()
+    if dist is None:
+        for c in ctrs:                 # outside the timed region: the timed steps accumulate from zero
+            c.zero_()
+        state["k"] = 0
+        torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
@@ -362,10 +368,16 @@ def measure(w, env):
         walls = [float(g[0]) for g in gathered]
         dev_ms = max(float(g[1]) for g in gathered)
     wall = max(walls)
-    last = reduced[(state["k"] - 1) & 1]
-    hits_total = int(last[1])
-    rays_total = int(last[0])
-    ranks_seen = int(last[7])
+    if dist is None:
+        # the two blocks hold the sums over their steps; every step casts the same rays
+        tot = (ctrs[0] + ctrs[1]).cpu()
+        assert int(tot[0]) % steps == 0 and int(tot[1]) % steps == 0, "counters are not a whole number of steps"
+        hits_total, rays_total, ranks_seen = int(tot[1]) // steps, int(tot[0]) // steps, 1
+    else:
+        last = reduced[(state["k"] - 1) & 1]
+        hits_total = int(last[1])
+        rays_total = int(last[0])
+        ranks_seen = int(last[7])
 
     # shoot-kernel duration: HIP events around each shoot launch on the launch stream (the stream the kernel runs on)
     nrep = max(1, min(steps, 30))

@@ -820,6 +820,12 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 #endif
     int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the polygons tested last (HARE_K2P_MAILBOX of them)
     unsigned int nhits = 0, nrays = 0;
+#ifdef HARE_K2P_STATS                   // developer build (tools/k2p_stats.py): what a round of the loop is made of; lane 0 counts
+    unsigned long long sp_round = 0, sp_alive = 0, sp_p = 0, sp_pl = 0, sp_c = 0, sp_cl = 0, sp_e = 0, sp_el = 0, sp_visit = 0;
+#define K2P_STAT(x) x
+#else
+#define K2P_STAT(x)
+#endif
 
     auto finish = [&]() {
         if (OCC) {
@@ -975,11 +981,13 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             }
         }
 
+        K2P_STAT(sp_round++; sp_alive += __popcll(__ballot(alive));)
         // ------------------------------------------------------------------ phase P: one child per step
 #pragma unroll 1
         for (int k = 0; k < STEPS; ++k) {
             const bool pop = alive && !parked && q == qe;
             if (__ballot(pop) == 0) break;
+            K2P_STAT(sp_p++; sp_pl += __popcll(__ballot(pop));)
             // Rays whose components are all finite and far from overflow never produce a NaN here (1/d is finite and non-zero,
             // boxes are finite), so for them Math.Max / Math.Min are the hardware's v_max_f64 / v_min_f64 (the sign of a zero
             // result is only ever compared); anything else takes the NaN-propagating compare-selects.
@@ -1035,6 +1043,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         for (int kc = 0; kc < CULLS / 2; ++kc) {
             const bool culling = alive && !parked && q < qe;
             if (__ballot(culling) == 0) break;
+            K2P_STAT(sp_c++; sp_cl += __popcll(__ballot(culling));)
             if (culling) {
                 const bool has1 = q + 1 < qe;
                 // the two entries AFTER this pair, for the next iteration: one 8-byte gather (4-byte alignment is all the hardware asks
@@ -1085,6 +1094,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             const unsigned long long pm = __ballot(alive && parked);
             const unsigned long long busy = __ballot(alive && !parked);
             if (pm != 0 && (__popcll(pm) >= EXACT_MIN_PARKED || busy == 0)) {
+                K2P_STAT(sp_e++; sp_el += __popcll(pm);)
                 if (alive && parked) {
                     const int i = idx;                                       // == items[q]
                     const PolyRec& p = g.polys[i];
@@ -1126,6 +1136,12 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         }
     }
     timeline(2);
+#ifdef HARE_K2P_STATS
+    if (lane == 0 && io.prof) {
+        const unsigned long long v[8] = {sp_round, sp_alive, sp_p, sp_pl, sp_c, sp_cl, sp_e, sp_el};
+        for (int k = 0; k < 8; ++k) atomicAdd(&io.prof[k], v[k]);
+    }
+#endif
     launch_epilogue(io, nrays, nhits, 4u);
 }
 

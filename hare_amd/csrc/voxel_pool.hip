@@ -259,9 +259,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                             L_xyzf[slot] = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (d.x < 0 ? F_NX : 0u) | (d.y < 0 ? F_NY : 0u) |
                                            (d.z < 0 ? F_NZ : 0u) | (moved ? F_MOVED : 0u);
                             L_d1[slot] = -1;
-                            double* sc = reinterpret_cast<double*>(&io.out[ray]);      // the ray's scratch (see the header)
-                            sc[0] = kDblMax;
-                            if (moved) sc[1] = t_start;
+                            // the ray's scratch is its event slot (see the header).  Nothing is written at set-up: "no hit pending" is the
+                            // absence of F_HIT in the slot flags (round 4: one store and one visit of the record less per ray) -- except
+                            // for a ray that AABB.Intersect moved, whose t_start waits in the u field
+                            if (moved) reinterpret_cast<double*>(&io.out[ray])[1] = t_start;
                             unsigned q = 0, qe = 0;
                             int idx = -1, nexti = -1;
                             if (occupied(X, Y, Z, cell)) {
@@ -744,7 +745,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const int after = g.items[qa];                              // items[q + 2]: nexti once this candidate is done
                 // items[q + 1]: in the pool's slot state, except behind the wide cull, which leaves only L_idx (the candidate) current
                 const int succ = wide ? g.items[q + 1u < qe ? q + 1u : qe - 1u] : L_nexti[slot];
-                const double tmin = sc[0];
+                const double tmin = (xf & F_HIT) ? sc[0] : kDblMax;             // Voxel_Grid.cs:688: tmin starts at double.MaxValue
                 const RayRec r = io.rays[ray];
                 const PolyRec& p = g.polys[i];
                 const double v0[3] = {p.v0[0], p.v0[1], p.v0[2]}, v1[3] = {p.v1[0], p.v1[1], p.v1[2]};
