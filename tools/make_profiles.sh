@@ -1,27 +1,38 @@
-# Round-3 profiles (same recipe as round 2) (run on the MI355X box): rocprofv3 kernel-trace stats and PMC passes for the bench configurations.
-# FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), the SQ counters in a third; never combined with other trace domains.
+# Round-4 profiles (run on the MI355X box): rocprofv3 kernel-trace stats and PMC passes for the bench configurations.
+# FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), the SQ counters in two more, TA / TCP in a fifth; never combined with other
+# trace domains.  Condensed into profiles/r04_* by tools/condense_profiles.py (ROUND=r04).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03prof
+O=$R/gpurun_out/r04prof
 mkdir -p $O
+pmc() {  # tag, pass name, counters..., then "--", bench args
+  tag=$1; name=$2; shift 2
+  ctrs=()
+  while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
+  shift
+  echo "[$tag] $name" >> $O/progress.log
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d $O/${tag}_$name -- python3 $R/bench.py "$@" --no-cpu-baseline --no-e2e --no-extra-configs > $O/${tag}_$name.log 2>&1 || echo "  failed" >> $O/progress.log
+}
 prof() {  # tag, bench args...
   tag=$1; shift
   echo "[$tag] kernel trace" >> $O/progress.log
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_kt -- python3 $R/bench.py "$@" --no-cpu-baseline --no-e2e --no-extra-configs > $O/${tag}_kt.log 2>&1 || echo "  failed" >> $O/progress.log
-  for c in FETCH_SIZE WRITE_SIZE; do
-    echo "[$tag] $c" >> $O/progress.log
-    timeout -k 5 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/${tag}_$c -- python3 $R/bench.py "$@" --no-cpu-baseline --no-e2e --no-extra-configs > $O/${tag}_$c.log 2>&1 || echo "  failed" >> $O/progress.log
-  done
-  echo "[$tag] SQ" >> $O/progress.log
-  timeout -k 5 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS --output-format csv -d $O/${tag}_SQ -- python3 $R/bench.py "$@" --no-cpu-baseline --no-e2e --no-extra-configs > $O/${tag}_SQ.log 2>&1 || echo "  failed" >> $O/progress.log
-  echo "[$tag] TA" >> $O/progress.log
-  timeout -k 5 300 rocprofv3 --kernel-trace --pmc TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE --output-format csv -d $O/${tag}_TA -- python3 $R/bench.py "$@" --no-cpu-baseline --no-e2e --no-extra-configs > $O/${tag}_TA.log 2>&1 || echo "  failed" >> $O/progress.log
+  if [ -z "$KT_ONLY" ]; then
+    pmc $tag FETCH_SIZE FETCH_SIZE -- "$@"
+    pmc $tag WRITE_SIZE WRITE_SIZE -- "$@"
+    pmc $tag SQ SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS -- "$@"
+    # lane-level VALU utilisation = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64; vector-memory instructions by direction
+    pmc $tag SQ2 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES -- "$@"
+    pmc $tag TA TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum -- "$@"
+  fi
   # the bench line of the same command, un-profiled, with the oracle (roofline, cpu_baseline, parity)
   python3 $R/bench.py "$@" --no-extra-configs > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 }
 prof c2 --steps 20 --warmup 3
 prof c2_4M --rays 4194304 --steps 8 --warmup 2
 prof c3 --kind octree --steps 5 --warmup 1
+prof c3_262k --kind octree --rays 262144 --steps 8 --warmup 2
 prof c4shard --scene cathedral --domain 128 --rays 2097152 --steps 8 --warmup 2
 prof c5 --scene cathedral --domain 128 --bounces 8 --steps 3 --warmup 1
-python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
+KT_ONLY=1 prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
+ROUND=r04 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
