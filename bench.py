@@ -431,7 +431,7 @@ def measure(w, env):
 
             host_call()                         # sizes the scene's staging buffers: not part of the measurement
             best = None
-            for _ in range(3):
+            for _ in range(5):
                 t1 = time.perf_counter()
                 host_call()
                 dt = time.perf_counter() - t1
@@ -447,7 +447,7 @@ def measure(w, env):
 
             host_call_slim()
             best = None
-            for _ in range(3):
+            for _ in range(5):
                 t1 = time.perf_counter()
                 host_call_slim()
                 dt = time.perf_counter() - t1
