@@ -271,7 +271,7 @@ def measure(w, env):
     out_sets = [d_out] + [torch.empty_like(d_out) for _ in range(n_sets - 1)]
 
     d_rays0 = d_rays.clone() if B > 1 else None
-    d_excl = torch.full((n,), -1, dtype=torch.int32, device="cuda") if B > 1 else None
+    d_excl = torch.zeros(2 * n, dtype=torch.int32, device="cuda") if B > 1 else None       # hare_bounce_device's work array
     # the per-batch hit-count reduce runs on RCCL's stream, overlapped with the NEXT batch's kernel:
     # two counter blocks alternate, a block is reused only after its all-reduce has been waited for
     ctrs = [torch.zeros(8, dtype=torch.int64, device="cuda"), torch.zeros(8, dtype=torch.int64, device="cuda")]
@@ -284,18 +284,14 @@ def measure(w, env):
 
     def cast_pass(c_ptr, events=None):
         """One pass of the hot path over this rank's batch: 1 cast, or B casts with a specular bounce between them."""
-        if B > 1:     # config 5: shoot -> reflect -> shoot with poly_origin1 = the polygon just hit
-            d_rays.copy_(d_rays0)
-            d_excl.fill_(-1)
-            for b in range(B):
-                if events is not None:
-                    events[2 * b].record(stream)
-                part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl1=d_excl.data_ptr(), d_counters=c_ptr, stream=sp,
-                                  flags=H.capi.SHOOT_RETIRED_RAYS)
-                if events is not None:
-                    events[2 * b + 1].record(stream)
-                if b + 1 < B:
-                    part.reflect_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_excl.data_ptr(), stream=sp)
+        if B > 1:     # config 5: shoot -> reflect -> shoot with poly_origin1 = the polygon just hit, B casts, device-resident:
+            # hare_bounce_device -- ONE launch in which every ray runs through its casts (Voxel_Grid), or a launch per cast (trees)
+            d_rays.copy_(d_rays0)        # the call overwrites its rays (work array): every step starts from the burst
+            if events is not None:
+                events[0].record(stream)
+            part.bounce_device(n, d_rays.data_ptr(), B, d_excl.data_ptr(), d_events_last=d_out.data_ptr(), d_counters=c_ptr, stream=sp)
+            if events is not None:
+                events[1].record(stream)
         else:
             i = state["set"] = (state["set"] + 1) % n_sets
             if events is not None:
@@ -387,8 +383,9 @@ def measure(w, env):
     for r in range(nrep):
         cast_pass(0, evs[r])
     torch.cuda.synchronize()
-    per_cast_ms = [sum(evs[r][2 * b].elapsed_time(evs[r][2 * b + 1]) for r in range(nrep)) / nrep for b in range(B)]
-    kern_ms = sum(per_cast_ms) / B            # average duration of one shoot launch, an event pair around every launch
+    loop_ms = sum(evs[r][0].elapsed_time(evs[r][1]) for r in range(nrep)) / nrep      # one shoot launch, or the whole bounce loop
+    per_cast_ms = [loop_ms / B] * B
+    kern_ms = loop_ms / B                     # average per cast; an event pair around every call
     kern_ms_pairs = kern_ms
     if B == 1 and dist is None:
         # one rank, one cast per step: a timed step IS one shoot launch and nothing else (the counters run on, no reset kernel), so the
@@ -590,7 +587,8 @@ def measure(w, env):
                     "hbm_busy_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1)}
         if B > 1:
-            roofline["per_cast_ms"] = [round(x, 4) for x in per_cast_ms]
+            roofline["bounce_loop_ms"] = round(loop_ms, 4)
+            roofline["bounce_loop"] = "hare_bounce_device: " + (part.bounce_kernel_name(n, B) or "a launch per cast")
             roofline["live_casts_per_pass"] = casts
         # parity check of the bench buffers themselves (not timed): every ray of this rank's shard, all eight fields, bit for bit
         got = device_events(n)

@@ -96,6 +96,7 @@ namespace Hare
             public const int HARE_KIND_VOXEL = 0, HARE_KIND_OCTREE = 1, HARE_KIND_KDTREE = 2;
             public const uint HARE_SHOOT_WRITEBACK_ORIGIN = 1;
             public const uint HARE_SHOOT_RETIRED_RAYS = 8;   // device-resident bounce loop only (hare_shoot_device)
+            public const uint HARE_SHOOT_BOUNCE_LOOP = 32;   // hare_shoot_kernel_name only
             public const uint HARE_SHOOT_SLIM_EVENTS = 16;   // host-buffer batches: hare_slim_event records come back (16 B per ray, not 56)
 
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr hare_last_error();
@@ -198,6 +199,12 @@ namespace Hare
                                                           IntPtr d_tmax, uint flags, IntPtr d_events, IntPtr d_occluded, IntPtr d_counters, IntPtr stream);
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
             public static extern int hare_reflect_device(IntPtr scene, int top_index, long n, IntPtr d_rays, IntPtr d_events, IntPtr d_excl_out, IntPtr stream);
+            /// <summary>The whole bounce loop on device buffers, stream-ordered (one launch for a Voxel_Grid where the pool kernel serves).
+            /// d_rays is read and overwritten; d_work is 2 n int32 of scratch; d_events_all (bounces x n) and the counters may be null.</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]
+            public static extern int hare_bounce_device(IntPtr scene, int kind, int top_index, long n, IntPtr d_rays, IntPtr d_excl1, IntPtr d_excl2,
+                                                        int bounces, uint flags, IntPtr d_work, IntPtr d_events_all, IntPtr d_events_last,
+                                                        IntPtr d_counters, IntPtr d_counters_per_cast, IntPtr stream);
 
             public static void Check(int rc)
             {

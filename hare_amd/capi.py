@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("HARE_LIB") or os.path.join(_HERE, "libhare_hip.so")  
 HARE_OK = 0
 HARE_E_INVALID, HARE_E_NOMEM, HARE_E_HIP, HARE_E_NODEVICE, HARE_E_STATE, HARE_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 KIND_VOXEL, KIND_OCTREE, KIND_KDTREE = 0, 1, 2
-SHOOT_WRITEBACK_ORIGIN, SHOOT_COUNT_WORK, SHOOT_SIMPLE_KERNEL, SHOOT_RETIRED_RAYS, SHOOT_SLIM_EVENTS = 1, 2, 4, 8, 16
+SHOOT_WRITEBACK_ORIGIN, SHOOT_COUNT_WORK, SHOOT_SIMPLE_KERNEL, SHOOT_RETIRED_RAYS, SHOOT_SLIM_EVENTS, SHOOT_BOUNCE_LOOP = 1, 2, 4, 8, 16, 32
 
 RAY_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("dx", "<f8"), ("dy", "<f8"), ("dz", "<f8")])
 XEVENT_DTYPE = np.dtype(
@@ -86,6 +86,7 @@ SYMBOLS = {
     "hare_shoot_batch_sharded": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp]),
     "hare_shoot_device": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "hare_reflect_device": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "hare_bounce_device": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hare_shoot_kernel_name": (C.c_char_p, [_vp, _i32, _i32, _i64, _u32]),
     "hare_shoot_one": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "hare_bounce_batch": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _u32, _vp, _vp, _vp, _vp]),

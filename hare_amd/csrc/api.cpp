@@ -82,6 +82,11 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_pool_quad", &m->voxel_pool_quad},
         {"hare_voxel_pool_tri_g", &m->voxel_pool_tri_g},
         {"hare_voxel_pool_quad_g", &m->voxel_pool_quad_g},
+        {"hare_voxel_bounce_tri", &m->voxel_bounce_tri},
+        {"hare_voxel_bounce_quad", &m->voxel_bounce_quad},
+        {"hare_voxel_bounce_tri_g", &m->voxel_bounce_tri_g},
+        {"hare_voxel_bounce_quad_g", &m->voxel_bounce_quad_g},
+        {"hare_counters_sum", &m->counters_sum},
         {"hare_octree_shoot", &m->octree},
         {"hare_octree_shoot_count", &m->octree_count},
         {"hare_octree_persist", &m->octree_persist},
@@ -465,7 +470,8 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass on a scene whose
 // `dev` option is set (HARE_DEV=1 when the scene was created, or hare_scene_set_option), so a stray bit from a caller can
 // never reach a kernel.
-constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS | HARE_SHOOT_SLIM_EVENTS;
+constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS | HARE_SHOOT_SLIM_EVENTS |
+                                 HARE_SHOOT_BOUNCE_LOOP;
 uint32_t sanitize_flags(const Scene& s, uint32_t flags)
 {
     return flags & (kPublicFlags | (s.opt.dev ? 0xF000u : 0u));
@@ -482,6 +488,7 @@ void read_env_options(SceneOptions& o)
     if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
     if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : 0));
     if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
+    if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
     if (const char* t = getenv("HARE_K2P_TAIL_MAX")) o.k2p_tail_max = atoi(t);
     if (const char* t = getenv("HARE_K2P_TAIL_PATIENCE")) o.k2p_tail_patience = atoi(t);
     if (const char* t = getenv("HARE_TICKET")) o.ticket_rays = atoi(t);
@@ -681,6 +688,133 @@ bool ranges_overlap(const void* a, size_t na, const void* b, size_t nb)
 {
     const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
     return a && b && x < y + nb && y < x + na;
+}
+
+// The grid as the voxel kernels take it
+static void fill_voxel_args(const Scene& s, int32_t top, VoxelArgs& g)
+{
+    memset(&g, 0, sizeof g);
+    g.polys = (const PolyRec*)s.d_polys[top];
+    g.cull = (const unsigned char*)s.d_cull[top];
+    g.cf = s.cull_frames[(size_t)top];
+    g.quads = (const QuadRec*)s.d_quads[top];
+    g.cells = (const CellRec*)s.d_cells[top];
+    g.items = (const int32_t*)s.d_items[top];
+    g.occ = (const uint32_t*)s.d_occ[top];
+    g.ct = s.vox.ct;
+    g.occ_words = s.occ_words;
+    g.occ_shift = s.occ_shift;
+    g.occ_cd = s.occ_cd;
+    for (int a = 0; a < 3; ++a) {
+        g.omin[a] = s.vox.omin[a];
+        g.omax[a] = s.vox.omax[a];
+        g.vd[a] = s.vox.vd[a];
+    }
+}
+
+// ---- the specular bounce loop on device buffers (hare_bounce_device, and the loop inside hare_bounce_batch) ------------------------
+// `casts` casts per ray; between casts the ray is reflected about the polygon it hit and that polygon is excluded (hare_reflect).
+// Voxel_Grid where the pool kernel serves (every grid up to 512 voxels a side whose bitmap leaves room for the pools) and casts <= 16:
+// ONE launch of hare_voxel_bounce_* -- every ray runs through its casts on its own, no barrier between casts (voxel_pool.hip).
+// Anything else: casts x (shoot + reflect) launches on the stream, retired rays skipped; no host synchronisation either way.
+//   d_rays   n rays, READ AND OVERWRITTEN (a work array: a ray's last reflection remains)
+//   d_work   2 n int32 of scratch (the exclusions of the casts behind the first)
+//   d_all    nullable: casts x n events, cast-major;  d_last: nullable when d_all is given: the last cast's n events
+//   d_ctr    nullable: totals, accumulated (rays = casts with a live ray);  d_ctr_casts: nullable, `casts` blocks, accumulated
+int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays, const void* d_e1, const void* d_e2,
+                       int32_t casts, uint32_t flags, void* d_work, void* d_all, void* d_last, void* d_ctr, void* d_ctr_casts, hipStream_t st)
+{
+    if (n < 0 || casts < 1 || casts > 4096 || top < 0 || top >= (int32_t)s.topos.size()) {
+        set_error("hare_bounce: bad n, bounces or top_index");
+        return HARE_E_INVALID;
+    }
+    if (n == 0) return HARE_OK;
+    if (!d_rays || !d_work || (!d_all && !d_last)) {
+        set_error("hare_bounce: null rays / work array / events");
+        return HARE_E_INVALID;
+    }
+    if (n > 0x7FFFFF00ll) {
+        set_error("hare_bounce: batch too large");
+        return HARE_E_INVALID;
+    }
+    flags = sanitize_flags(s, flags) & (HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL);
+    const DeviceModule& M = *s.module;
+    hare_xevent* const all = (hare_xevent*)d_all;
+    hare_xevent* const last = d_last ? (hare_xevent*)d_last : all + (size_t)(casts - 1) * (size_t)n;
+    int32_t* const work = (int32_t*)d_work;
+    if (!M.reflect || !M.events_fill_miss) {
+        set_error("hare_bounce: bounce kernels missing from code object");
+        return HARE_E_STATE;
+    }
+    // ---- one launch?
+    if (kind == HARE_KIND_VOXEL && casts <= kBounceMaxCasts && flags == 0 && s.vox.built && !s.d_cells.empty()) {
+        const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, 0u);
+        const bool quads = s.topos[top].has_quads, coarse = s.occ_shift > 0;
+        hipFunction_t f = !coarse ? (quads ? M.voxel_bounce_quad : M.voxel_bounce_tri) : (quads ? M.voxel_bounce_quad_g : M.voxel_bounce_tri_g);
+        const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
+        const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)(kPoolWaveBytes + kPoolBounceExtra);
+        if (kc.k == Kern::VoxelPool && f != nullptr && plds <= kLdsMax && s.opt.bounce_fused) {
+            // the work arrays: exclusions of cast 0 (none: -1), rewritten per ray as it goes from cast to cast
+            if (d_e1) HIP_TRY(H->MemcpyAsync(work, d_e1, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            else HIP_TRY(H->MemsetAsync(work, 0xFF, (size_t)n * sizeof(int32_t), st));
+            if (d_e2) HIP_TRY(H->MemcpyAsync(work + n, d_e2, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            if (all) {       // a ray that dies leaves the events of its later casts untouched: they start as miss records
+                void* full = all;
+                long long nn = (long long)n * casts;
+                void* a1[] = {&full, &nn};
+                if (int rc = launch(H, M.events_fill_miss, (unsigned)((nn + 255) / 256), 256, 0, st, a1)) return rc;
+            }
+            VoxelArgs g;
+            fill_voxel_args(s, top, g);
+            ShootIO io;
+            memset(&io, 0, sizeof io);
+            io.rays = (RayRec*)d_rays;
+            io.excl1 = work;
+            io.excl2 = d_e2 ? work + n : nullptr;
+            io.out = (XEventRec*)last;
+            io.ctr = (unsigned long long*)d_ctr;
+            io.n = n;
+            io.bounce_casts = casts;
+            io.out_all = (XEventRec*)all;
+            io.out_stride = n;
+            io.ctr_casts = (unsigned long long*)d_ctr_casts;
+            const unsigned cus = (unsigned)std::max(1, M.cu_count);
+            unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + kPoolWaves - 1) / kPoolWaves));
+            if (pgrid == 0) pgrid = 1;
+            const int64_t per_wave = (n + (int64_t)pgrid * kPoolWaves - 1) / ((int64_t)pgrid * kPoolWaves);
+            io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(128, (per_wave + 7) / 8 * 8));
+            io.ticket_rays = ticket_rays_for(s, n, true);
+            void* args[] = {&g, &io};
+            return launch_on_slot(s, H, f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
+        }
+    }
+    // ---- a launch per cast
+    for (int32_t c = 0; c < casts; ++c) {
+        hare_xevent* out_c = all ? all + (size_t)c * (size_t)n : last;
+        void* ctr_c = d_ctr_casts ? (void*)((hare_counters*)d_ctr_casts + c) : d_ctr;
+        const uint32_t f = flags | (c > 0 ? (uint32_t)HARE_SHOOT_RETIRED_RAYS : 0u);
+        if (int rc = shoot_device_impl(s, H, kind, top, n, d_rays, c == 0 ? d_e1 : work, c == 0 ? d_e2 : nullptr, f, out_c, ctr_c, st)) return rc;
+        if (c + 1 < casts) {
+            const void* polys = s.d_polys[(size_t)top];
+            const void* ev = out_c;
+            void* ex = work;
+            long long mm = n;
+            void* a[] = {&polys, &d_rays, &ev, &ex, &mm};
+            if (int rc = launch(H, M.reflect, (unsigned)((n + 255) / 256), 256, 0, st, a)) return rc;
+        }
+    }
+    if (all && d_last) HIP_TRY(H->MemcpyAsync(d_last, all + (size_t)(casts - 1) * (size_t)n, (size_t)n * sizeof(hare_xevent), hipMemcpyDeviceToDevice, st));
+    if (d_ctr_casts && d_ctr) {
+        if (!M.counters_sum) {
+            set_error("hare_bounce: hare_counters_sum missing from code object");
+            return HARE_E_STATE;
+        }
+        const void* pc = d_ctr_casts;
+        int cc = casts;
+        void* a[] = {&pc, &cc, &d_ctr};
+        if (int rc = launch(H, M.counters_sum, 1, 64, 0, st, a)) return rc;
+    }
+    return HARE_OK;
 }
 
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
@@ -1751,11 +1885,54 @@ int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_ray
     GUARD_END
 }
 
+int hare_bounce_device(hare_scene* s, int32_t kind, int32_t top_index, int64_t n, void* d_rays, const void* d_excl1, const void* d_excl2,
+                       int32_t bounces, uint32_t flags, void* d_work, void* d_events_all, void* d_events_last, void* d_counters,
+                       void* d_counters_per_cast, void* stream)
+{
+    if (!s) {
+        set_error("null scene");
+        return HARE_E_INVALID;
+    }
+    GUARD_BEGIN
+    const HipApi* H = api_or_err();
+    if (!H) return HARE_E_NODEVICE;
+    DeviceGuard dev_guard(H, s->device);
+    if (!s->module) {
+        int rc = ensure_device(*s, H);
+        if (rc) return rc;
+    }
+    if (int rc = upload_polys(*s, H)) return rc;
+    if (n > 0) {
+        const size_t rb = (size_t)n * sizeof(hare_ray), ob = (size_t)n * sizeof(hare_xevent), wb = (size_t)n * 2 * sizeof(int32_t),
+                     ab = ob * (size_t)std::max(1, bounces), eb = (size_t)n * sizeof(int32_t);
+        if (ranges_overlap(d_rays, rb, d_work, wb) || ranges_overlap(d_rays, rb, d_events_all, ab) || ranges_overlap(d_rays, rb, d_events_last, ob) ||
+            ranges_overlap(d_work, wb, d_events_all, ab) || ranges_overlap(d_work, wb, d_events_last, ob) ||
+            ranges_overlap(d_events_all, ab, d_events_last, ob) || ranges_overlap(d_excl1, eb, d_work, wb) || ranges_overlap(d_excl2, eb, d_work, wb) ||
+            ranges_overlap(d_excl1, eb, d_rays, rb) || ranges_overlap(d_excl2, eb, d_rays, rb)) {
+            set_error("hare_bounce_device: rays, exclusions, work array and events must not overlap");
+            return HARE_E_INVALID;
+        }
+    }
+    return bounce_device_impl(*s, H, kind, top_index, n, d_rays, d_excl1, d_excl2, bounces, flags, d_work, d_events_all, d_events_last,
+                              d_counters, d_counters_per_cast, (hipStream_t)stream);
+    GUARD_END
+}
+
 const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t top_index, int64_t n, uint32_t flags)
 {
     if (!s || top_index < 0 || top_index >= (int32_t)s->topos.size() || kind < HARE_KIND_VOXEL || kind > HARE_KIND_KDTREE) return "";
     // the launcher's own selection (choose_kernel), fall-backs included
-    return choose_kernel(*s, s->module, kind, (size_t)top_index, n, sanitize_flags(*s, flags)).name;
+    const KernChoice kc = choose_kernel(*s, s->module, kind, (size_t)top_index, n, sanitize_flags(*s, flags) & ~HARE_SHOOT_BOUNCE_LOOP);
+    if ((flags & HARE_SHOOT_BOUNCE_LOOP) && kc.k == Kern::VoxelPool && s->opt.bounce_fused && (flags & (HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL)) == 0) {
+        // hare_bounce_device (<= 16 casts): the fused build of the pool kernel, where it exists and fits (bounce_device_impl's rule)
+        const bool quads = s->topos[(size_t)top_index].has_quads, coarse = s->occ_shift > 0;
+        const unsigned plds = (unsigned)((s->occ_words + 3) / 4) * 16u + (unsigned)kPoolWaves * (unsigned)(kPoolWaveBytes + kPoolBounceExtra);
+        const DeviceModule* M = s->module;
+        const bool have = !M || (!coarse ? (quads ? M->voxel_bounce_quad : M->voxel_bounce_tri) : (quads ? M->voxel_bounce_quad_g : M->voxel_bounce_tri_g)) != nullptr;
+        if (have && plds <= kLdsMax)
+            return !coarse ? (quads ? "hare_voxel_bounce_quad" : "hare_voxel_bounce_tri") : (quads ? "hare_voxel_bounce_quad_g" : "hare_voxel_bounce_tri_g");
+    }
+    return kc.name;
 }
 
 // Slim records back to X_Events (include/hare_hip.h).  Same arithmetic as the kernels: hare_math.h is compiled for the host with
@@ -1834,6 +2011,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
         {"octree_kernel", &SceneOptions::octree_kernel, 0, 3},
         {"octree_tail", &SceneOptions::octree_tail, 0, 2},
+        {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},
         {"k2p_tail_max", &SceneOptions::k2p_tail_max, 0, 64},
         {"k2p_tail_patience", &SceneOptions::k2p_tail_patience, -1, 100000},
         {"ticket_rays", &SceneOptions::ticket_rays, 0, 4096},

@@ -102,6 +102,22 @@ int bounce_on_scene(Scene& s, const HipApi* H, Scene::BatchCtx& c, int32_t kind,
     hipStream_t st = c.st[0];
     const void* polys = s.d_polys[(size_t)top];
 
+    if (!events_all && s.opt.bounce_fused) {
+        // ---- only the last cast's events are wanted: the whole loop is enqueued ONCE, with no host round trip between casts
+        // (bounce_device_impl, api.cpp: one launch for a Voxel_Grid where the pool kernel serves, else a launch per cast with the
+        // retired rays skipped), and the call synchronises once, at its end.  b.ev[1] serves as the loop's work array (2 n int32).
+        HIP_TRY(H->MemcpyAsync(b.rays[0], rays, (size_t)n * sizeof(hare_ray), hipMemcpyHostToDevice, st));
+        if (excl1) HIP_TRY(H->MemcpyAsync(b.excl[0], excl1, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (excl2) HIP_TRY(H->MemcpyAsync(b.excl2, excl2, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(H->MemsetAsync(b.ctr, 0, (size_t)bounces * sizeof(hare_counters), st));
+        if (int rc = bounce_device_impl(s, H, kind, top, n, b.rays[0], excl1 ? b.excl[0] : nullptr, excl2 ? b.excl2 : nullptr, bounces, flags,
+                                        b.ev[1], nullptr, b.ev[0], nullptr, b.ctr, st))
+            return rc;
+        if (events_last) HIP_TRY(H->MemcpyAsync(events_last, b.ev[0], (size_t)n * sizeof(hare_xevent), hipMemcpyDeviceToHost, st));
+        HIP_TRY(H->MemcpyAsync(per_cast, b.ctr, (size_t)bounces * sizeof(hare_counters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(H->StreamSynchronize(st));
+        return HARE_OK;
+    }
     HIP_TRY(H->MemcpyAsync(b.rays[0], rays, (size_t)n * sizeof(hare_ray), hipMemcpyHostToDevice, st));
     if (excl1) HIP_TRY(H->MemcpyAsync(b.excl[0], excl1, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (excl2) HIP_TRY(H->MemcpyAsync(b.excl2, excl2, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));

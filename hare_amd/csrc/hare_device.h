@@ -224,6 +224,10 @@ constexpr int kPoolSlots = HARE_K1Q_SLOTS;
 constexpr int kPoolRing = kPoolSlots <= 64 ? 64 : (kPoolSlots <= 128 ? 128 : 256);   // queue capacity: the power of two >= slots
 constexpr int kPoolWaveBytes = kPoolSlots * (6 * 8 + 7 * 4) + 5 * kPoolRing;   // per wave: 6 doubles + 7 words per slot, 5 byte queues
 // (origin and FP32 direction in LDS as well -- no ray re-read in the cull phase -- was measured in round 2: +2.7 % at 8 waves, far behind 12 waves)
+// the fused bounce build of K1q (hare_voxel_bounce_*): per wave a rearm queue, a cast number per slot, rays / hits per cast
+constexpr int kBounceMaxCasts = 16;
+constexpr int kPoolBounceExtra = kPoolRing + kPoolSlots + 2 * 4 * kBounceMaxCasts;
+static_assert(kPoolBounceExtra % 8 == 0, "K1q bounce block keeps its words aligned");
 static_assert(kPoolSlots >= 64 && kPoolSlots <= 256 && kPoolSlots % 2 == 0, "K1q slots: even, 64..256");
 static_assert(kPoolWaveBytes % 8 == 0, "K1q: per-wave LDS block keeps the doubles aligned");
 
@@ -335,6 +339,11 @@ struct ShootIO {
     int32_t oct_tail_levels;   // frames per record (= the levels K2p keeps in LDS)
     int32_t oct_tail_max;      // K2p: a drained wave hands its rays over once at most this many are alive (64: all of them, at once) ...
     int32_t oct_tail_patience; // ... and they have outlived the rest of the batch by this many rounds
+    // the fused bounce kernels (hare_voxel_bounce_*, voxel_pool.hip): rays, excl1 (and excl2 when given) are WORK arrays there
+    int32_t bounce_casts;      // casts per ray (1 .. kBounceMaxCasts)
+    XEventRec* out_all;        // nullable: bounce_casts x out_stride records, cast-major: every cast's final X_Event (pre-filled with miss records)
+    int64_t out_stride;
+    unsigned long long* ctr_casts;   // nullable: bounce_casts counter blocks (rays = rays that started the cast, hits), accumulated
     unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
     int32_t oct_spill_cap;
 };

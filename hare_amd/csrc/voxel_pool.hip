@@ -72,7 +72,16 @@
 
 namespace {
 
-template <bool QUADS, bool COARSE>
+// BOUNCE (hare_voxel_bounce_*, round 4): the whole specular bounce loop of a ray inside ONE launch.  Rays are independent, also across
+// casts: ray i's cast c + 1 needs nothing but ray i's cast c.  The launch-per-cast loop puts a chip-wide barrier between casts and
+// pays the end of a launch -- a quarter of a late cast in the cathedral -- once per cast.  Here a ray whose hit stands is not
+// freed: its slot goes to a fifth queue, `rearm`, whose phase reflects the ray about the polygon's normal (the expressions of
+// hare_reflect), writes the reflected ray and the polygon it left into the caller's work arrays (io.rays, io.excl1) and sets the
+// slot up again -- Voxel_Grid.cs:563-632, the same code as for a new ray.  A ray that misses dies and frees its slot: no retired
+// rays are carried, no packing.  Per ray the sequence of operations is that of the launch-per-cast loop; the events of every cast
+// are identical to it (tests).  The event slot io.out[ray] is the ray's scratch through all its casts and ends up holding the last
+// cast's X_Event (a miss record once the ray has died); io.out_all, if given, receives every cast's final event.
+template <bool QUADS, bool COARSE, bool BOUNCE = false>
 __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -106,6 +115,14 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     uint8_t* const Q_exact = Q_cull + R;
     uint8_t* const Q_pend = Q_exact + R;
     uint8_t* const Q_free = Q_pend + R;
+    // BOUNCE: per wave, behind the twelve pools: the rearm queue, each slot's cast number, rays started / hits per cast
+    unsigned char* const xb = lds_raw + ((size_t)nw4 << 4) + (size_t)kPoolWaves * kPoolWaveBytes + (size_t)wave * kPoolBounceExtra;
+    uint8_t* const Q_rearm = xb;
+    uint8_t* const L_cast = Q_rearm + R;
+    uint32_t* const C_rays = reinterpret_cast<uint32_t*>(L_cast + S);
+    uint32_t* const C_hits = C_rays + kBounceMaxCasts;
+    const int n_casts = BOUNCE ? io.bounce_casts : 1;
+    if (BOUNCE) for (unsigned k = lane; k < 2u * (unsigned)kBounceMaxCasts; k += 64) C_rays[k] = 0u;
     constexpr uint32_t F_NX = 1u << 27, F_NY = 1u << 28, F_NZ = 1u << 29;   // direction component < 0 (Voxel_Grid.cs:589-632)
     constexpr uint32_t F_MOVED = 1u << 30;                                   // origin clipped to OBox: t_start in the scratch
     constexpr uint32_t F_HIT = 1u << 31;                                     // a hit is pending (tmin, point, polygon in the scratch)
@@ -117,6 +134,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     const double fct = (double)ct;
     // wave-uniform queue state
     unsigned hW = 0, nW = 0, hC = 0, nC = 0, hE = 0, nE = 0, hP = 0, nP = 0, hF = 0, nF = S;
+    unsigned hR = 0, nR = 0;            // BOUNCE: slots whose hit stands and whose ray goes on to its next cast
     auto push = [&](uint8_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
         const unsigned long long m = __ballot(flag);
         if (flag) Q[(head + cnt + (unsigned)__popcll(m & lane_lt)) & SM] = (uint8_t)slot;
@@ -179,6 +197,62 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         tMaxZ = sz ? nZ : tMaxZ;                                                                 \
     }
 
+    // ---- per-ray set-up into a slot: Voxel_Grid.cs:563-632 (a new ray of the batch; BOUNCE: also a reflected ray, rearm phase)
+    auto arm = [&](unsigned slot, unsigned ray, V3 o, const V3 d, bool& to_walk, bool& to_cull, bool& freed) {
+        bool alive = true, moved = false;
+        double t_start = 0;
+        double fx = floor((o.x - g.omin[0]) / g.vd[0]);
+        double fy = floor((o.y - g.omin[1]) / g.vd[1]);
+        double fz = floor((o.z - g.omin[2]) / g.vd[2]);
+        bool inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
+        if (!inside) {
+            if (!aabb_clip_move(g.omin, g.omax, o, d, t_start)) {
+                alive = false;
+            } else {
+                moved = true;
+                if (writeback) { io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z; }
+                fx = floor((o.x - g.omin[0] + d.x * 1E-6) / g.vd[0]);
+                fy = floor((o.y - g.omin[1] + d.y * 1E-6) / g.vd[1]);
+                fz = floor((o.z - g.omin[2] + d.z * 1E-6) / g.vd[2]);
+                inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
+                if (!inside) alive = false;
+            }
+        }
+        if (alive) {
+            const int X = (int)fx, Y = (int)fy, Z = (int)fz;
+            const int cell = (X * ct + Y) * ct + Z;
+            double tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ;
+            if (d.x < 0) { tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
+            else         { tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
+            if (d.y < 0) { tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
+            else         { tMaxY = (voxel_hi(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * 1.0; }
+            if (d.z < 0) { tMaxZ = (voxel_lo(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * -1.0; }
+            else         { tMaxZ = (voxel_hi(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * 1.0; }
+            L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
+            L_tdx[slot] = tDeltaX; L_tdy[slot] = tDeltaY; L_tdz[slot] = tDeltaZ;
+            L_ray[slot] = ray;
+            L_xyzf[slot] = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (d.x < 0 ? F_NX : 0u) | (d.y < 0 ? F_NY : 0u) |
+                           (d.z < 0 ? F_NZ : 0u) | (moved ? F_MOVED : 0u);
+            L_d1[slot] = -1;
+            // the ray's scratch is its event slot (see the header).  Nothing is written at set-up: "no hit pending" is the
+            // absence of F_HIT in the slot flags (round 4: one store and one visit of the record less per ray) -- except
+            // for a ray that AABB.Intersect moved, whose t_start waits in the u field
+            if (moved) reinterpret_cast<double*>(&io.out[ray])[1] = t_start;
+            unsigned q = 0, qe = 0;
+            int idx = -1, nexti = -1;
+            if (occupied(X, Y, Z, cell)) {
+                const CellRec c = g.cells[cell];
+                q = c.start; qe = c.start + c.count; idx = c.i0; nexti = c.i1;
+            }
+            L_q[slot] = q; L_qe[slot] = qe; L_idx[slot] = idx; L_nexti[slot] = nexti;
+            to_cull = q < qe;
+            to_walk = !to_cull;
+        } else {
+            store_miss(ray);
+            freed = true;
+        }
+    };
+
     // developer timeline (flag 0x2000, tools/timeline_prof.py): per wave {start, tickets dry, end, rounds} on the 100 MHz clock
     auto timeline = [&](int slot, unsigned long long v) {
         if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
@@ -192,9 +266,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     // turn into a wave that does not finish (rays it left behind would keep their scratch values and fail every parity test)
 #define HARE_K1Q_PHASE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define HARE_K1Q_TAIL_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define HARE_K1Q_FINAL_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+    unsigned helped = 0;
+    unsigned long long t_coop = 0;
+    for (;;) {          // (BOUNCE: the cooperative tail can send a ray back to the pool for its next cast)
     for (unsigned round = 0; round < (1u << 24); ++round) {
         // ------------------------------------------------------------------ set-up of new rays into free slots
-        if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP == 0)) {
+        if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP + nR == 0)) {
             if (cn >= ce) {
                 unsigned base = 0;
                 const unsigned dyn = (unsigned)io.ticket_rays;
@@ -216,67 +294,16 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 cn += m;
                 bool to_walk = false, to_cull = false, freed = false;
                 if (act) {
-                    // ---------------- per-ray set-up: Voxel_Grid.cs:563-632
                     const RayRec r = io.rays[ray];
-                    V3 o = {r.x, r.y, r.z};
+                    const V3 o = {r.x, r.y, r.z};
                     const V3 d = {r.dx, r.dy, r.dz};
-                    bool alive = true, moved = false;
-                    double t_start = 0;
                     if ((io.flags & SHOOT_RETIRED_RAYS) && io.excl1 && io.excl1[ray] == -2) {   // retired by the bounce loop: miss, not counted
-                        alive = false;
-                    } else {
-                        nrays++;
-                        double fx = floor((o.x - g.omin[0]) / g.vd[0]);
-                        double fy = floor((o.y - g.omin[1]) / g.vd[1]);
-                        double fz = floor((o.z - g.omin[2]) / g.vd[2]);
-                        bool inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
-                        if (!inside) {
-                            if (!aabb_clip_move(g.omin, g.omax, o, d, t_start)) {
-                                alive = false;
-                            } else {
-                                moved = true;
-                                if (writeback) { io.rays[ray].x = o.x; io.rays[ray].y = o.y; io.rays[ray].z = o.z; }
-                                fx = floor((o.x - g.omin[0] + d.x * 1E-6) / g.vd[0]);
-                                fy = floor((o.y - g.omin[1] + d.y * 1E-6) / g.vd[1]);
-                                fz = floor((o.z - g.omin[2] + d.z * 1E-6) / g.vd[2]);
-                                inside = (fx >= 0.0 && fx < fct) & (fy >= 0.0 && fy < fct) & (fz >= 0.0 && fz < fct);
-                                if (!inside) alive = false;
-                            }
-                        }
-                        if (alive) {
-                            const int X = (int)fx, Y = (int)fy, Z = (int)fz;
-                            const int cell = (X * ct + Y) * ct + Z;
-                            double tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ;
-                            if (d.x < 0) { tMaxX = (voxel_lo(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * -1.0; }
-                            else         { tMaxX = (voxel_hi(X, g.vd[0], g.omin[0]) - o.x) / d.x; tDeltaX = g.vd[0] / d.x * 1.0; }
-                            if (d.y < 0) { tMaxY = (voxel_lo(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * -1.0; }
-                            else         { tMaxY = (voxel_hi(Y, g.vd[1], g.omin[1]) - o.y) / d.y; tDeltaY = g.vd[1] / d.y * 1.0; }
-                            if (d.z < 0) { tMaxZ = (voxel_lo(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * -1.0; }
-                            else         { tMaxZ = (voxel_hi(Z, g.vd[2], g.omin[2]) - o.z) / d.z; tDeltaZ = g.vd[2] / d.z * 1.0; }
-                            L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
-                            L_tdx[slot] = tDeltaX; L_tdy[slot] = tDeltaY; L_tdz[slot] = tDeltaZ;
-                            L_ray[slot] = ray;
-                            L_xyzf[slot] = (uint32_t)X | ((uint32_t)Y << 9) | ((uint32_t)Z << 18) | (d.x < 0 ? F_NX : 0u) | (d.y < 0 ? F_NY : 0u) |
-                                           (d.z < 0 ? F_NZ : 0u) | (moved ? F_MOVED : 0u);
-                            L_d1[slot] = -1;
-                            // the ray's scratch is its event slot (see the header).  Nothing is written at set-up: "no hit pending" is the
-                            // absence of F_HIT in the slot flags (round 4: one store and one visit of the record less per ray) -- except
-                            // for a ray that AABB.Intersect moved, whose t_start waits in the u field
-                            if (moved) reinterpret_cast<double*>(&io.out[ray])[1] = t_start;
-                            unsigned q = 0, qe = 0;
-                            int idx = -1, nexti = -1;
-                            if (occupied(X, Y, Z, cell)) {
-                                const CellRec c = g.cells[cell];
-                                q = c.start; qe = c.start + c.count; idx = c.i0; nexti = c.i1;
-                            }
-                            L_q[slot] = q; L_qe[slot] = qe; L_idx[slot] = idx; L_nexti[slot] = nexti;
-                            to_cull = q < qe;
-                            to_walk = !to_cull;
-                        }
-                    }
-                    if (!alive) {
                         store_miss(ray);
                         freed = true;
+                    } else {
+                        nrays++;
+                        if (BOUNCE) { L_cast[slot] = 0; atomicAdd(&C_rays[0], 1u); }
+                        arm(slot, ray, o, d, to_walk, to_cull, freed);
                     }
                 }
                 push(Q_walk, hW, nW, to_walk, slot);
@@ -284,15 +311,67 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 push(Q_free, hF, nF, freed, slot);
             }
         }
+#ifndef HARE_K1Q_REARM_MIN
+#define HARE_K1Q_REARM_MIN 8      // BOUNCE: reflect + set up again when this many rays wait for it (or nothing else can run, or the launch drains); swept
+                                  // 1 / 8 / 16 / 32 / 48: C5 shard 675 / 677 / 664 / 610 / 520 Mcasts/s -- a ray parked in this queue is a slot of the pool not working
+#endif
+        if (BOUNCE && nR > 0 && (nR >= (unsigned)HARE_K1Q_REARM_MIN || nW + nC + nE + nP == 0 || drained)) {
+            // -------------------------------------------------------------- BOUNCE: the hit stands -- next cast of the same ray
+            HARE_K1Q_PHASE_FENCE();      // the confirmed event in the scratch, before it is read here
+            bool act;
+            const unsigned slot = pop(Q_rearm, hR, nR, act);
+            bool to_walk = false, to_cull = false, freed = false;
+            if (act) {
+                const unsigned ray = L_ray[slot];
+                const int c = (int)L_cast[slot];
+                double* const sc = reinterpret_cast<double*>(&io.out[ray]);
+                const double hx = sc[3], hy = sc[4], hz = sc[5];                 // X_Point of the hit that stands
+                const double w6 = sc[6];
+                const int pid = __double2loint(w6);
+                if (io.out_all) {                                               // every cast's event, cast-major
+                    double* const dst = reinterpret_cast<double*>(&io.out_all[(int64_t)c * io.out_stride + ray]);
+                    const double t0 = sc[0], u0 = sc[1], v0 = sc[2];
+                    __builtin_nontemporal_store(t0, dst + 0); __builtin_nontemporal_store(u0, dst + 1); __builtin_nontemporal_store(v0, dst + 2);
+                    __builtin_nontemporal_store(hx, dst + 3); __builtin_nontemporal_store(hy, dst + 4); __builtin_nontemporal_store(hz, dst + 5);
+                    __builtin_nontemporal_store(w6, dst + 6);
+                }
+                if (c + 1 < n_casts) {
+                    // hare_reflect's expressions: o' = X_Point, d' = d - (2 * (d . n)) * n, the next cast excludes the polygon just left
+                    const RayRec r = io.rays[ray];
+                    const PolyRec& p = g.polys[pid];
+                    const double dn = dot3(r.dx, r.dy, r.dz, p.n[0], p.n[1], p.n[2]);
+                    const double k = 2.0 * dn;
+                    RayRec nr;
+                    nr.x = hx; nr.y = hy; nr.z = hz;
+                    nr.dx = r.dx - k * p.n[0];
+                    nr.dy = r.dy - k * p.n[1];
+                    nr.dz = r.dz - k * p.n[2];
+                    io.rays[ray] = nr;
+                    const_cast<int32_t*>(io.excl1)[ray] = pid;
+                    if (io.excl2) const_cast<int32_t*>(io.excl2)[ray] = -1;
+                    L_cast[slot] = (uint8_t)(c + 1);
+                    atomicAdd(&C_rays[c + 1], 1u);
+                    nrays++;
+                    const V3 o2 = {nr.x, nr.y, nr.z}, d2 = {nr.dx, nr.dy, nr.dz};
+                    arm(slot, ray, o2, d2, to_walk, to_cull, freed);
+                } else {
+                    freed = true;                                               // its last cast: the event is where it belongs
+                }
+            }
+            push(Q_walk, hW, nW, to_walk, slot);
+            push(Q_cull, hC, nC, to_cull, slot);
+            push(Q_free, hF, nF, freed, slot);
+        }
         {
-            const unsigned left = nW + nC + nE + nP;
+            const unsigned left = nW + nC + nE + nP + nR;
             if (drained) {
                 if (left == 0) break;
                 // down to the last rays: one or two at once; a handful when they have outlived the others by HARE_K1Q_COOP_PATIENCE
                 // rounds (heavy rays) -- from here on the whole wave traces them one after the other (voxel_coop.hip)
-                if (coop && (left <= (unsigned)HARE_K1Q_COOP_NOW || (left <= (unsigned)HARE_K1Q_COOP_MAX && tail_rounds >= (unsigned)HARE_K1Q_COOP_PATIENCE))) break;
+                if (coop && nR == 0 && (left <= (unsigned)HARE_K1Q_COOP_NOW || (left <= (unsigned)HARE_K1Q_COOP_MAX && tail_rounds >= (unsigned)HARE_K1Q_COOP_PATIENCE))) break;
                 ++tail_rounds;
             } else if (left == 0) continue;
+            if (BOUNCE && nW + nC + nE + nP == 0) continue;              // only the rearm queue holds rays: its phase runs at the top of the round
         }
         ++rounds_done;
         if (__builtin_expect((io.flags & 0x1000u) != 0 && io.prof != nullptr, 0)) {
@@ -310,10 +389,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         // left, every non-empty phase runs each round, in the order a ray passes through them (walk -> cull -> exact ->
         // pend), so that a ray advances several phases per round: at the end of a launch latency is all that counts.
         const unsigned big = nW > nC ? nW : nC;
-        const bool tail = drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_TAIL;
+        const bool tail = drained && nW + nC + nE + nP + nR <= (unsigned)HARE_K1Q_TAIL;
         // ... and once the pool is down to a few rays, a ray's candidates are spread over several lanes (the wide cull below).  Both
         // conditions only ever go from false to true (no ray is set up after the tickets ran dry), which the wide cull relies on.
-        const bool wide = HARE_K1Q_WIDE_MAX > 0 && wide_on && drained && nW + nC + nE + nP <= (unsigned)HARE_K1Q_WIDE_MAX;
+        const bool wide = HARE_K1Q_WIDE_MAX > 0 && wide_on && drained && nW + nC + nE + nP + nR <= (unsigned)HARE_K1Q_WIDE_MAX;
         const int sel = (nE >= (unsigned)HARE_K1Q_EXACT_MIN || (big == 0 && nP == 0)) ? 0
                         : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
         HARE_K1Q_PHASE_FENCE();      // the set-up's scratch stores, before any phase reads them
@@ -852,7 +931,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 sc[1] = ((xf & F_MOVED) && (io.flags & SHOOT_SLIM_EVENTS)) ? tmin : 0.0;     // u: 0 as the reference returns it (see SHOOT_SLIM_EVENTS)
                 sc[2] = 0;
                 nhits++;
+                if (BOUNCE) atomicAdd(&C_hits[L_cast[slot]], 1u);
             }
+            const bool rearm = BOUNCE && freed && !exited;                 // the ray goes on to its next cast (or hands its event over): rearm phase
             if (exited) {
                 store_miss(ray);
                 freed = true;
@@ -871,18 +952,15 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             }
             push(Q_pend, hP, nP, walking, slot);
             push(Q_cull, hC, nC, to_cull, slot);
-            push(Q_free, hF, nF, freed, slot);
+            push(Q_free, hF, nF, freed && !rearm, slot);
+            if (BOUNCE) push(Q_rearm, hR, nR, rearm, slot);
         }
     }
-#undef HARE_K1Q_STEP
-#undef HARE_K1Q_PHASE_FENCE
-    unsigned helped = 0;
-    const unsigned long long t_coop = __builtin_amdgcn_s_memrealtime();       // developer timeline: when the pool rounds ended
+    t_coop = __builtin_amdgcn_s_memrealtime();       // developer timeline: when the pool rounds ended
     if (coop && nW + nC + nE + nP > 0) {
         // ---- the cooperative tail: what is left (at most HARE_K1Q_COOP_MAX rays, in whatever queue) is traced by the whole wave,
         // one ray after the other, from the state the pool left it in
         HARE_K1Q_TAIL_FENCE();
-#undef HARE_K1Q_TAIL_FENCE
         const uint8_t* const Qs[4] = {Q_walk, Q_cull, Q_exact, Q_pend};
         unsigned* const heads[4] = {&hW, &hC, &hE, &hP};
         unsigned* const cnts[4] = {&nW, &nC, &nE, &nP};
@@ -916,12 +994,30 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         ev.poly_id = pid;
                         ev.hit = 1;
                         nhits++;
+                        if (BOUNCE) atomicAdd(&C_hits[L_cast[slot]], 1u);
                     } else {
                         set_miss(ev);
                     }
-                    store_event_streaming(&io.out[ray], ev);
+                    if (BOUNCE && hit) io.out[ray] = ev;                         // read back by the rearm phase: plain stores, through the L1
+                    else store_event_streaming(&io.out[ray], ev);
+                    if (BOUNCE && hit) Q_rearm[(hR + nR) & SM] = (uint8_t)slot;  // the hit stands: on to the ray's next cast
                 }
+                if (BOUNCE && hit) nR += 1u;
             }
+        }
+    }
+    if (!BOUNCE || nR == 0) break;
+    HARE_K1Q_TAIL_FENCE();           // lane 0's rearm entries and events, before the rearm phase reads them
+    }
+#undef HARE_K1Q_PHASE_FENCE
+#undef HARE_K1Q_TAIL_FENCE
+    if (BOUNCE && io.ctr_casts) {
+        // rays started / hits per cast: this wave's share, added to the caller's per-cast blocks
+        HARE_K1Q_FINAL_FENCE();
+        if (lane < (unsigned)n_casts) {
+            const uint32_t r = C_rays[lane], h = C_hits[lane];
+            if (r) atomicAdd(&io.ctr_casts[(size_t)lane * CTR_WORDS + CTR_RAYS], (unsigned long long)r);
+            if (h) atomicAdd(&io.ctr_casts[(size_t)lane * CTR_WORDS + CTR_HITS], (unsigned long long)h);
         }
     }
     timeline(2, __builtin_amdgcn_s_memrealtime());
@@ -944,4 +1040,9 @@ __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_tri(Voxel
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_quad(VoxelArgs g, ShootIO io) { voxel_pool_body<true, false>(g, io); }
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_tri_g(VoxelArgs g, ShootIO io) { voxel_pool_body<false, true>(g, io); }
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_quad_g(VoxelArgs g, ShootIO io) { voxel_pool_body<true, true>(g, io); }
+// the whole specular bounce loop of every ray in one launch (BOUNCE, above): dynamic LDS = bitmap + waves x (kPoolWaveBytes + kPoolBounceExtra)
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_bounce_tri(VoxelArgs g, ShootIO io) { voxel_pool_body<false, false, true>(g, io); }
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_bounce_quad(VoxelArgs g, ShootIO io) { voxel_pool_body<true, false, true>(g, io); }
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_bounce_tri_g(VoxelArgs g, ShootIO io) { voxel_pool_body<false, true, true>(g, io); }
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_bounce_quad_g(VoxelArgs g, ShootIO io) { voxel_pool_body<true, true, true>(g, io); }
 }

@@ -325,8 +325,25 @@ class Spatial_Partition:
         """The gfx950 kernel a shoot of n rays launches (what rocprofv3 will list)."""
         return (lib.hare_shoot_kernel_name(self._h, self._kind, int(top_index), int(n), int(flags)) or b"").decode()
 
+    def bounce_kernel_name(self, n: int, bounces: int, top_index: int = 0) -> str:
+        """The fused kernel hare_bounce_device launches for n rays, or "" when it runs a launch per cast."""
+        if bounces > 16:
+            return ""
+        name = self.kernel_name(n, top_index, flags=32)          # HARE_SHOOT_BOUNCE_LOOP
+        return name if "bounce" in name else ""
+
     def reflect_device(self, n: int, d_rays: int, d_events: int, d_excl_out: int, top_index: int = 0, stream: int = 0):
         check(lib.hare_reflect_device(self._h, int(top_index), int(n), d_rays, d_events, d_excl_out, stream or None))
+
+    def bounce_device(self, n: int, d_rays: int, bounces: int, d_work: int, d_events_last: int = 0, d_events_all: int = 0,
+                      top_index: int = 0, d_excl1: int = 0, d_excl2: int = 0, d_counters: int = 0, d_counters_per_cast: int = 0,
+                      stream: int = 0, flags: int = 0):
+        """The bounce loop on device buffers (hare_bounce_device): `bounces` casts per ray, reflection + exclusion of the polygon left
+        between them; d_rays is read and overwritten, d_work is 2 n int32 of scratch.  One launch for a Voxel_Grid where the pool
+        kernel serves, else a launch per cast; stream-ordered, no host synchronisation."""
+        check(lib.hare_bounce_device(self._h, self._kind, int(top_index), int(n), d_rays or None, d_excl1 or None, d_excl2 or None,
+                                     int(bounces), int(flags), d_work or None, d_events_all or None, d_events_last or None,
+                                     d_counters or None, d_counters_per_cast or None, stream or None))
 
 
 class Voxel_Grid(Spatial_Partition):

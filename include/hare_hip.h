@@ -69,6 +69,8 @@ extern "C" {
                                        /* HARE_SHOOT_WRITEBACK_ORIGIN (HARE_E_INVALID): hare_expand_events redoes the origin move from    */
                                        /* the rays as they were passed in, which the write-back would have overwritten                   */
 
+#define HARE_SHOOT_BOUNCE_LOOP 32u     /* hare_shoot_kernel_name only: name the kernel hare_bounce_device (<= 16 casts) launches for n rays           */
+
 /* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
  * only serve the reference's mailbox pool and are not needed here. 48 bytes. */
 typedef struct hare_ray {
@@ -173,6 +175,7 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
  *   "octree_kernel"   0: the library's rule (K2g below 655k rays on a 256-CU part, K2p + tail above), 1: hare_octree_persist (K2p, one lane
  *                     per ray), 2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray)
+ *   "bounce_fused"    1: hare_bounce_device / hare_bounce_batch (last cast's events only) run a Voxel_Grid's bounce loop as ONE launch where they can; 0 (default): a launch per cast
  *   "octree_tail"     what finishes the rays K2p's waves still walk at the end of a launch: 2 (default) hare_octree_group_tail (eight lanes per
  *                     ray, every ray a wave holds 32 rounds after its tickets ran dry), 1 hare_octree_tail (a wave per ray, a wave's last 16), 0 nothing
  *   "k2p_tail_max", "k2p_tail_patience"   the hand-over rule (0 / -1: the library's)
@@ -321,6 +324,27 @@ HARE_API int hare_occluded_batch_sharded(hare_scene *const *scenes, int32_t n_sc
  * Device pointers, stream-ordered. */
 HARE_API int hare_reflect_device(hare_scene *s, int32_t top_index, int64_t n, void *d_rays, const void *d_events,
                         void *d_excl_out, void *stream);
+
+/* ---- the bounce loop on DEVICE buffers, stream-ordered, no host synchronisation (harness-defined like hare_reflect_device) ----
+ * `bounces` casts per ray: Shoot, reflect about Model[top].Normal(Poly_id) (Hare_Geometry_Polygons.cs:161-171), Shoot again with
+ * poly_origin1 = the polygon just hit (Spatial_Partition.cs:33; Voxel_Grid.cs:351,477); a ray that misses is retired (its later
+ * events are the miss record X_Event(), it is not counted).
+ * By default `bounces` x (shoot + reflect) launches, retired rays skipped.  With the scene option "bounce_fused" = 1, a Voxel_Grid
+ * wherever the pool kernel serves a batch, and bounces <= 16: ONE persistent launch (hare_voxel_bounce_*) in which every ray runs
+ * through its casts on its own -- rays are independent across casts too, so no cast waits for the slowest ray of the one before.
+ * Results are identical either way; measured on MI355X the single launch gains 2.5 % in the 100k-triangle hall and loses up to
+ * 10 % in the 1M-triangle cathedral, hence the default.
+ *   d_rays               n rays: READ AND OVERWRITTEN (work array; every ray's last reflection remains)
+ *   d_excl1 / d_excl2    nullable, read only: poly_origin1 / poly_origin2 of cast 0 (a negative index excludes nothing)
+ *   d_work               scratch, 2 n int32
+ *   d_events_all         nullable: bounces x n X_Events, cast-major
+ *   d_events_last        the n X_Events of the last cast (nullable when d_events_all is given)
+ *   d_counters           nullable: totals, ACCUMULATED (rays = casts with a live ray, hits)
+ *   d_counters_per_cast  nullable: `bounces` hare_counters, ACCUMULATED (rays = rays alive in that cast, hits = rays that live on)
+ *   flags                HARE_SHOOT_COUNT_WORK / HARE_SHOOT_SIMPLE_KERNEL only (either forces the launch per cast) */
+HARE_API int hare_bounce_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays, const void *d_excl1,
+                                const void *d_excl2, int32_t bounces, uint32_t flags, void *d_work, void *d_events_all,
+                                void *d_events_last, void *d_counters, void *d_counters_per_cast, void *stream);
 
 /* ---- the whole bounce loop behind one call, from host buffers (harness-defined like hare_reflect_device) ----
  * What a Pachyderm-style caller does per ray with the reference -- Shoot, reflect about Model[top].Normal(Poly_id)
