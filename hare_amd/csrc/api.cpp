@@ -1122,6 +1122,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.items = (const int32_t*)s.d_kd_items;
         g.n_nodes = (int32_t)s.kd.nodes.size();
         g.max_depth = s.kd.depth_reached;
+        g.cull = (const unsigned char*)s.d_cull[top];
+        g.cf = s.cull_frames[(size_t)top];
         hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only).f;
         if (!f) {
             set_error("hare_shoot: kd-tree kernel missing from code object");

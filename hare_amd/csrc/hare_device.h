@@ -191,6 +191,8 @@ struct KdArgs {
     const int32_t* items;
     int32_t n_nodes;
     int32_t max_depth;
+    const unsigned char* cull; // as in VoxelArgs (device kernels; null on the host)
+    CullFrame cf;
 };
 
 struct BuildArgs {             // Voxel_Grid construction kernels (build_kernels.hip)

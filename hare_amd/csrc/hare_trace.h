@@ -281,11 +281,18 @@ HARE_HD void trace_octree(const OctreeArgs& g, const OctFrames& fr, int tid, int
 // KDTree.Shoot: KDTree.cs:204-361.  Both children of every interior node are pushed (:355-356), so
 // every leaf is visited; the split-plane logic only fixes the ORDER, which decides
 // exact-t ties.  Explicit node stack in LDS, [slot][lane].
-template <bool COUNT>
+// CULL (device only, round 4): the conservative FP32 pre-cull in front of the exact test, as in every other kernel -- the reference's
+// query visits EVERY leaf, so all P polygons are candidates of every ray and nearly all of them fail: a candidate the cull rejects
+// is one the exact test is certain to reject, results unchanged.
+template <bool COUNT, bool CULL = false>
 HARE_HD void trace_kdtree(const KdArgs& g, int* stack, int tid, int nt, const V3& o, const V3& d, int e1, int e2,
                                              XEventRec& ev, Work& w)
 {
     set_miss(ev);
+#if defined(__HIPCC__)
+    CullRay cray = {};
+    if (CULL) cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
+#endif
     double closestT = kDblMax;
     int sp = 0;
     stack[tid] = 0;
@@ -303,6 +310,9 @@ HARE_HD void trace_kdtree(const KdArgs& g, int* stack, int tid, int nt, const V3
                 const int i = g.items[q];
                 if (i == e1 || i == e2) continue;                 // :221
                 if (COUNT) w.tests++;
+#if defined(__HIPCC__)
+                if (CULL && cull_test(g, cray, cull_load(g, i))) continue;
+#endif
                 const PolyRec& p = g.polys[i];
                 double t, u, v;
                 const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;

@@ -1224,7 +1224,7 @@ __device__ __forceinline__ void kdtree_shoot_body(const KdArgs& g, const ShootIO
         const int e1 = io.excl1 ? io.excl1[i] : -1;
         const int e2 = io.excl2 ? io.excl2[i] : -1;
         live = !(e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS));
-        if (live) trace_kdtree<COUNT>(g, stack, threadIdx.x, blockDim.x, o, d, e1, e2, ev, w);
+        if (live) trace_kdtree<COUNT, !COUNT>(g, stack, threadIdx.x, blockDim.x, o, d, e1, e2, ev, w);     // the counting build runs the reference's walk as it is
         if (io.out) io.out[i] = ev;
         if (io.occluded) {
             const bool occ = ev.hit != 0 && (io.tmax == nullptr || ev.t < io.tmax[i]);
