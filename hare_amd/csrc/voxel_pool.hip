@@ -135,6 +135,12 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     // wave-uniform queue state
     unsigned hW = 0, nW = 0, hC = 0, nC = 0, hE = 0, nE = 0, hP = 0, nP = 0, hF = 0, nF = S;
     unsigned hR = 0, nR = 0;            // BOUNCE: slots whose hit stands and whose ray goes on to its next cast
+#ifdef HARE_K1Q_STATS                   // developer build (tools/k1q_stats.py): executions and active lanes of every phase; lane 0 counts
+    unsigned long long kq_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kq_l[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kq_steps = 0;
+#define K1Q_STAT(i, act) { kq_n[i]++; kq_l[i] += (unsigned long long)__popcll(__ballot(act)); }
+#else
+#define K1Q_STAT(i, act)
+#endif
     auto push = [&](uint8_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
         const unsigned long long m = __ballot(flag);
         if (flag) Q[(head + cnt + (unsigned)__popcll(m & lane_lt)) & SM] = (uint8_t)slot;
@@ -287,6 +293,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             if (m > nF) m = nF;
             if (m > 0) {
                 const bool act = lane < m;
+                K1Q_STAT(0, act)
                 const unsigned slot = Q_free[(hF + (act ? lane : 0u)) & SM];
                 hF = (hF + m) & SM;
                 nF -= m;
@@ -397,6 +404,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         : ((nP >= (unsigned)HARE_K1Q_PEND_MIN || big == 0) ? 1 : (nC >= nW ? 2 : 3));
         HARE_K1Q_PHASE_FENCE();      // the set-up's scratch stores, before any phase reads them
         if (HARE_K1Q_WIDE_WALK && wide && nW > 0) {
+            K1Q_STAT(5, true)
             // -------------------------------------------------------------- the WIDE walk of the drain: several occupied voxels ahead
             // What is left at the very end of a launch are rays that cross many occupied voxels whose candidates all fail the pre-cull:
             // walk -> cull -> walk ..., one voxel per round, three dependent round trips each (tools/round_trace.py: the latest waves
@@ -530,6 +538,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // -------------------------------------------------------------- DDA walk over empty voxels (no hit pending)
             bool act;
             const unsigned slot = pop(Q_walk, hW, nW, act);
+            K1Q_STAT(1, act)
             bool walking = act;
             double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0;
             int X = 0, Y = 0, Z = 0, dx1 = 1, dy1 = 1, dz1 = 1;
@@ -550,6 +559,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             for (int k = 0; k < walk_steps; ++k) {
                 const unsigned long long wm = __ballot(walking);
                 if (wm == 0 || (k > 0 && __popcll(wm) < walk_min)) break;
+#ifdef HARE_K1Q_STATS
+                kq_n[7]++; kq_l[7] += (unsigned long long)__popcll(wm);
+#endif
                 if (walking) {
                     HARE_K1Q_STEP();
                     const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
@@ -579,6 +591,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         }
         HARE_K1Q_PHASE_FENCE();
         if (wide && nC > 0) {
+            K1Q_STAT(6, true)
             // -------------------------------------------------------------- the WIDE pre-cull of the drain
             // The launch ends with its longest chains, and in the drain those are list scans: a ray in a voxel with a hundred entries
             // needs a dozen cull tasks of eight candidates, each task five dependent round trips (tools/round_trace.py: ~9 us per round,
@@ -658,6 +671,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // -------------------------------------------------------------- FP32 pre-cull, 2 x CULL_PAIRS candidates per ray at most
             bool act;
             const unsigned slot = pop(Q_cull, hC, nC, act);
+            K1Q_STAT(2, act)
             bool to_walk = false, to_cull = false, to_exact = false, to_pend = false;
             int share_idx = -1;
             if (act) {
@@ -812,6 +826,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // -------------------------------------------------------------- exact FP64 test of one candidate per ray
             bool act;
             const unsigned slot = pop(Q_exact, hE, nE, act);
+            K1Q_STAT(3, act)
             bool to_walk = false, to_cull = false, to_pend = false;
             if (act) {
                 const unsigned ray = L_ray[slot];
@@ -882,6 +897,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // -------------------------------------------------------------- walk with a pending hit (Voxel_Grid.cs:705-759)
             bool act;
             const unsigned slot = pop(Q_pend, hP, nP, act);
+            K1Q_STAT(4, act)
             bool to_cull = false, freed = false;
             bool walking = act;
             double tMaxX = 0, tMaxY = 0, tMaxZ = 0, tDeltaX = 0, tDeltaY = 0, tDeltaZ = 0, tmin = 0, hx = 0, hy = 0, hz = 0;
@@ -1020,6 +1036,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             if (h) atomicAdd(&io.ctr_casts[(size_t)lane * CTR_WORDS + CTR_HITS], (unsigned long long)h);
         }
     }
+#ifdef HARE_K1Q_STATS
+    if (lane == 0 && io.prof) {
+        for (int k = 0; k < 8; ++k) { atomicAdd(&io.prof[2 * k], kq_n[k]); atomicAdd(&io.prof[2 * k + 1], kq_l[k]); }
+        atomicAdd(&io.prof[16], (unsigned long long)rounds_done);
+    }
+    (void)kq_steps;
+#endif
     timeline(2, __builtin_amdgcn_s_memrealtime());
     timeline(3, (rounds_done & 0xFFFFu) | ((unsigned long long)(helped & 0xFFu) << 16) | (t_coop << 24));
     if (__builtin_expect((io.flags & 0x3000u) == 0x3000u && io.prof != nullptr, 0)) {
