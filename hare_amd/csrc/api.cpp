@@ -789,6 +789,18 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
         }
     }
     // ---- a launch per cast
+    auto sum_counters = [&](int sign) -> int {
+        if (!(d_ctr_casts && d_ctr)) return HARE_OK;
+        if (!M.counters_sum) {
+            set_error("hare_bounce: hare_counters_sum missing from code object");
+            return HARE_E_STATE;
+        }
+        const void* pc = d_ctr_casts;
+        int cc = casts;
+        void* a[] = {&pc, &cc, &d_ctr, &sign};
+        return launch(H, M.counters_sum, 1, 64, 0, st, a);
+    };
+    if (int rc = sum_counters(-1)) return rc;            // the per-cast blocks are accumulated into: the totals get what THIS loop adds
     for (int32_t c = 0; c < casts; ++c) {
         hare_xevent* out_c = all ? all + (size_t)c * (size_t)n : last;
         void* ctr_c = d_ctr_casts ? (void*)((hare_counters*)d_ctr_casts + c) : d_ctr;
@@ -804,16 +816,7 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
         }
     }
     if (all && d_last) HIP_TRY(H->MemcpyAsync(d_last, all + (size_t)(casts - 1) * (size_t)n, (size_t)n * sizeof(hare_xevent), hipMemcpyDeviceToDevice, st));
-    if (d_ctr_casts && d_ctr) {
-        if (!M.counters_sum) {
-            set_error("hare_bounce: hare_counters_sum missing from code object");
-            return HARE_E_STATE;
-        }
-        const void* pc = d_ctr_casts;
-        int cc = casts;
-        void* a[] = {&pc, &cc, &d_ctr};
-        if (int rc = launch(H, M.counters_sum, 1, 64, 0, st, a)) return rc;
-    }
+    if (int rc = sum_counters(+1)) return rc;
     return HARE_OK;
 }
 

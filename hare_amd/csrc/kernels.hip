@@ -1454,14 +1454,16 @@ __global__ __launch_bounds__(256) void hare_events_pack_slim(const XEventRec* ev
 
 // A9 occlusion predicate (harness-defined): a ray is occluded when its CLOSEST hit -- the
 // X_Event the shoot kernel just wrote, so the closest-hit oracle pins it -- lies before t_max.  t_max null: any hit.
-// per-cast counter blocks of a bounce loop summed into the caller's totals (the launch-per-cast path of hare_bounce_device)
-__global__ __launch_bounds__(64) void hare_counters_sum(const unsigned long long* per_cast, int casts, unsigned long long* total)
+// per-cast counter blocks of a bounce loop summed into the caller's totals (the launch-per-cast path of hare_bounce_device).  Both are
+// ACCUMULATED by contract, so the call subtracts the blocks as they stand before the loop (sign = -1) and adds them after it (sign = +1):
+// the totals move by what the loop added (arithmetic modulo 2^64)
+__global__ __launch_bounds__(64) void hare_counters_sum(const unsigned long long* per_cast, int casts, unsigned long long* total, int sign)
 {
     const int w = threadIdx.x;
     if (w >= CTR_WORDS) return;
     unsigned long long s = 0;
     for (int c = 0; c < casts; ++c) s += per_cast[(size_t)c * CTR_WORDS + w];
-    if (s) atomicAdd(&total[w], s);
+    if (s) atomicAdd(&total[w], sign < 0 ? (0ull - s) : s);
 }
 
 __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const double* tmax, int32_t* occluded, int64_t n)

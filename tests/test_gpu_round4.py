@@ -105,6 +105,24 @@ def test_more_casts_than_the_fused_kernel_takes_and_the_trees_fall_back_to_a_lau
     g.set_option("bounce_fused", 1)
     allc, last, pc, tot = bounce_on_device(g, rays, 20)                     # 20 > 16 casts: launch per cast even where the single launch is asked for
     assert allc.tobytes() == ref.tobytes() and pc == rc
+    # counters are ACCUMULATED, per cast and in total, on both paths: two calls into the same blocks give twice the counts
+    import torch
+    for fused in (1, 0):
+        g.set_option("bounce_fused", fused)
+        ref5, rc5 = oracle_bounce_loop(po, To, o, rays, 5)
+        d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+        d_pc = torch.zeros(8 * 5, dtype=torch.int64, device="cuda")
+        d_work = torch.zeros(2 * len(rays), dtype=torch.int32, device="cuda")
+        d_last = torch.zeros(len(rays) * 56, dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            d_r = torch.from_numpy(rays).cuda()
+            g.bounce_device(len(rays), d_r.data_ptr(), 5, d_work.data_ptr(), d_events_last=d_last.data_ptr(), d_counters=d_ctr.data_ptr(),
+                            d_counters_per_cast=d_pc.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        pc = d_pc.cpu().numpy().reshape(5, 8)
+        assert [(int(r[0]), int(r[1])) for r in pc] == [(2 * c["rays"], 2 * c["hits"]) for c in rc5], fused
+        assert (int(d_ctr[0]), int(d_ctr[1])) == (2 * sum(c["rays"] for c in rc5), 2 * sum(c["hits"] for c in rc5)), fused
+    g.set_option("bounce_fused", 0)
     for part, orc in ((H.Octree([T], 4, 8), po.Octree([To], 4, 8)), (H.KDTree([T], 6, 8), po.KDTree([To], 6, 8))):
         ref, rc = oracle_bounce_loop(po, To, orc, rays, 5)
         allc, last, pc, tot = bounce_on_device(part, rays, 5)
