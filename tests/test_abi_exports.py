@@ -93,3 +93,24 @@ def test_slim_events_with_origin_writeback_is_refused_before_anything_runs():
     rc = capi.lib.hare_shoot_batch(g._h, capi.KIND_VOXEL, 0, 64, rays.ctypes.data, None, None,
                                    capi.SHOOT_SLIM_EVENTS | capi.SHOOT_WRITEBACK_ORIGIN, out.ctypes.data, None)
     assert rc == capi.HARE_E_INVALID
+
+
+def test_bounce_device_without_a_gpu_fails_loudly_and_the_kernel_name_query_follows_the_option():
+    """hare_bounce_device has no CPU fallback (HARE_E_NODEVICE on a GPU-less box); hare_shoot_kernel_name with HARE_SHOOT_BOUNCE_LOOP names
+    the one-launch kernel only when the scene option asks for it (the default is a launch per cast)."""
+    m = H.scenes.shoebox()
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    n = 1 << 20
+    assert g.kernel_name(n) == "hare_voxel_pool_tri"
+    assert g.bounce_kernel_name(n, 8) == ""
+    g.set_option("bounce_fused", 1)
+    assert g.bounce_kernel_name(n, 8) == "hare_voxel_bounce_tri" and g.bounce_kernel_name(n, 17) == ""
+    assert g.kernel_name(n, flags=capi.SHOOT_BOUNCE_LOOP | capi.SHOOT_SIMPLE_KERNEL) == "hare_voxel_shoot_tri"
+    g.set_option("bounce_fused", 0)
+    if H.device_count() == 0:
+        rc = capi.lib.hare_bounce_device(g._h, capi.KIND_VOXEL, 0, 16, 1, None, None, 4, 0, 1, None, 1, None, None, None)
+        assert rc == capi.HARE_E_NODEVICE
+    o = H.Octree([H.Topology(m.verts, m.nverts)], 4, 8)
+    assert o.kernel_name(1000) == "hare_octree_group" and o.kernel_name(1 << 20) == "hare_octree_persist"      # the crossover rule, 256-CU part
+    o.set_option("octree_kernel", 1)
+    assert o.kernel_name(1000) == "hare_octree_persist"
