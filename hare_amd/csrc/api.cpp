@@ -94,6 +94,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_tail", &m->octree_tail},
         {"hare_octree_group", &m->octree_group},
         {"hare_octree_group_tail", &m->octree_group_tail},
+        {"hare_octree_dense", &m->octree_dense},
         {"hare_kdtree_shoot", &m->kdtree},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
@@ -486,7 +487,7 @@ void read_env_options(SceneOptions& o)
     o.dev = on(getenv("HARE_DEV"));
     if (!o.dev) return;            // everything below is a developer override: ignored unless the process opted in
     if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
-    if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : 0));
+    if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : (strcmp(k, "dense") == 0 ? 4 : 0)));
     if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
     if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
     if (const char* t = getenv("HARE_K2P_TAIL_MAX")) o.k2p_tail_max = atoi(t);
@@ -546,7 +547,7 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 //  * a cache-resident scene (the 100k-triangle hall at D = 16 ... 128, 18 - 52 MB): from two fills (786 432 rays) on a grid with one
 //    occupancy bit per voxel, three on a coarser bitmap (round 2, before the cooperative tails: three fills everywhere).
 // Both thresholds scale with the CU count of the device the scene lives on.
-enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctGroup, OctOccl,
+enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctDense, OctGroup, OctOccl,
                   KdSimple, KdCount, None };
 struct KernChoice {
     Kern k = Kern::None;
@@ -640,16 +641,24 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             const bool pool_wanted = s.opt.octree_kernel == 2 || (s.opt.octree_kernel == 0 && kOctreePoolDefault && n >= 65536);
             if (pool_wanted && have(&DeviceModule::octree_pool)) { pick(Kern::OctPool, "hare_octree_pool", &DeviceModule::octree_pool); return c; }
             // K2g (octree_group.hip): eight lanes per ray -- the production kernel for closest-hit batches of every size
-            // Octree.Shoot has two production kernels (measured on MI355X, hall, 8 levels; profiles/r04_experiments/k2_crossover.log):
-            //   K2g (octree_group.hip, eight lanes per ray): a ray lives < 100 us, so a launch has next to no drain -- 2.1x K2p at 65k rays,
-            //       1.4x at 262k, 1.1x at 524k -- but it spends 1.5x K2p's instructions per ray: steady state 330 Mrays/s against 560;
-            //   K2p (one lane per ray) + K2g-tail from 655 360 rays: 655k 298 / 299 (K2p+tail / K2g), 786k 342 / 306, 1M 396 / 312, 4M 563 / 331.
-            // Both thresholds scale with the CU count.
+            // Octree.Shoot has two production kernels (measured on MI355X, hall, 8 levels; profiles/r04_experiments/k2d_*.log, k2_crossover.log):
+            //   K2g (octree_group.hip, eight lanes per ray): a ray lives < 100 us, so a launch has next to no drain -- 2.1x K2p at 65k rays --
+            //       but it spends 1.5x K2p's instructions per ray: steady state 335 Mrays/s;
+            //   K2d (hare_octree_dense: one lane per ray, leaf entries spread densely over the wave, exact tests deferred) from 425 984 rays:
+            //       K2d / K2g Mrays/s at 262k 235 / 256, 393k 271 / 281, 524k 350 / 301, 786k 441 / 312, 1M 493 / 319, 4M 656 / 337.
+            //   K2p (hare_octree_persist) is K2d's predecessor: the A/B baseline (octree_kernel = 1) and the fall-back where K2d's LDS does not fit.
+            // The threshold scales with the CU count.
             const bool fits_p = (unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist);
             const bool group_ok = have(&DeviceModule::octree_group);
-            const int64_t group_below = (int64_t)cus * 2560;          // 655 360 rays on the 256-CU part
+            const int64_t group_below = (int64_t)cus * 1664;          // 425 984 rays on the 256-CU part
             const bool group_wanted = s.opt.octree_kernel == 3 || (s.opt.octree_kernel == 0 && (n < group_below || !fits_p));
             if (group_wanted && group_ok) { pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group); return c; }
+            // K2d (K2p's DENSE build) wherever it exists and its LDS fits; K2p (octree_kernel = 1) is the A/B baseline and the fall-back
+            if ((s.opt.octree_kernel == 4 || s.opt.octree_kernel == 0) && (unsigned)levels * 256u * 20u + kOctDenseExtra <= kLdsMax &&
+                have(&DeviceModule::octree_dense)) {
+                pick(Kern::OctDense, "hare_octree_dense", &DeviceModule::octree_dense);
+                return c;
+            }
             if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist)) {
                 pick(Kern::OctPersist, "hare_octree_persist", &DeviceModule::octree_persist);
                 return c;
@@ -1073,7 +1082,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             sub.n = m;
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
-            const unsigned plds = (unsigned)g.max_depth * 256u * 20u;   // 20 bytes x levels x 256 lanes per workgroup (interval + child word)
+            // 20 bytes x levels x 256 lanes per workgroup (interval + child word); the dense build: + its pending survivors and tables
+            const unsigned plds = (unsigned)g.max_depth * 256u * 20u + (f == M.octree_dense && f != nullptr ? kOctDenseExtra : 0u);
             unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = cus * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);
@@ -1085,7 +1095,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // The closest-hit kernel hands rays to a tail kernel (the occlusion build keeps them).  Rule: K2g-tail takes EVERY ray a wave
             // still walks when the tickets run dry (option "octree_tail" 2, the default); K2t takes a wave's last sixteen after 64 rounds (1)
             OctScratch oc;
-            if (closest_hit && s.opt.octree_tail != 0) {
+            // K2d hands nothing over by the rule: its dense passes put the whole wave on whatever entries its last rays hold, which is what
+            // a tail kernel was for (1M rays: no tail 485 Mrays/s, K2g-tail after 8 / 16 / 32 / 64 / 96 rounds 428 / 451 / 465 / 454 / 463, K2t 464)
+            const bool dense = f == M.octree_dense && f != nullptr;
+            if (closest_hit && s.opt.octree_tail != 0 && !(dense && s.opt.k2p_tail_max == 0 && s.opt.k2p_tail_patience < 0)) {
                 oc.tail_levels = g.max_depth;
                 oc.group_tail = s.opt.octree_tail == 2 && M.octree_group_tail != nullptr;
                 oc.tail_max = oc.group_tail ? 64 : kOctTailMax;
@@ -1099,7 +1112,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return launch_on_slot(s, H, f, pgrid, 256, plds, stream, sub, a, false, oc);
         };
         if (kc.k == Kern::OctGroup) return launch_group(0, n, st);
-        if (kc.k == Kern::OctPersist || kc.k == Kern::OctOccl) return launch_persist(kc.f, kc.k == Kern::OctPersist, 0, n, st);
+        if (kc.k == Kern::OctPersist || kc.k == Kern::OctDense || kc.k == Kern::OctOccl) return launch_persist(kc.f, kc.k != Kern::OctOccl, 0, n, st);
         void* args[] = {&g, &io};
         // one frame per interior level and lane in LDS: 24 bytes x levels x block
         const unsigned levels = (unsigned)g.max_depth;
@@ -2014,7 +2027,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"dev", &SceneOptions::dev, 0, 1},
         {"build_host", &SceneOptions::build_host, 0, 1},
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
-        {"octree_kernel", &SceneOptions::octree_kernel, 0, 3},
+        {"octree_kernel", &SceneOptions::octree_kernel, 0, 4},
         {"octree_tail", &SceneOptions::octree_tail, 0, 2},
         {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},
         {"k2p_tail_max", &SceneOptions::k2p_tail_max, 0, 64},

@@ -762,7 +762,45 @@ __device__ __forceinline__ double omin(double a, double b) { return (a < b || a 
 // t_max.  The reference pops the FAR children first and returns early as soon as a hit lies in front of the current leaf's
 // entry ("Octree - alt.cs":233), so a far leaf can end the query with a hit beyond t_max (not occluded) that a
 // walk without that leaf would replace by a nearer one (occluded): the flag would differ from the reference's closest hit.
-template <bool OCC>
+// Inclusive scans over the 64 lanes of a wave on the DPP network (row shifts inside rows of 16, then the two row broadcasts of gfx9):
+// six VALU instructions, no LDS -- __shfl_up is a ds_bpermute per step.  `ident` is what a lane without a source keeps.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int wave_dpp(int ident, int v) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_scan_add(int v)
+{
+    v += wave_dpp<0x111, 0xF>(0, v);      // row_shr:1
+    v += wave_dpp<0x112, 0xF>(0, v);      // row_shr:2
+    v += wave_dpp<0x114, 0xF>(0, v);      // row_shr:4
+    v += wave_dpp<0x118, 0xF>(0, v);      // row_shr:8
+    v += wave_dpp<0x142, 0xA>(0, v);      // row_bcast:15 into rows 1 and 3
+    v += wave_dpp<0x143, 0xC>(0, v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v)   // values >= -1
+{
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    v = mx(v, wave_dpp<0x111, 0xF>(-1, v));
+    v = mx(v, wave_dpp<0x112, 0xF>(-1, v));
+    v = mx(v, wave_dpp<0x114, 0xF>(-1, v));
+    v = mx(v, wave_dpp<0x118, 0xF>(-1, v));
+    v = mx(v, wave_dpp<0x142, 0xA>(-1, v));
+    v = mx(v, wave_dpp<0x143, 0xC>(-1, v));
+    return v;
+}
+
+// DENSE (hare_octree_dense, round 4): the same walk -- one lane owns a ray, frames in LDS, phase P as it is -- with the two things
+// K2g taught about Octree.Shoot applied to it:
+//   * a leaf's entries are not scanned by the owning lane, a pair per iteration at a third of the wave's lanes: ALL entries of all
+//     leaves the wave's lanes hold are spread densely over the 64 lanes (exclusive scan of the counts; an item finds its owner by a
+//     max-scan over segment starts in LDS and fetches the owner's pre-cull operands by ds_bpermute);
+//   * a survivor of the pre-cull does not park its lane: it is NOTED (polygon, the leaf's nodeTmin, the leaf's visit number; two per
+//     lane, in LDS) and the lane walks on with the closestT it has (stale = prunes less, never more); the exact tests run when
+//     enough lanes hold one, each lane on its own survivors in order, with the reference's rules replayed: entering a new leaf,
+//     skipped = hit && closestT <= leafTmin (:210); not skipped and t < closestT: accept (:225); accepted t <= leafTmin: return (:233).
+// Knobs (hare_device.h): HARE_K2D_PEND survivors a lane may hold before it has to wait for the exact phase; HARE_K2D_CAP list entries of one
+// leaf that go into one round's dense passes; HARE_K2D_EXACT_MIN lanes holding a survivor that make the exact phase run (or one that
+// cannot go on); HARE_K2D_STEPS pop steps per round.
+template <bool OCC, bool DENSE = false>
 __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
 {
     int tail_rounds = 0;
@@ -772,6 +810,11 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] interval start of the frame's node
     double* const fb = fa + (size_t)levels * nt;                    // [levels][nt] interval end
     int* const fpk = reinterpret_cast<int*>(fb + (size_t)levels * nt);   // [levels][nt] first_child << 8 | children still to pop (by cursor position)
+    // DENSE: behind the frames, the lanes' pending survivors and a 64-word table per wave (segment starts of the dense cull)
+    constexpr int P = HARE_K2D_PEND;
+    double* const pend_lca = reinterpret_cast<double*>(fpk + (size_t)levels * nt);     // [P][nt]
+    int2* const pend_pw = reinterpret_cast<int2*>(pend_lca + (size_t)P * nt);           // [P][nt] {polygon, leaf visit number}
+    int* const seg_mark = reinterpret_cast<int*>(pend_pw + (size_t)P * nt) + (tid >> 6) * 64;
 
     const int lane = tid & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -789,7 +832,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 #define HARE_K2P_REFILL 8
 #define HARE_K2P_EXACT 1
 #endif
-    const int STEPS = HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS, REFILL_MIN_IDLE = HARE_K2P_REFILL, EXACT_MIN_PARKED = HARE_K2P_EXACT;
+    const int STEPS = DENSE ? HARE_K2D_STEPS : HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS, REFILL_MIN_IDLE = DENSE ? HARE_K2D_REFILL : HARE_K2P_REFILL,
+              EXACT_MIN_PARKED = HARE_K2P_EXACT;
     const int RAY_CHUNK = io.static_rays > 0 ? io.static_rays : 128;      // the host sizes it by the batch (ShootIO::static_rays)
     const unsigned int n32 = (unsigned int)io.n;
     // static first chunk per wave, tickets of io.ticket_rays after those (as in the voxel kernel)
@@ -820,6 +864,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 #endif
     int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the polygons tested last (HARE_K2P_MAILBOX of them)
     unsigned int nhits = 0, nrays = 0;
+    int np = 0;                         // DENSE: survivors noted and not yet tested
+    int nvisit = 0, cur_visit = -1;      // DENSE: leaves visited (numbers the survivors' leaves); replay: the leaf of the last survivor replayed ...
+    bool cur_skip = false;              // ... and whether the reference skipped it
+    bool leaving = false;               // DENSE: the wave hands its rays over after one more exact phase
 #ifdef HARE_K2P_STATS                   // developer build (tools/k2p_stats.py): what a round of the loop is made of; lane 0 counts
     unsigned long long sp_round = 0, sp_alive = 0, sp_p = 0, sp_pl = 0, sp_c = 0, sp_cl = 0, sp_e = 0, sp_el = 0, sp_visit = 0;
 #define K2P_STAT(x) x
@@ -862,6 +910,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             q = nd.item_start; qe = nd.item_start + nd.item_count; leaf_ca = ca;
             idx = nd.pad;                                  // a leaf's first two list entries travel in its node record (OctNode, hare_device.h)
             nexti = -2 - nd.first_child;
+            if (DENSE) ++nvisit;
         } else {
             double nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];     // entry / exit parameter of the low (0) and high (1) child slab
             {
@@ -941,6 +990,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                     m0 = m1 = m2 = m3 = -1;
                     lvl = -1; q = 0; qe = 0;
+                    np = 0; nvisit = 0; cur_visit = -1; cur_skip = false;
                     if (e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {
                         finish();
                     } else {
@@ -976,7 +1026,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             // tickets dry and down to the last few rays, which have outlived the rest of the batch by HARE_K2P_TAIL_PATIENCE rounds:
             // they go to the cooperative tail kernel (octree_coop.hip), this wave ends
             if (!OCC && drained && io.oct_tail != nullptr) {
-                if (__popcll(am) <= io.oct_tail_max && tail_rounds >= io.oct_tail_patience) break;
+                if (__popcll(am) <= io.oct_tail_max && tail_rounds >= io.oct_tail_patience) {
+                    if (!DENSE || __ballot(alive && np > 0) == 0) break;
+                    leaving = true;                          // DENSE: the records hold no pending survivors -- one exact phase first
+                }
                 ++tail_rounds;
             }
         }
@@ -985,7 +1038,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         // ------------------------------------------------------------------ phase P: one child per step
 #pragma unroll 1
         for (int k = 0; k < STEPS; ++k) {
-            const bool pop = alive && !parked && q == qe;
+            // DENSE: a lane whose walk is over but which still holds survivors waits for the exact phase; so does one whose list is full
+            if (DENSE && alive && q == qe && lvl < 0 && np == 0) finish();
+            const bool pop = DENSE ? (alive && !leaving && np < P && q == qe && lvl >= 0) : (alive && !parked && q == qe);
             if (__ballot(pop) == 0) break;
             K2P_STAT(sp_p++; sp_pl += __popcll(__ballot(pop));)
             // Rays whose components are all finite and far from overflow never produce a NaN here (1/d is finite and non-zero,
@@ -1029,6 +1084,115 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             }
         }
 
+        if (DENSE) {
+        // ------------------------------------------------------------------ DENSE B1: every leaf entry in hand, one per lane
+        {
+            const bool own = alive && !leaving && np < P && q < qe;
+            const int cnt = own ? (qe - q < HARE_K2D_CAP ? qe - q : HARE_K2D_CAP) : 0;
+            const int inc = wave_scan_add(cnt);                              // inclusive scan of the counts over the lanes
+            const int off = inc - cnt;
+            const int total = __builtin_amdgcn_readlane(inc, 63);
+            const int q0 = q;                                                // where this lane's segment starts in its list
+            bool stop = false;                                               // owner: its list is full, the rest of its segment waits
+#pragma unroll 1
+            for (int base = 0; base < total; base += 64) {
+                K2P_STAT(sp_c++; sp_cl += (total - base < 64 ? total - base : 64);)
+                // which owner does item (base + lane) belong to?  Owners mark the start of their segment inside this window (or position
+                // 0 when the segment began before it); an inclusive max-scan spreads the owner's lane number over its items
+                seg_mark[lane] = -1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (cnt > 0 && off < base + 64 && off + cnt > base) seg_mark[off > base ? off - base : 0] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int owner = wave_scan_max(seg_mark[lane]);
+                const bool valid = base + lane < total;
+                const int ow = valid ? owner : lane;
+                // the owner's list position and pre-cull operands: seven shuffles (what can be rebuilt from them is rebuilt: cull_ray's
+                // |d|_1 and error bound; the owner's exclusions are applied by the owner, below)
+                const int rel_o = __shfl(q0 - off, ow, 64);                   // list index of item x = rel_o + x
+                CullRay cr;
+                cr.ox = __shfl(cray.ox, ow, 64); cr.oy = __shfl(cray.oy, ow, 64); cr.oz = __shfl(cray.oz, ow, 64);
+                cr.dfx = __shfl(cray.dfx, ow, 64); cr.dfy = __shfl(cray.dfy, ow, 64); cr.dfz = __shfl(cray.dfz, ow, 64);
+#if HARE_CULL32
+                cr.err = __builtin_fmaf(2.3841858e-07f /* 2^-22 */, fabsf(cr.ox) + fabsf(cr.oy) + fabsf(cr.oz), g.cf.err0);   // as cull_ray
+#endif
+                cr.dm = fabsf(cr.dfx) + fabsf(cr.dfy) + fabsf(cr.dfz);
+                int i = -1;
+                bool surv = false;
+                if (valid) {
+                    i = g.items[rel_o + base + lane];
+                    surv = !cull_test(g, cr, cull_load(g, i));
+                }
+                const unsigned long long sb = __ballot(surv);
+                // owner side: the survivors of its segment, in list order, as far as its pending list has room
+                const int lo = off > base ? off - base : 0;
+                const int hi = off + cnt - base < 64 ? off + cnt - base : 64;
+                const bool mine = cnt > 0 && !stop && lo < hi && hi > 0 && lo < 64;
+                unsigned long long seg = 0;
+                if (mine) {
+                    const unsigned long long m_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+                    seg = sb & m_hi & ~((1ull << lo) - 1ull);
+                }
+                int consumed = mine ? hi - lo : 0;                           // entries of this window the owner is done with
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    const bool take = mine && seg != 0 && np < P;
+                    const int pos = take ? (int)__builtin_ctzll(seg) : lane;
+                    const int poly = __shfl(i, pos, 64);                     // every lane executes the shuffle
+                    if (take) {
+                        if (poly != e1 && poly != e2) {                      // :218, applied by the owner
+                            pend_lca[np * nt + tid] = leaf_ca;
+                            pend_pw[np * nt + tid] = make_int2(poly, nvisit);
+                            ++np;
+                        }
+                        seg &= seg - 1ull;
+                    }
+                }
+                if (mine && seg != 0) {                                      // survivors left over: the list is full -- they are scanned again later
+                    consumed = (int)__builtin_ctzll(seg) - lo;
+                    stop = true;
+                }
+                if (mine) q += consumed;
+            }
+        }
+        // ------------------------------------------------------------------ DENSE B2: the noted survivors, each lane its own, in order
+        {
+            const bool over = alive && lvl < 0 && q == qe;                   // nothing left to visit
+            const unsigned long long holding = __ballot(alive && np > 0);
+            const unsigned long long blocked = __ballot(alive && np > 0 && (np >= P || over));
+            if (holding != 0 && (blocked != 0 || leaving || __popcll(holding) >= HARE_K2D_EXACT_MIN)) {
+                K2P_STAT(sp_e++; sp_el += __popcll(holding);)
+                bool ended = false;
+#pragma unroll 1
+                for (int k = 0; k < P; ++k) {
+                    const bool act = alive && !ended && k < np;
+                    if (__ballot(act) == 0) break;
+                    if (act) {
+                        const int2 w = pend_pw[k * nt + tid];
+                        const double lk = pend_lca[k * nt + tid];
+                        const int i = w.x;
+                        const PolyRec& p = g.polys[i];
+                        const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
+                        double t, u, v;
+                        const bool ok = poly_full(p, v3, o, d, t, u, v) && t > kTMin;                  // :224
+                        if (w.y != cur_visit) { cur_visit = w.y; cur_skip = hit && closestT <= lk; }   // :210 at that leaf's pop
+                        if (ok && !cur_skip && t < closestT) {                                          // :225
+                            closestT = t; bu = u; bv = v; pid = i;
+                            hit = true;
+                            if (closestT <= lk) ended = true;                                           // :233
+                        }
+                    }
+                }
+                if (alive && np > 0) {
+                    np = 0;
+                    if (ended) finish();
+                }
+            }
+            if (alive && lvl < 0 && q == qe && np == 0) finish();             // the walk is over and nothing is pending
+            if (leaving && __ballot(alive && np > 0) == 0) break;             // the hand-over records can be written now
+        }
+        } else {
         // ------------------------------------------------------------------ phase B1: FP32 cull (leaf candidates)
         // Two candidates per iteration: both list entries, then both polygon records, are requested together and the culls
         // run back to back -- two culls per pair of dependent loads instead of one.  (This kernel is held to three workgroups
@@ -1112,6 +1276,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     }
                 }
             }
+        }
         }
     }
 
@@ -1290,6 +1455,9 @@ __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persis
 __global__ __launch_bounds__(256) void hare_octree_tail(OctreeArgs g, ShootIO io) { octree_tail_body(g, io); }
 // the occlusion predicate on the same walk (flags only, any-hit early out); same launch geometry
 __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true>(g, io); }
+// K2d: K2p with its leaf entries spread densely over the wave and its exact tests deferred (octree_persist_body<.., DENSE>);
+// dynamic LDS = K2p's frames + kOctDenseExtra bytes per workgroup
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense(OctreeArgs g, ShootIO io) { octree_persist_body<false, true>(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }

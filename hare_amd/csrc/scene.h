@@ -34,7 +34,7 @@ struct SceneOptions {
     int dev = 0;               // HARE_DEV=1: developer flag bits (timeline, phase profile, cull audit) pass sanitize_flags
     int build_host = 0;        // HARE_BUILD=host: host builders even when a GPU is present (identical output)
     int voxel_kernel = 0;      // 0 = the library's rule, 1 = K1p (persist), 2 = K1q (pool)
-    int octree_kernel = 0;     // 0 = the library's rule (K2g below 655k rays, K2p + K2g-tail above), 1 = K2p (persist), 2 = K2q (pool), 3 = K2g (group)
+    int octree_kernel = 0;     // 0 = the library's rule (K2g below 426k rays, K2d above), 1 = K2p (persist), 2 = K2q (pool), 3 = K2g (group), 4 = K2d (dense)
     int ticket_rays = 0;       // rays per ticket of the persistent kernels (0 = the host's rule)
     int k1p_static_rays = 0;   // static first chunk per wave (0 = the host's rule)
     int k2p_static_rays = 0;
@@ -93,7 +93,7 @@ struct DeviceModule {
     hipFunction_t voxel_persist_tri_g = nullptr, voxel_persist_quad_g = nullptr;
     hipFunction_t voxel_pool_tri = nullptr, voxel_pool_quad = nullptr, voxel_pool_tri_g = nullptr, voxel_pool_quad_g = nullptr;
     hipFunction_t voxel_bounce_tri = nullptr, voxel_bounce_quad = nullptr, voxel_bounce_tri_g = nullptr, voxel_bounce_quad_g = nullptr, counters_sum = nullptr;
-    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr, octree_group = nullptr, octree_group_tail = nullptr;
+    hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr, octree_group = nullptr, octree_group_tail = nullptr, octree_dense = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr;

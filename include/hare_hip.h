@@ -169,12 +169,13 @@ HARE_API void hare_scene_destroy(hare_scene *s);
 
 /* Diagnostics and A/B switches of ONE scene, for tests, profiling and tools; production callers never need them.  A scene takes
  * its defaults from the environment ONCE, inside hare_scene_create (HARE_BUILD=host; and, only in a process that opted in with
- * HARE_DEV=1, HARE_VOXEL_KERNEL = pool|persist, HARE_OCTREE_KERNEL = group|persist|pool, HARE_TICKET, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
+ * HARE_DEV=1, HARE_VOXEL_KERNEL = pool|persist, HARE_OCTREE_KERNEL = dense|group|persist|pool, HARE_TICKET, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
  * HARE_BATCH_CHUNKS, HARE_TUNE): no call reads the environment afterwards.  Options:
  *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
- *   "octree_kernel"   0: the library's rule (K2g below 655k rays on a 256-CU part, K2p + tail above), 1: hare_octree_persist (K2p, one lane
- *                     per ray), 2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray)
+ *   "octree_kernel"   0: the library's rule (K2g below 426k rays on a 256-CU part, K2d above), 1: hare_octree_persist (K2p, one lane per ray),
+ *                     2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray), 4: hare_octree_dense (K2d: K2p with its leaf
+ *                     entries spread densely over the wave and its exact tests deferred)
  *   "bounce_fused"    1: hare_bounce_device / hare_bounce_batch (last cast's events only) run a Voxel_Grid's bounce loop as ONE launch where they can; 0 (default): a launch per cast
  *   "octree_tail"     what finishes the rays K2p's waves still walk at the end of a launch: 2 (default) hare_octree_group_tail (eight lanes per
  *                     ray, every ray a wave holds 32 rounds after its tickets ran dry), 1 hare_octree_tail (a wave per ray, a wave's last 16), 0 nothing

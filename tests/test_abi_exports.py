@@ -111,6 +111,6 @@ def test_bounce_device_without_a_gpu_fails_loudly_and_the_kernel_name_query_foll
         rc = capi.lib.hare_bounce_device(g._h, capi.KIND_VOXEL, 0, 16, 1, None, None, 4, 0, 1, None, 1, None, None, None)
         assert rc == capi.HARE_E_NODEVICE
     o = H.Octree([H.Topology(m.verts, m.nverts)], 4, 8)
-    assert o.kernel_name(1000) == "hare_octree_group" and o.kernel_name(1 << 20) == "hare_octree_persist"      # the crossover rule, 256-CU part
+    assert o.kernel_name(1000) == "hare_octree_group" and o.kernel_name(1 << 20) == "hare_octree_dense"        # the crossover rule, 256-CU part
     o.set_option("octree_kernel", 1)
     assert o.kernel_name(1000) == "hare_octree_persist"

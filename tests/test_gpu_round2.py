@@ -355,7 +355,7 @@ def test_both_voxel_kernels_bounce_loop_with_retired_rays(hall, kernel, monkeypa
     assert int(d_ctr[0]) == casts and dead.sum() >= n // 97
 
 
-@pytest.mark.parametrize("kernel", ["group", "pool", "persist"])
+@pytest.mark.parametrize("kernel", ["group", "dense", "pool", "persist"])
 def test_both_octree_kernels(hall, kernel, monkeypatch):
     """K2g (hare_octree_group, the default: eight lanes per ray), K2p (hare_octree_persist, one lane per ray) and K2q (hare_octree_pool, opt-in: rays outnumber lanes, frames below the top
     one in a device scratch block): bench workload at 300k rays, tree shapes from a single leaf to 12 levels with
@@ -402,7 +402,7 @@ def test_both_octree_kernels(hall, kernel, monkeypatch):
         assert outs[k].cpu().numpy().tobytes() == ref.tobytes(), f"launch {k}"
 
 
-@pytest.mark.parametrize("what", ["voxel", "octree_pool", "octree_persist", "octree_group"])
+@pytest.mark.parametrize("what", ["voxel", "octree_pool", "octree_persist", "octree_group", "octree_dense"])
 def test_concurrent_batch_callers_on_one_scene(hall, what):
     """Pachyderm shoots from many worker threads at once: six host threads call Shoot_batch on ONE scene at the same time
     (four staging contexts: two of them wait their turn; up to 12 chunk streams launch side by side), different ray sets and
@@ -415,7 +415,7 @@ def test_concurrent_batch_callers_on_one_scene(hall, what):
         sizes = [300_000, 70_000, 1_000, 250_000, 33, 120_000]
     else:
         g, o = H.Octree([T], 8, 16), po.Octree([To], 8, 16)
-        g.set_option("octree_kernel", {"octree_pool": 2, "octree_persist": 1, "octree_group": 3}[what])
+        g.set_option("octree_kernel", {"octree_pool": 2, "octree_persist": 1, "octree_group": 3, "octree_dense": 4}[what])
         sizes = [200_000, 70_000, 1_000, 66_000, 33, 100_000]          # three chunks from 196 608 rays: several launches per call
         assert g.kernel_name(sizes[0]) == "hare_" + what
     burst = H.scenes.burst_rays(1 << 22, m.size)

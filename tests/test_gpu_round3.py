@@ -19,7 +19,7 @@ def hall():
     return m, H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
 
 
-@pytest.mark.parametrize("kind", ["voxel_persist", "voxel_pool", "octree_persist", "octree_pool", "octree_group"])
+@pytest.mark.parametrize("kind", ["voxel_persist", "voxel_pool", "octree_persist", "octree_pool", "octree_group", "octree_dense"])
 def test_more_launches_in_flight_than_launch_slots(hall, kind):
     """A scene keeps the scratch of its persistent launches (ticket word, done counters, counter shards) in a ring of 64
     slots which the launches themselves leave zeroed.  200 launches are queued here without a host synchronisation, round
@@ -32,7 +32,7 @@ def test_more_launches_in_flight_than_launch_slots(hall, kind):
         g.set_option("voxel_kernel", 2 if kind.endswith("pool") else 1)
     else:
         g, o = H.Octree([T], 8, 16), po.Octree([To], 8, 16)
-        g.set_option("octree_kernel", 2 if kind.endswith("pool") else (3 if kind.endswith("group") else 1))
+        g.set_option("octree_kernel", {"pool": 2, "group": 3, "dense": 4}.get(kind.split("_")[1], 1))
     n = 20_000
     L = 200 if kind.startswith("voxel") else 80
     rays = H.scenes.burst_rays(n, m.size)

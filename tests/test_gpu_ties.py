@@ -94,7 +94,7 @@ def test_voxel_exact_ties(ties, kernel, domain, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", ["group", "persist", "pool"])
+@pytest.mark.parametrize("kernel", ["group", "dense", "persist", "pool"])
 def test_tree_exact_ties(ties, kernel, monkeypatch):
     monkeypatch.setenv("HARE_DEV", "1")     # developer overrides are read (once, at scene creation) only in a process that opted in
     monkeypatch.setenv("HARE_OCTREE_KERNEL", kernel)

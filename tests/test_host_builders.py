@@ -106,7 +106,7 @@ def test_scene_options_are_range_checked_without_a_gpu():
     refuse values outside their range and refuse unknown names -- nothing here launches a kernel."""
     m = H.scenes.shoebox()
     g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
-    for name, good, bad in (("voxel_kernel", 2, 3), ("octree_kernel", 3, 4), ("octree_tail", 1, 3), ("coop_tail", 0, 2), ("wide_drain", 0, 2), ("ticket_rays", 64, 1 << 20)):
+    for name, good, bad in (("voxel_kernel", 2, 3), ("octree_kernel", 4, 5), ("octree_tail", 1, 3), ("coop_tail", 0, 2), ("wide_drain", 0, 2), ("ticket_rays", 64, 1 << 20)):
         g.set_option(name, good)
         with pytest.raises(H.HareError):
             g.set_option(name, bad)

@@ -55,8 +55,8 @@ def main():
         depth = min(depth, max(0, int(np.floor(np.log2(max(ext, 1e-9))))))
         oc, oo = H.Octree([T], depth, maxp), po.Octree([To], depth, maxp)
         oref, _ = oo.shoot(rays); orefx, _ = oo.shoot(rays, excl1=e1, excl2=e2)
-        for kern in ("group", "persist", "pool"):
-            oc.set_option("octree_kernel", {"persist": 1, "pool": 2, "group": 3}[kern])
+        for kern in ("group", "dense", "persist", "pool"):
+            oc.set_option("octree_kernel", {"persist": 1, "pool": 2, "group": 3, "dense": 4}[kern])
             cfg = "seed %d octree %d/%d n=%d kernel=%s" % (seed, depth, maxp, n, kern)
             for what, got, want in (("plain", oc.Shoot_batch(rays)[0], oref), ("excl", oc.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], orefx)):
                 bad = same(got, want); checks += 1
