@@ -247,8 +247,8 @@ constexpr int kOctPoolWaveBytes = kOctPoolSlots * (5 * 8 + 11 * 4) + 4 * kOctPoo
 static_assert(kOctPoolSlots >= 64 && kOctPoolSlots <= 256 && kOctPoolSlots % 2 == 0 && kOctPoolWaveBytes % 8 == 0, "K2q pool geometry");
 constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool kernel that may be in flight (each owns a scratch block)
 
-// K2d (hare_octree_dense: K2p's DENSE build, kernels.hip): per workgroup of 256 lanes, behind the frames: two pending survivors per lane
-// (16 bytes each) and a 64-word table per wave
+// K2d (hare_octree_dense: K2p's DENSE build, kernels.hip): per workgroup of 256 lanes, behind the frames: HARE_K2D_PEND pending survivors per
+// lane (12 bytes each) and a 64-word table per wave
 #ifndef HARE_K2D_PEND
 #define HARE_K2D_PEND 2
 #define HARE_K2D_CAP 128
@@ -258,7 +258,7 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 #define HARE_K2D_STEPS 3           // pop steps per round of the dense build (K2p: 4)
 #define HARE_K2D_REFILL 8
 #endif
-constexpr unsigned kOctDenseExtra = 256u * 16u * (unsigned)HARE_K2D_PEND + 4u * 64u * 4u;
+constexpr unsigned kOctDenseExtra = 256u * 12u * (unsigned)HARE_K2D_PEND + 4u * 64u * 4u;
 
 // K2g (octree_group.hip): eight lanes per ray, eight rays per wave.  Per group in LDS: the top kGroupStack entries of the ray's
 // stack (24 bytes: clamped interval + the node's child / list words) and kGroupPend pending survivors (16 bytes each).

@@ -793,8 +793,8 @@ __device__ __forceinline__ int wave_scan_max(int v)   // values >= -1
 //   * a leaf's entries are not scanned by the owning lane, a pair per iteration at a third of the wave's lanes: ALL entries of all
 //     leaves the wave's lanes hold are spread densely over the 64 lanes (exclusive scan of the counts; an item finds its owner by a
 //     max-scan over segment starts in LDS and fetches the owner's pre-cull operands by ds_bpermute);
-//   * a survivor of the pre-cull does not park its lane: it is NOTED (polygon, the leaf's nodeTmin, the leaf's visit number; two per
-//     lane, in LDS) and the lane walks on with the closestT it has (stale = prunes less, never more); the exact tests run when
+//   * a survivor of the pre-cull does not park its lane: it is NOTED (polygon, the leaf's nodeTmin, a bit on the first one noted from
+//     its leaf; two per lane, in LDS: three were measured, 483 against 494 Mrays/s) and the lane walks on with the closestT it has (stale = prunes less, never more); the exact tests run when
 //     enough lanes hold one, each lane on its own survivors in order, with the reference's rules replayed: entering a new leaf,
 //     skipped = hit && closestT <= leafTmin (:210); not skipped and t < closestT: accept (:225); accepted t <= leafTmin: return (:233).
 // Knobs (hare_device.h): HARE_K2D_PEND survivors a lane may hold before it has to wait for the exact phase; HARE_K2D_CAP list entries of one
@@ -813,8 +813,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     // DENSE: behind the frames, the lanes' pending survivors and a 64-word table per wave (segment starts of the dense cull)
     constexpr int P = HARE_K2D_PEND;
     double* const pend_lca = reinterpret_cast<double*>(fpk + (size_t)levels * nt);     // [P][nt]
-    int2* const pend_pw = reinterpret_cast<int2*>(pend_lca + (size_t)P * nt);           // [P][nt] {polygon, leaf visit number}
-    int* const seg_mark = reinterpret_cast<int*>(pend_pw + (size_t)P * nt) + (tid >> 6) * 64;
+    int* const pend_w = reinterpret_cast<int*>(pend_lca + (size_t)P * nt);             // [P][nt] polygon | bit 31: the first survivor noted from its leaf
+    int* const seg_mark = pend_w + (size_t)P * nt + (tid >> 6) * 64;
 
     const int lane = tid & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -865,8 +865,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     int m0 = -1, m1 = -1, m2 = -1, m3 = -1;       // the polygons tested last (HARE_K2P_MAILBOX of them)
     unsigned int nhits = 0, nrays = 0;
     int np = 0;                         // DENSE: survivors noted and not yet tested
-    int nvisit = 0, cur_visit = -1;      // DENSE: leaves visited (numbers the survivors' leaves); replay: the leaf of the last survivor replayed ...
-    bool cur_skip = false;              // ... and whether the reference skipped it
+    bool leaf_fresh = false;            // DENSE: no survivor has been noted from the leaf in hand yet
+    bool cur_skip = false;              // DENSE, replay: the reference skipped the leaf of the survivors being replayed (:210)
     bool leaving = false;               // DENSE: the wave hands its rays over after one more exact phase
 #ifdef HARE_K2P_STATS                   // developer build (tools/k2p_stats.py): what a round of the loop is made of; lane 0 counts
     unsigned long long sp_round = 0, sp_alive = 0, sp_p = 0, sp_pl = 0, sp_c = 0, sp_cl = 0, sp_e = 0, sp_el = 0, sp_visit = 0;
@@ -910,7 +910,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             q = nd.item_start; qe = nd.item_start + nd.item_count; leaf_ca = ca;
             idx = nd.pad;                                  // a leaf's first two list entries travel in its node record (OctNode, hare_device.h)
             nexti = -2 - nd.first_child;
-            if (DENSE) ++nvisit;
+            if (DENSE) leaf_fresh = true;
         } else {
             double nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];     // entry / exit parameter of the low (0) and high (1) child slab
             {
@@ -990,7 +990,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                     m0 = m1 = m2 = m3 = -1;
                     lvl = -1; q = 0; qe = 0;
-                    np = 0; nvisit = 0; cur_visit = -1; cur_skip = false;
+                    np = 0; leaf_fresh = false; cur_skip = false;
                     if (e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {
                         finish();
                     } else {
@@ -1143,7 +1143,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     if (take) {
                         if (poly != e1 && poly != e2) {                      // :218, applied by the owner
                             pend_lca[np * nt + tid] = leaf_ca;
-                            pend_pw[np * nt + tid] = make_int2(poly, nvisit);
+                            pend_w[np * nt + tid] = poly | (leaf_fresh ? (int)0x80000000 : 0);
+                            leaf_fresh = false;
                             ++np;
                         }
                         seg &= seg - 1ull;
@@ -1169,14 +1170,14 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     const bool act = alive && !ended && k < np;
                     if (__ballot(act) == 0) break;
                     if (act) {
-                        const int2 w = pend_pw[k * nt + tid];
+                        const int w = pend_w[k * nt + tid];
                         const double lk = pend_lca[k * nt + tid];
-                        const int i = w.x;
+                        const int i = w & 0x7FFFFFFF;
                         const PolyRec& p = g.polys[i];
                         const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
                         double t, u, v;
                         const bool ok = poly_full(p, v3, o, d, t, u, v) && t > kTMin;                  // :224
-                        if (w.y != cur_visit) { cur_visit = w.y; cur_skip = hit && closestT <= lk; }   // :210 at that leaf's pop
+                        if (w < 0) cur_skip = hit && closestT <= lk;              // a new leaf: :210 as at its pop (no accept lies in between)
                         if (ok && !cur_skip && t < closestT) {                                          // :225
                             closestT = t; bu = u; bv = v; pid = i;
                             hit = true;

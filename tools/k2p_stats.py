@@ -5,11 +5,11 @@ import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import hare_amd as H
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20          # K2d: "cull iterations" are dense passes, their "lanes" the items of a pass
 m = H.scenes.hall()
 g = H.Octree([H.Topology(m.verts, m.nverts)], 8, 16)
 g.set_option("dev", 1)
-g.set_option("octree_kernel", 1)
+g.set_option("octree_kernel", 4 if os.environ.get("KERNEL", "persist") == "dense" else 1)      # KERNEL=dense: K2d
 g.set_option("octree_tail", 0)
 rays = torch.from_numpy(H.scenes.burst_rays(n, m.size)).cuda()
 out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
