@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_sha)
 
-SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_octree_group", "hare_octree_tail", "hare_kdtree",
+SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_octree_dense", "hare_octree_group", "hare_octree_tail", "hare_kdtree",
          "hare_reflect")
 NSHOOT = len(SHOOT) - 1          # the kernels a shoot consists of (hare_reflect is listed in the summary, not priced)
 ROUND = os.environ.get("ROUND", "r04")
