@@ -1088,7 +1088,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             unsigned pgrid = cus * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
-            sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 32;   // an octree ray costs ~10x a voxel ray: ticket atomics never bind
+            // an octree ray costs ~10x a voxel ray: ticket atomics never bind.  K2p: 32 rays; K2d finishes rays sooner and likes 16
+            // (8 / 16 / 24 / 32 rays per ticket: 1M rays 478 / 502 / 466 / 489 Mrays/s, 1.5M 553 / 570 / 569 / 563, 524k 353 / 354 / 348 / 346)
+            const bool dense_k = f == M.octree_dense && f != nullptr;
+            sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : (dense_k ? 16 : 32);
             sub.static_rays = static_chunk_rays(m, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
             if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
             void* a[] = {&g, &sub};
@@ -1097,7 +1100,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             OctScratch oc;
             // K2d hands nothing over by the rule: its dense passes put the whole wave on whatever entries its last rays hold, which is what
             // a tail kernel was for (1M rays: no tail 485 Mrays/s, K2g-tail after 8 / 16 / 32 / 64 / 96 rounds 428 / 451 / 465 / 454 / 463, K2t 464)
-            const bool dense = f == M.octree_dense && f != nullptr;
+            const bool dense = dense_k;
             if (closest_hit && s.opt.octree_tail != 0 && !(dense && s.opt.k2p_tail_max == 0 && s.opt.k2p_tail_patience < 0)) {
                 oc.tail_levels = g.max_depth;
                 oc.group_tail = s.opt.octree_tail == 2 && M.octree_group_tail != nullptr;
