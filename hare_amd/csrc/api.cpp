@@ -1348,13 +1348,24 @@ static int sync_partition_to_device(hare_scene* s, int kind)
     if (rc) return rc;
     if (kind == HARE_KIND_VOXEL) return upload_voxel(*s, H);
     if (kind == HARE_KIND_OCTREE) {
-        // the device copy of a leaf carries its first two list entries (OctNode, hare_device.h)
+        // the device copy of a leaf carries its first two list entries; that of an interior node the mask of its children that are
+        // EMPTY leaves, by octant (OctNode, hare_device.h): popping one has no effect, so K2p / K2d never push it
         std::vector<OctNode> dev(s->oct.nodes);
-        for (OctNode& nd : dev)
+        const std::vector<OctNode>& host = s->oct.nodes;
+        for (size_t k = 0; k < dev.size(); ++k) {
+            OctNode& nd = dev[k];
             if (nd.first_child < 0) {
                 nd.pad = nd.item_count > 0 ? s->oct.items[(size_t)nd.item_start] : -1;
                 nd.first_child = nd.item_count > 1 ? -2 - s->oct.items[(size_t)nd.item_start + 1] : -1;
+            } else {
+                int32_t empty = 0;
+                for (int oct = 0; oct < 8; ++oct) {
+                    const OctNode& ch = host[(size_t)nd.first_child + (size_t)oct];
+                    if (ch.first_child < 0 && ch.item_count == 0) empty |= 1 << oct;
+                }
+                nd.pad = empty;
             }
+        }
         rc = upload(H, &s->d_oct_nodes, dev.data(), dev.size() * sizeof(OctNode));
         if (rc) return rc;
         return upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));

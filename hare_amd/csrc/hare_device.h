@@ -85,7 +85,7 @@ struct OctNode {               // 64 bytes
                                // costs no list load for its first pair of candidates (as CellRec does for the grid)
     int32_t item_start;
     int32_t item_count;
-    int32_t pad;
+    int32_t pad;               // device copy: a leaf's items[start] (above); an interior node's mask of children that are empty leaves, by octant
 };
 static_assert(sizeof(OctNode) == 64, "octree node size");
 

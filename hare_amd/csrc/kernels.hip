@@ -944,9 +944,14 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             for (int oct = 0; oct < 8; ++oct) {
                 const double tmn = mx(nxy[(oct >> 2) & 1][(oct >> 1) & 1], nz[oct & 1]);
                 const double tmx = mn(fxy[(oct >> 2) & 1][(oct >> 1) & 1], fz[oct & 1]);
-                const bool p = !(tmx < tmn || tmx < 0 || tmn > cb || tmx < ca);                   // :268
+                bool p = !(tmx < tmn || tmx < 0 || tmn > cb || tmx < ca);                         // :268
+                // a child the state prunes already -- hit && closestT <= its clamped entry, :210 -- stays pruned until it would be popped
+                // (closestT only falls): it is not pushed.  (tmn is the child's own entry parameter, bit for bit: derived planes, above.)
+                p = p && !(hit && closestT <= mx(tmn, ca));
                 pushed |= p ? (1u << oct) : 0u;
             }
+            pushed &= ~((unsigned)nd.pad & 255u);                   // children that are empty leaves (the device copy's mask, api.cpp): popping one
+                                                                   // has no effect ("Octree - alt.cs":213: the list loop does not run), a third of K2p's pops
             unsigned byc = 0;                                      // octant bit -> cursor bit: cursor k examines octant k ^ mask
 #pragma unroll
             for (int k = 0; k < 8; ++k) byc |= ((pushed >> (k ^ mask)) & 1u) << k;
