@@ -870,6 +870,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     bool leaving = false;               // DENSE: the wave hands its rays over after one more exact phase
 #ifdef HARE_K2P_STATS                   // developer build (tools/k2p_stats.py): what a round of the loop is made of; lane 0 counts
     unsigned long long sp_round = 0, sp_alive = 0, sp_p = 0, sp_pl = 0, sp_c = 0, sp_cl = 0, sp_e = 0, sp_el = 0, sp_visit = 0;
+    unsigned long long sp_is = 0, sp_il = 0, sp_ls = 0, sp_ll = 0, sp_xl = 0, sp_fl = 0;   // steps with an interior visit / their lanes; leaf visits; exhausted frames; failed pops
+    int st_kind = 0;                    // what this lane's last pop step did: 1 frame exhausted, 2 popped and dropped, 3 leaf, 4 interior
 #define K2P_STAT(x) x
 #else
 #define K2P_STAT(x)
@@ -955,10 +957,12 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             unsigned byc = 0;                                      // octant bit -> cursor bit: cursor k examines octant k ^ mask
 #pragma unroll
             for (int k = 0; k < 8; ++k) byc |= ((pushed >> (k ^ mask)) & 1u) << k;
-            ++lvl;
-            fa[lvl * nt + tid] = ca;
-            fb[lvl * nt + tid] = cb;
-            fpk[lvl * nt + tid] = (int)(((unsigned)nd.first_child << 8) | byc);
+            if (byc != 0) {                                        // a node that pushes nothing opens no frame: every open frame has a child to pop
+                ++lvl;
+                fa[lvl * nt + tid] = ca;
+                fb[lvl * nt + tid] = cb;
+                fpk[lvl * nt + tid] = (int)(((unsigned)nd.first_child << 8) | byc);
+            }
         }
     };
 
@@ -1061,10 +1065,16 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     const int pk = fpk[lvl * nt + tid];
                     const unsigned rem = (unsigned)pk & 255u;
                     if (rem == 0) {
-                        --lvl;                                               // frame exhausted: back to the parent, nothing to re-read
+                        --lvl;                                               // (never since round 4: frames are closed with their last child, below)
+                        K2P_STAT(st_kind = 1;)
                     } else {
                         const int cur = 31 - __builtin_clz(rem);             // pop order: order[7] down to order[0]
-                        fpk[lvl * nt + tid] = pk & ~(1 << cur);
+                        const double pa = fa[lvl * nt + tid], pb = fb[lvl * nt + tid];
+                        // the frame's last child closes the frame: what that child opens takes its place, and no step is spent on finding
+                        // a frame empty (a third of the pop steps before: tools/k2p_stats.py).  The stack is the reference's all the same --
+                        // a frame without children left holds nothing that is ever popped.
+                        if ((rem & (rem - 1u)) == 0u) --lvl;
+                        else fpk[lvl * nt + tid] = pk & ~(1 << cur);
                         const int c = (int)((unsigned)pk >> 8) + (cur ^ mask);
                         const OctNode& nd = g.nodes[c];
                         // the child's slab interval from its own box (:253-266)
@@ -1075,18 +1085,23 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         if (invDy < 0) { const double sw = ty0; ty0 = ty1; ty1 = sw; }
                         if (invDz < 0) { const double sw = tz0; tz0 = tz1; tz1 = sw; }
                         const double tmn = mx(mx(tx0, ty0), tz0), tmx = mn(mn(tx1, ty1), tz1);
-                        const double pa = fa[lvl * nt + tid], pb = fb[lvl * nt + tid];
                         const double ca = mx(tmn, pa), cb = mn(tmx, pb);                     // :271
-                        if (!(cb < ca || cb < 0) && !(hit && closestT <= ca))              // popped and kept (:207-211)
+                        K2P_STAT(st_kind = 2;)
+                        if (!(cb < ca || cb < 0) && !(hit && closestT <= ca)) {            // popped and kept (:207-211)
+                            K2P_STAT(st_kind = nd.first_child < 0 ? 3 : 4;)
                             visit(nd, ca, cb, fast_tag);
+                        }
                     }
                 }
             };
             const bool all_tame = __ballot(pop && !tame) == 0;
+            K2P_STAT(st_kind = 0;)
             if (pop) {
                 if (all_tame) pstep(std::true_type{});
                 else pstep(std::false_type{});
             }
+            K2P_STAT({ const int ni = __popcll(__ballot(st_kind == 4)); sp_is += ni ? 1 : 0; sp_il += ni; const int nl = __popcll(__ballot(st_kind == 3));
+                       sp_ls += nl ? 1 : 0; sp_ll += nl; sp_xl += __popcll(__ballot(st_kind == 1)); sp_fl += __popcll(__ballot(st_kind == 2)); })
         }
 
         if (DENSE) {
@@ -1309,8 +1324,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     timeline(2);
 #ifdef HARE_K2P_STATS
     if (lane == 0 && io.prof) {
-        const unsigned long long v[8] = {sp_round, sp_alive, sp_p, sp_pl, sp_c, sp_cl, sp_e, sp_el};
-        for (int k = 0; k < 8; ++k) atomicAdd(&io.prof[k], v[k]);
+        const unsigned long long v[14] = {sp_round, sp_alive, sp_p, sp_pl, sp_c, sp_cl, sp_e, sp_el, sp_is, sp_il, sp_ls, sp_ll, sp_xl, sp_fl};
+        for (int k = 0; k < 14; ++k) atomicAdd(&io.prof[k], v[k]);
     }
 #endif
     launch_epilogue(io, nrays, nhits, 4u);

@@ -29,3 +29,8 @@ print("per round: P steps %.2f (lanes %.1f)  cull iterations %.2f (lanes %.1f)  
       (st["P"] / st["rounds"], st["P_lanes"] / max(st["P"], 1), st["C"] / st["rounds"], st["C_lanes"] / max(st["C"], 1),
        st["E"] / st["rounds"], st["E_lanes"] / max(st["E"], 1)))
 print("per ray: pops %.1f  cull pair-iterations %.1f  exact tests %.2f" % (st["P_lanes"] / r, st["C_lanes"] / r, st["E_lanes"] / r))
+x = dict(zip(["int_steps", "int_lanes", "leaf_steps", "leaf_lanes", "exhausted", "dropped"], [float(v) for v in c[16:22]]))
+print("pop steps with an interior visit %.2f per round at %.1f lanes; with a leaf visit %.2f at %.1f lanes" %
+      (x["int_steps"] / st["rounds"], x["int_lanes"] / max(x["int_steps"], 1), x["leaf_steps"] / st["rounds"], x["leaf_lanes"] / max(x["leaf_steps"], 1)))
+print("per ray: interior visits %.1f  leaf visits %.1f  exhausted-frame steps %.1f  pops dropped at the pop test %.1f" %
+      (x["int_lanes"] / r, x["leaf_lanes"] / r, x["exhausted"] / r, x["dropped"] / r))
