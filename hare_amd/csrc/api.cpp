@@ -1364,6 +1364,16 @@ static int sync_partition_to_device(hare_scene* s, int kind)
                     if (ch.first_child < 0 && ch.item_count == 0) empty |= 1 << oct;
                 }
                 nd.pad = empty;
+                // ... and the same mask in CURSOR order for each of the eight direction masks m (cursor k examines octant k ^ m), one byte
+                // each, in the two list words an interior node does not use: the fast visit of K2p / K2d takes byte m as it is
+                uint64_t by_mask = 0;
+                for (int m = 0; m < 8; ++m) {
+                    uint64_t byte = 0;
+                    for (int k = 0; k < 8; ++k) byte |= (uint64_t)((empty >> (k ^ m)) & 1) << k;
+                    by_mask |= byte << (8 * m);
+                }
+                nd.item_start = (int32_t)(uint32_t)(by_mask & 0xFFFFFFFFull);
+                nd.item_count = (int32_t)(uint32_t)(by_mask >> 32);
             }
         }
         rc = upload(H, &s->d_oct_nodes, dev.data(), dev.size() * sizeof(OctNode));

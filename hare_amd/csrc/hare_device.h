@@ -86,6 +86,7 @@ struct OctNode {               // 64 bytes
     int32_t item_start;
     int32_t item_count;
     int32_t pad;               // device copy: a leaf's items[start] (above); an interior node's mask of children that are empty leaves, by octant
+                               // (an interior node's item_start / item_count there: the same mask in cursor order per direction mask, api.cpp)
 };
 static_assert(sizeof(OctNode) == 64, "octree node size");
 
@@ -255,8 +256,14 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 #define HARE_K2D_EXACT_MIN 24
 #endif
 #ifndef HARE_K2D_STEPS
-#define HARE_K2D_STEPS 3           // pop steps per round of the dense build (K2p: 4)
-#define HARE_K2D_REFILL 8
+#define HARE_K2D_STEPS 2           // pop steps per round of the dense build (K2p: 4); 3 until frames closed with their last child
+#define HARE_K2D_REFILL 16
+#endif
+#ifndef HARE_K2D_STEPS_DRAIN
+#define HARE_K2D_STEPS_DRAIN 2     // ... once the tickets are dry
+#endif
+#ifndef HARE_K2D_POP_MIN
+#define HARE_K2D_POP_MIN 1         // lanes that make a second, third ... pop step of a round worth its instructions
 #endif
 constexpr unsigned kOctDenseExtra = 256u * 12u * (unsigned)HARE_K2D_PEND + 4u * 64u * 4u;
 

@@ -913,6 +913,60 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             idx = nd.pad;                                  // a leaf's first two list entries travel in its node record (OctNode, hare_device.h)
             nexti = -2 - nd.first_child;
             if (DENSE) leaf_fresh = true;
+        } else if (FAST) {
+            // A tame ray (finite, far from overflow, and the sign of 1/d is the sign of d on every axis -- `tame`, set-up): no NaN can
+            // arise, so Math.Max / Math.Min are v_max_f64 / v_min_f64 and the four conditions of :268 fold.  The slabs are formed in
+            // CURSOR order (cursor index a along an axis is the octant slab a ^ (d < 0)), so the eight tests yield the frame's mask as it
+            // is stored -- no octant -> cursor permutation -- and the children that are empty leaves come as a cursor-ordered byte of
+            // the device copy (one per direction mask, api.cpp).  Same expressions on the same operands as below: same bits.
+            double ncx[2], fcx[2], ncy[2], fcy[2], ncz[2], fcz[2];
+            {
+                const double c = (nd.bmax[0] + nd.bmin[0]) / 2;
+                const double a0 = ((nd.bmin[0] - 0.1) - o.x) * invDx, a1 = ((c + 0.1) - o.x) * invDx;
+                const double b0 = ((c - 0.1) - o.x) * invDx, b1 = ((nd.bmax[0] + 0.1) - o.x) * invDx;
+                const bool m = (mask & 4) != 0;
+                ncx[0] = m ? b1 : a0; fcx[0] = m ? b0 : a1; ncx[1] = m ? a1 : b0; fcx[1] = m ? a0 : b1;
+            }
+            {
+                const double c = (nd.bmax[1] + nd.bmin[1]) / 2;
+                const double a0 = ((nd.bmin[1] - 0.1) - o.y) * invDy, a1 = ((c + 0.1) - o.y) * invDy;
+                const double b0 = ((c - 0.1) - o.y) * invDy, b1 = ((nd.bmax[1] + 0.1) - o.y) * invDy;
+                const bool m = (mask & 2) != 0;
+                ncy[0] = m ? b1 : a0; fcy[0] = m ? b0 : a1; ncy[1] = m ? a1 : b0; fcy[1] = m ? a0 : b1;
+            }
+            {
+                const double c = (nd.bmax[2] + nd.bmin[2]) / 2;
+                const double a0 = ((nd.bmin[2] - 0.1) - o.z) * invDz, a1 = ((c + 0.1) - o.z) * invDz;
+                const double b0 = ((c - 0.1) - o.z) * invDz, b1 = ((nd.bmax[2] + 0.1) - o.z) * invDz;
+                const bool m = (mask & 1) != 0;
+                ncz[0] = m ? b1 : a0; fcz[0] = m ? b0 : a1; ncz[1] = m ? a1 : b0; fcz[1] = m ? a0 : b1;
+            }
+            double nxy[2][2], fxy[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { nxy[i][j] = __builtin_fmax(ncx[i], ncy[j]); fxy[i][j] = __builtin_fmin(fcx[i], fcy[j]); }
+            // :268 is !(tmx < tmn || tmx < 0 || tmn > cb || tmx < ca): without NaN, tmx >= max(tmn, 0, ca) && tmn <= cb.  The prune of
+            // :210 at the child's pop, hit && closestT <= max(tmn, ca): an accepted t is > 1e-10, so max(tmn, ca, 0) decides the same.
+            const double m0 = __builtin_fmax(ca, 0.0);
+            unsigned byc = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double tmn = __builtin_fmax(nxy[(k >> 2) & 1][(k >> 1) & 1], ncz[k & 1]);
+                const double tmx = __builtin_fmin(fxy[(k >> 2) & 1][(k >> 1) & 1], fcz[k & 1]);
+                const double e = __builtin_fmax(tmn, m0);
+                const bool p = (tmx >= e) & (tmn <= cb) & !(hit & (closestT <= e));
+                byc |= p ? (1u << k) : 0u;
+            }
+            // children that are empty leaves, in cursor order for this ray's direction mask (popping one has no effect, :213)
+            const unsigned long long empties = ((unsigned long long)(unsigned)nd.item_count << 32) | (unsigned)nd.item_start;
+            byc &= ~(unsigned)(empties >> (mask * 8)) & 255u;
+            if (byc != 0) {                                        // a node that pushes nothing opens no frame: every open frame has a child to pop
+                ++lvl;
+                fa[lvl * nt + tid] = ca;
+                fb[lvl * nt + tid] = cb;
+                fpk[lvl * nt + tid] = (int)(((unsigned)nd.first_child << 8) | byc);
+            }
         } else {
             double nx[2], fx[2], ny[2], fy[2], nz[2], fz[2];     // entry / exit parameter of the low (0) and high (1) child slab
             {
@@ -996,6 +1050,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     e2 = io.excl2 ? io.excl2[ray] : -1;
                     hit = false; parked = false; alive = true;
                     tame = fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300 && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
+                    // ... and 1/d has the sign of d on every axis (a component within 1e-16 of zero gets +1e16 whatever its sign, :165-167):
+                    // the fast visit forms its slabs in cursor order from the direction mask alone
+                    tame = tame && (d.x < 0) == (fabs(d.x) > 1e-16 && d.x < 0) && (d.y < 0) == (fabs(d.y) > 1e-16 && d.y < 0) &&
+                           (d.z < 0) == (fabs(d.z) > 1e-16 && d.z < 0);
                     closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                     m0 = m1 = m2 = m3 = -1;
                     lvl = -1; q = 0; qe = 0;
@@ -1045,12 +1103,18 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 
         K2P_STAT(sp_round++; sp_alive += __popcll(__ballot(alive));)
         // ------------------------------------------------------------------ phase P: one child per step
+        // (DENSE) once the tickets are dry the chip empties and a wave's time is the chain of dependent loads of its last rays, a node
+        // record per pop: more pop steps per round then (HARE_K2D_STEPS_DRAIN), which the steady state cannot afford
+        const int steps_now = (DENSE && drained) ? HARE_K2D_STEPS_DRAIN : STEPS;
 #pragma unroll 1
-        for (int k = 0; k < STEPS; ++k) {
+        for (int k = 0; k < steps_now; ++k) {
             // DENSE: a lane whose walk is over but which still holds survivors waits for the exact phase; so does one whose list is full
             if (DENSE && alive && q == qe && lvl < 0 && np == 0) finish();
             const bool pop = DENSE ? (alive && !leaving && np < P && q == qe && lvl >= 0) : (alive && !parked && q == qe);
-            if (__ballot(pop) == 0) break;
+            {
+                const unsigned long long pm = __ballot(pop);
+                if (pm == 0 || (DENSE && k > 0 && __popcll(pm) < HARE_K2D_POP_MIN)) break;     // a further step only when enough lanes take it
+            }
             K2P_STAT(sp_p++; sp_pl += __popcll(__ballot(pop));)
             // Rays whose components are all finite and far from overflow never produce a NaN here (1/d is finite and non-zero,
             // boxes are finite), so for them Math.Max / Math.Min are the hardware's v_max_f64 / v_min_f64 (the sign of a zero
@@ -1076,7 +1140,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         if ((rem & (rem - 1u)) == 0u) --lvl;
                         else fpk[lvl * nt + tid] = pk & ~(1 << cur);
                         const int c = (int)((unsigned)pk >> 8) + (cur ^ mask);
-                        const OctNode& nd = g.nodes[c];
+                        // the whole 64-byte record in ONE batch of loads: left to itself the compiler fetches the last four words -- child
+                        // index, list words -- in the branches that use them, a second and a third wait per pop
+                        OctNode nd = g.nodes[c];
+                        asm volatile("" : "+v"(nd.first_child), "+v"(nd.item_start), "+v"(nd.item_count), "+v"(nd.pad));
                         // the child's slab interval from its own box (:253-266)
                         double tx0 = (nd.bmin[0] - o.x) * invDx, tx1 = (nd.bmax[0] - o.x) * invDx;
                         double ty0 = (nd.bmin[1] - o.y) * invDy, ty1 = (nd.bmax[1] - o.y) * invDy;
