@@ -509,10 +509,11 @@ void read_env_options(SceneOptions& o)
 // is cheap against the ~30 ns of a ticket draw, so K1p takes the whole per-wave share statically (393k rays: 0.286 ms, with a
 // quarter kept for tickets 0.335); an octree ray costs ten times as much and the end of the batch matters more than the
 // tickets, so K2p keeps a quarter of the share for them (524k rays: 2.34 ms against 2.61 all static).
-int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tickets)
+int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tickets, bool keep_half = false)
 {
     int64_t per_wave = n / ((int64_t)std::max(1u, pgrid) * 4);
-    if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
+    if (keep_half) per_wave = per_wave / 2;          // K2d (swept, tools/k2d_static_sweep.sh): the optimum is half the share at every size below 786k rays
+    else if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
     return (int32_t)std::max<int64_t>(64, std::min<int64_t>(128, per_wave / 32 * 32));
 }
 size_t voxel_scene_bytes(const Scene& s, size_t top)
@@ -650,7 +651,10 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             // The threshold scales with the CU count.
             const bool fits_p = (unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist);
             const bool group_ok = have(&DeviceModule::octree_group);
-            const int64_t group_below = (int64_t)cus * 1664;          // 425 984 rays on the 256-CU part
+            // (second half of round 4: K2d no longer spends a pop step on an exhausted frame, forms its slabs in cursor order and keeps HALF
+            //  of a wave's share for tickets -- K2d / K2g at 131k 159 / 180, 196k 235 / 225, 262k 293 / 255, 393k 418 / 283, 524k 474 / 304:
+            //  the crossover is a ray for every lane of K2d's grid, 768 per CU)
+            const int64_t group_below = (int64_t)cus * 768;           // 196 608 rays on the 256-CU part
             const bool group_wanted = s.opt.octree_kernel == 3 || (s.opt.octree_kernel == 0 && (n < group_below || !fits_p));
             if (group_wanted && group_ok) { pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group); return c; }
             // K2d (K2p's DENSE build) wherever it exists and its LDS fits; K2p (octree_kernel = 1) is the A/B baseline and the fall-back
@@ -1092,7 +1096,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // (8 / 16 / 24 / 32 rays per ticket: 1M rays 478 / 502 / 466 / 489 Mrays/s, 1.5M 553 / 570 / 569 / 563, 524k 353 / 354 / 348 / 346)
             const bool dense_k = f == M.octree_dense && f != nullptr;
             sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : (dense_k ? 16 : 32);
-            sub.static_rays = static_chunk_rays(m, pgrid, true);    // 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336
+            sub.static_rays = static_chunk_rays(m, pgrid, true, dense_k);    // K2p: 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336; K2d: half
+                                                                             // the share (393k rays 338 -> 418 Mrays/s, 524k 421 -> 474, 655k 393 -> 515)
             if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
             void* a[] = {&g, &sub};
             // The closest-hit kernel hands rays to a tail kernel (the occlusion build keeps them).  Rule: K2g-tail takes EVERY ray a wave
