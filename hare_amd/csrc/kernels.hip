@@ -805,7 +805,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 {
     int tail_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int nt = blockDim.x, tid = threadIdx.x;
+    constexpr int nt = 256;          // the launch's block size (api.cpp: launch_persist): frame indices are shifts, not 32-bit multiplies (quarter rate)
+    const int tid = threadIdx.x;
     const int levels = g.max_depth > 0 ? g.max_depth : 1;
     double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] interval start of the frame's node
     double* const fb = fa + (size_t)levels * nt;                    // [levels][nt] interval end
