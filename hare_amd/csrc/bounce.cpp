@@ -6,7 +6,8 @@
 // hare_shoot_batch it would cross the host link (104 B per ray) every bounce and reflect in managed code.  Here the rays go
 // up once, every cast and every reflection runs on the device, and what comes down is the X_Events the caller asks for.
 //
-// Per cast the loop reads back the 64-byte counter block (one stream synchronisation): the number of rays that hit is the
+// A call that wants the LAST cast's events only is enqueued once and synchronises once (below).  A call that wants every cast's
+// events reads back, per cast, the 64-byte counter block (one stream synchronisation): the number of rays that hit is the
 // number that live on.  When a quarter or more of the rays in flight have died since the last packing, the survivors are
 // PACKED (hare_live_count / hare_scan_tiles / hare_reflect_compact: stable, so results and order are deterministic) and the
 // next cast is launched on the survivors only -- SURVEY.md 7.1 step 9; in a closed room nearly nothing dies and the rays stay
@@ -102,10 +103,11 @@ int bounce_on_scene(Scene& s, const HipApi* H, Scene::BatchCtx& c, int32_t kind,
     hipStream_t st = c.st[0];
     const void* polys = s.d_polys[(size_t)top];
 
-    if (!events_all && s.opt.bounce_fused) {
+    if (!events_all) {
         // ---- only the last cast's events are wanted: the whole loop is enqueued ONCE, with no host round trip between casts
-        // (bounce_device_impl, api.cpp: one launch for a Voxel_Grid where the pool kernel serves, else a launch per cast with the
-        // retired rays skipped), and the call synchronises once, at its end.  b.ev[1] serves as the loop's work array (2 n int32).
+        // (bounce_device_impl, api.cpp: a launch per cast with the retired rays skipped -- or, under the scene option `bounce_fused`,
+        // one launch for a Voxel_Grid where the pool kernel serves), and the call synchronises once, at its end.  No packing: a
+        // retired ray costs its launch a record read and a miss record.  b.ev[1] serves as the loop's work array (2 n int32).
         HIP_TRY(H->MemcpyAsync(b.rays[0], rays, (size_t)n * sizeof(hare_ray), hipMemcpyHostToDevice, st));
         if (excl1) HIP_TRY(H->MemcpyAsync(b.excl[0], excl1, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
         if (excl2) HIP_TRY(H->MemcpyAsync(b.excl2, excl2, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
