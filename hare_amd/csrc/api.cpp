@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -489,6 +491,7 @@ void read_env_options(SceneOptions& o)
     if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
     if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : (strcmp(k, "dense") == 0 ? 4 : 0)));
     if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
+    if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
     if (const char* t = getenv("HARE_K2P_TAIL_MAX")) o.k2p_tail_max = atoi(t);
     if (const char* t = getenv("HARE_K2P_TAIL_PATIENCE")) o.k2p_tail_patience = atoi(t);
@@ -1002,6 +1005,11 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.quads = (const QuadRec*)s.d_quads[top];
         g.nodes = (const OctNode*)s.d_oct_nodes;
         g.items = (const int32_t*)s.d_oct_items;
+        if (s.opt.octree_tight && (size_t)top < s.d_oct_tight.size() && s.oct_tight_rad > 0) {
+            g.tight = (const float*)s.d_oct_tight[(size_t)top];
+            for (int a = 0; a < 3; ++a) g.tight_mid[a] = s.oct_tight_mid[a];
+            g.tight_rad = s.oct_tight_rad;
+        }
         g.n_nodes = (int32_t)s.oct.nodes.size();
         g.max_depth = std::max(1, s.oct_levels);   // frames per lane = interior levels the tree really has (<= maxDepth)
         if ((size_t)g.max_depth * 64u * 24u > kLdsMax) {   // (24 bytes per level and lane: the simple kernel's frames)   // cannot happen while hare_octree_build caps maxDepth at 24
@@ -1306,6 +1314,7 @@ void hare_scene_destroy(hare_scene* s)
             for (void*& p : *v) dev_free(H, p);
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_oct_tail})
             dev_free(H, *p);
+        for (void*& p : s->d_oct_tight) dev_free(H, p);
         free_bounce_buffers(H, *s);
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
@@ -1338,6 +1347,66 @@ void hare_scene_destroy(hare_scene* s)
         set_error("unexpected C++ exception");                  \
         return HARE_E_INVALID;                                  \
     }
+
+// The TIGHT boxes of an octree over one topology: for every node, the bounding box of all polygons the lists of its subtree hold --
+// whole polygons, not clipped to anything: Octree.Shoot accepts a hit wherever it lies on the polygon ("Octree - alt.cs":224-233, F15) --
+// grown by `delta` and rounded outwards to floats.  A ray that misses that box cannot make RayXtri accept any of those polygons: an
+// accepted hit lies on the polygon to within the rounding of the exact test (~1e-13 of the distances involved), and delta is 2^-20 of
+// the scene's extent -- ten million times that -- as long as the origin stays within 1 024 extents of the scene (the guard the kernels
+// apply; beyond it they test every node as before).  So K2p / K2d may skip a popped node whose box the ray misses: no accept is lost,
+// and nothing else about the walk depends on that node.  8 floats per node: lo xyz, hi xyz, two spare.
+static void make_tight_boxes(const OctreeHost& oct, const Topo& T, double delta, std::vector<float>& out)
+{
+    const size_t n = oct.nodes.size();
+    std::vector<double> box(n * 6);
+    const double inf = std::numeric_limits<double>::infinity();
+    for (size_t k = 0; k < n; ++k) {
+        double* b = &box[k * 6];
+        b[0] = b[1] = b[2] = inf;
+        b[3] = b[4] = b[5] = -inf;
+    }
+    // children are stored behind their parent (both builders append a node's eight children when they split it): one backward sweep
+    // folds every subtree into its root; a tree that is not laid out that way gets no boxes at all (out stays empty)
+    for (size_t k = n; k-- > 0;) {
+        const OctNode& nd = oct.nodes[k];
+        double* b = &box[k * 6];
+        if (nd.first_child < 0) {
+            for (int32_t q = 0; q < nd.item_count; ++q) {
+                const int32_t id = oct.items[(size_t)nd.item_start + (size_t)q];
+                if (id < 0 || id >= T.P) { out.clear(); return; }
+                const double* v = &T.verts[(size_t)id * 12];
+                const int nv = T.nverts[(size_t)id] == 4 ? 4 : 3;
+                for (int c = 0; c < nv; ++c)
+                    for (int a = 0; a < 3; ++a) {
+                        const double x = v[c * 3 + a];
+                        if (!(x == x)) { b[a] = -inf; b[3 + a] = inf; continue; }      // a NaN corner: the box is everything
+                        if (x < b[a]) b[a] = x;
+                        if (x > b[3 + a]) b[3 + a] = x;
+                    }
+            }
+        } else {
+            if ((size_t)nd.first_child <= k || (size_t)nd.first_child + 8 > n) { out.clear(); return; }
+            for (int c = 0; c < 8; ++c) {
+                const double* cb = &box[((size_t)nd.first_child + (size_t)c) * 6];
+                for (int a = 0; a < 3; ++a) {
+                    if (cb[a] < b[a]) b[a] = cb[a];
+                    if (cb[3 + a] > b[3 + a]) b[3 + a] = cb[3 + a];
+                }
+            }
+        }
+    }
+    auto down = [](double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; };
+    auto upf = [](double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; };
+    out.assign(n * 8, 0.0f);
+    for (size_t k = 0; k < n; ++k) {
+        const double* b = &box[k * 6];
+        float* o = &out[k * 8];
+        for (int a = 0; a < 3; ++a) {
+            o[a] = down(b[a] - delta);
+            o[3 + a] = upf(b[3 + a] + delta);
+        }
+    }
+}
 
 // After a host build: push the partition to the device when one is available.  Builds succeed
 // without a GPU (introspection works); shooting then fails with HARE_E_NODEVICE.
@@ -1383,6 +1452,31 @@ static int sync_partition_to_device(hare_scene* s, int kind)
         }
         rc = upload(H, &s->d_oct_nodes, dev.data(), dev.size() * sizeof(OctNode));
         if (rc) return rc;
+        // the tight boxes, per topology a query may name (one whose polygon ids the lists stay inside)
+        for (void*& p : s->d_oct_tight) dev_free(H, p);
+        s->d_oct_tight.assign(s->topos.size(), nullptr);
+        s->oct_tight_rad = -1;
+        if (!s->topos.empty()) {
+            double lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) { lo[a] = s->topos[0].mn[a]; hi[a] = s->topos[0].mx[a]; }
+            for (const Topo& T : s->topos)
+                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], T.mn[a]); hi[a] = std::max(hi[a], T.mx[a]); }
+            double ext = 0;
+            for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+            if (ext > 0 && std::isfinite(ext) && ext < 1e100) {
+                const double delta = std::ldexp(ext, -20);
+                for (size_t m = 0; m < s->topos.size(); ++m) {
+                    if (s->oct.id_count > s->topos[m].P) continue;
+                    std::vector<float> tb;
+                    make_tight_boxes(s->oct, s->topos[m], delta, tb);
+                    if (tb.empty()) continue;
+                    rc = upload(H, &s->d_oct_tight[m], tb.data(), tb.size() * sizeof(float));
+                    if (rc) return rc;
+                }
+                for (int a = 0; a < 3; ++a) s->oct_tight_mid[a] = 0.5 * (lo[a] + hi[a]);
+                s->oct_tight_rad = 1024.0 * ext;
+            }
+        }
         return upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
     }
     rc = upload(H, &s->d_kd_nodes, s->kd.nodes.data(), s->kd.nodes.size() * sizeof(KdNodeRec));
@@ -2058,6 +2152,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
         {"octree_kernel", &SceneOptions::octree_kernel, 0, 4},
         {"octree_tail", &SceneOptions::octree_tail, 0, 2},
+        {"octree_tight", &SceneOptions::octree_tight, 0, 1},
         {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},
         {"k2p_tail_max", &SceneOptions::k2p_tail_max, 0, 64},
         {"k2p_tail_patience", &SceneOptions::k2p_tail_patience, -1, 100000},

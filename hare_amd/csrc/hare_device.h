@@ -99,6 +99,10 @@ struct OctreeArgs {
     int32_t max_depth;
     const unsigned char* cull; // as in VoxelArgs
     CullFrame cf;
+    const float* tight;        // nullable: per node {lo xyz, hi xyz, 0, 0}: the box of ALL polygons the node's subtree lists, grown by a margin and
+                               // rounded outwards (api.cpp: make_tight_boxes).  A tame ray (K2p / K2d) that misses it cannot hit any of them.
+    double tight_mid[3];       // ... for origins with |o - tight_mid|_inf <= tight_rad only (the margin is sized for those)
+    double tight_rad;
 };
 
 // ---- the pre-cull as the kernels use it: load a candidate's record (cull_load: the gathers), prepare the ray once per task

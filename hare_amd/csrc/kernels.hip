@@ -849,6 +849,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     bool drained = false;
 
     bool alive = false, parked = false, hit = false, tame = true;
+    bool tight_ok = false;              // this ray may be tested against the subtrees' tight boxes (g.tight: a tame ray with its origin near the scene)
     unsigned int ray = 0;
     V3 o = {0, 0, 0}, d = {0, 0, 0};
     double invDx = 0, invDy = 0, invDz = 0;
@@ -1055,6 +1056,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     // the fast visit forms its slabs in cursor order from the direction mask alone
                     tame = tame && (d.x < 0) == (fabs(d.x) > 1e-16 && d.x < 0) && (d.y < 0) == (fabs(d.y) > 1e-16 && d.y < 0) &&
                            (d.z < 0) == (fabs(d.z) > 1e-16 && d.z < 0);
+                    tight_ok = tame && g.tight != nullptr && fabs(o.x - g.tight_mid[0]) <= g.tight_rad && fabs(o.y - g.tight_mid[1]) <= g.tight_rad &&
+                               fabs(o.z - g.tight_mid[2]) <= g.tight_rad;
                     closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                     m0 = m1 = m2 = m3 = -1;
                     lvl = -1; q = 0; qe = 0;
@@ -1144,6 +1147,12 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         // the whole 64-byte record in ONE batch of loads: left to itself the compiler fetches the last four words -- child
                         // index, list words -- in the branches that use them, a second and a third wait per pop
                         OctNode nd = g.nodes[c];
+                        // ... and, in the same batch, the box of the polygons its subtree lists (api.cpp: make_tight_boxes)
+                        float4 tb0 = make_float4(0, 0, 0, 0), tb1 = tb0;
+                        if (FAST && g.tight != nullptr) {
+                            const float4* tp = reinterpret_cast<const float4*>(g.tight) + 2 * (size_t)c;
+                            tb0 = tp[0]; tb1 = tp[1];
+                        }
                         asm volatile("" : "+v"(nd.first_child), "+v"(nd.item_start), "+v"(nd.item_count), "+v"(nd.pad));
                         // the child's slab interval from its own box (:253-266)
                         double tx0 = (nd.bmin[0] - o.x) * invDx, tx1 = (nd.bmax[0] - o.x) * invDx;
@@ -1155,7 +1164,22 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         const double tmn = mx(mx(tx0, ty0), tz0), tmx = mn(mn(tx1, ty1), tz1);
                         const double ca = mx(tmn, pa), cb = mn(tmx, pb);                     // :271
                         K2P_STAT(st_kind = 2;)
-                        if (!(cb < ca || cb < 0) && !(hit && closestT <= ca)) {            // popped and kept (:207-211)
+                        // The tight box: a ray that misses it -- or, holding a hit, reaches it behind that hit -- cannot make RayXtri accept
+                        // (:224-225, t > 1e-10 && t < closestT) any polygon of the subtree: the node is dropped as if it had been visited in
+                        // vain.  FP64 on the reference's own slab expressions; the box is grown by 2^-20 of the scene's extent, a million
+                        // times the rounding of either test, and rounded outwards (make_tight_boxes).  A stale closestT only drops less.
+                        bool vain = false;
+                        if (FAST && g.tight != nullptr) {
+                            double ux0 = ((double)tb0.x - o.x) * invDx, ux1 = ((double)tb0.w - o.x) * invDx;
+                            double uy0 = ((double)tb0.y - o.y) * invDy, uy1 = ((double)tb1.x - o.y) * invDy;
+                            double uz0 = ((double)tb0.z - o.z) * invDz, uz1 = ((double)tb1.y - o.z) * invDz;
+                            if (invDx < 0) { const double sw = ux0; ux0 = ux1; ux1 = sw; }
+                            if (invDy < 0) { const double sw = uy0; uy0 = uy1; uy1 = sw; }
+                            if (invDz < 0) { const double sw = uz0; uz0 = uz1; uz1 = sw; }
+                            const double un = mx(mx(ux0, uy0), uz0), uf = mn(mn(ux1, uy1), uz1);
+                            vain = tight_ok && ((uf < un) | (uf < 0) | (hit & (closestT <= un)));
+                        }
+                        if (!vain && !(cb < ca || cb < 0) && !(hit && closestT <= ca)) {   // popped and kept (:207-211)
                             K2P_STAT(st_kind = nd.first_child < 0 ? 3 : 4;)
                             visit(nd, ca, cb, fast_tag);
                         }

@@ -40,6 +40,7 @@ struct SceneOptions {
     int k2p_static_rays = 0;
     int bounce_fused = 0;      // 1: the bounce loop of a Voxel_Grid runs as ONE launch where the pool kernel serves (hare_voxel_bounce_*); 0 (default): a launch
                                // per cast -- measured: the hall +2.5 %, the cathedral -0 ... -10 % (a chip that works on all casts at once loses the L2 locality of one band)
+    int octree_tight = 1;      // 1: K2d / K2p skip a popped node whose subtree's polygons the ray cannot hit (the tight boxes of api.cpp); 0: every node the reference visits (A/B)
     int octree_tail = 2;       // what finishes the rays K2p gives up: 0 nothing (every lane finishes its own), 1 K2t (a wave per ray, a wave's last 16), 2 K2g-tail (eight lanes per ray, all of them)
     int k2p_tail_max = 0;      // developer sweeps: hand over once at most this many rays are alive in a wave (0 = the rule) ...
     int k2p_tail_patience = -1; // ... after this many rounds (-1 = the rule)
@@ -152,6 +153,8 @@ struct Scene {
     int32_t occ_shift = 0, occ_cd = 0;           // bitmap resolution: one bit per (2^occ_shift)^3 voxels, occ_cd blocks per axis
     void* d_oct_nodes = nullptr;
     void* d_oct_items = nullptr;
+    std::vector<void*> d_oct_tight;   // per topology: the box of the polygons every node's subtree lists, 8 floats per node (api.cpp: make_tight_boxes); null = none
+    double oct_tight_mid[3] = {0, 0, 0}, oct_tight_rad = -1;      // ray origins the boxes may be used for: |o - mid|_inf <= rad
     void* d_kd_nodes = nullptr;
     void* d_kd_items = nullptr;
     void* d_work = nullptr;                      // LaunchSlotMem[kLaunchSlots]: scratch of the persistent launches in flight
