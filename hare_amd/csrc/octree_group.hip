@@ -107,6 +107,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
 
     // ---- per-ray state, uniform over the group's eight lanes
     bool alive = false, hit = false, tame = true;
+    bool tight_ok = false;              // the subtrees' tight boxes may be used for this ray (g.tight, api.cpp: make_tight_boxes): tame, origin near the scene
     unsigned int ray = 0;
     V3 o = {0, 0, 0}, d = {0, 0, 0};
     double invDx = 0, invDy = 0, invDz = 0;
@@ -196,6 +197,8 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                         e2 = io.excl2 ? io.excl2[ray] : -1;
                         hit = false; alive = true;
                         tame = fabs(o.x) < 1e300 && fabs(o.y) < 1e300 && fabs(o.z) < 1e300 && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
+                        tight_ok = tame && g.tight != nullptr && fabs(o.x - g.tight_mid[0]) <= g.tight_rad && fabs(o.y - g.tight_mid[1]) <= g.tight_rad &&
+                                   fabs(o.z - g.tight_mid[2]) <= g.tight_rad;
                         closestT = kDblMax; pid = -1; bu = 0; bv = 0;
                         sp = 0; q = 0; qe = 0; np = 0; visit = 0; cur_visit = -1; cur_skip = false;
                         if (!TAIL && e1 == -2 && (io.flags & SHOOT_RETIRED_RAYS)) {
@@ -325,6 +328,20 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                 push = push && !(cb < ca || cb < 0);                                     // the pop test :207 is hit-independent: made here
                 push = push && !(cleaf && cw.y == 0);                                    // popping an empty leaf has no effect
                 push = push && !(hit && closestT <= ca);                                 // :210 true now stays true (closestT only falls)
+                // the tight box of the child's subtree (as in K2d, kernels.hip): a ray that misses the box of ALL the polygons below --
+                // or, holding a hit, reaches it behind that hit -- cannot make RayXtri accept any of them: the child is not pushed
+                if (FAST && g.tight != nullptr) {
+                    const float4* tp = reinterpret_cast<const float4*>(g.tight) + 2 * (size_t)(fc + (j ^ mask));
+                    const float4 tb0 = tp[0], tb1 = tp[1];
+                    double ux0 = ((double)tb0.x - o.x) * invDx, ux1 = ((double)tb0.w - o.x) * invDx;
+                    double uy0 = ((double)tb0.y - o.y) * invDy, uy1 = ((double)tb1.x - o.y) * invDy;
+                    double uz0 = ((double)tb0.z - o.z) * invDz, uz1 = ((double)tb1.y - o.z) * invDz;
+                    if (invDx < 0) { const double s = ux0; ux0 = ux1; ux1 = s; }
+                    if (invDy < 0) { const double s = uy0; uy0 = uy1; uy1 = s; }
+                    if (invDz < 0) { const double s = uz0; uz0 = uz1; uz1 = s; }
+                    const double un = mx(mx(ux0, uy0), uz0), uf = mn(mn(ux1, uy1), uz1);
+                    push = push && !(tight_ok && ((uf < un) | (uf < 0) | (hit & (closestT <= un))));
+                }
             };
             // Rays whose components are all finite and far from overflow never produce a NaN here, so for them Math.Max / Math.Min
             // are v_max_f64 / v_min_f64 (the sign of a zero result is only ever compared); anything else: NaN-propagating selects

@@ -1,4 +1,4 @@
-"""The subtree TIGHT BOXES of the octree kernels K2d / K2p (api.cpp: make_tight_boxes; scene option `octree_tight`): a popped node whose
+"""The subtree TIGHT BOXES of the octree kernels K2d / K2p / K2g (api.cpp: make_tight_boxes; scene option `octree_tight`): a popped node whose
 subtree's polygons the ray cannot hit is dropped without being visited.  Not in the reference -- "Octree - alt.cs":207-237 visits every
 node its loose boxes let through and lets RayXtri say no -- so the only acceptable effect is none: the same eight X_Event fields, bit for
 bit, with the boxes on, off, and from the oracle.  The cases are chosen where a box test has the least room: rays aimed exactly at
@@ -15,7 +15,7 @@ from tests.test_gpu_round2 import deep_scene
 from tests.test_gpu_ties import tie_rays, tie_scene
 
 pytestmark = pytest.mark.gpu
-KERNELS = {"dense": 4, "persist": 1}
+KERNELS = {"dense": 4, "persist": 1, "group": 3}
 
 
 def both_ways(oc, oo, rays, what, **kw):
