@@ -1156,6 +1156,11 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         g.max_depth = s.kd.depth_reached;
         g.cull = (const unsigned char*)s.d_cull[top];
         g.cf = s.cull_frames[(size_t)top];
+        if (s.opt.octree_tight && (size_t)top < s.d_kd_tight.size() && s.kd_tight_rad > 0) {     // the option name is the octree's: one switch for both trees
+            g.tight = (const float*)s.d_kd_tight[(size_t)top];
+            for (int a = 0; a < 3; ++a) g.tight_mid[a] = s.kd_tight_mid[a];
+            g.tight_rad = s.kd_tight_rad;
+        }
         hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only).f;
         if (!f) {
             set_error("hare_shoot: kd-tree kernel missing from code object");
@@ -1315,6 +1320,7 @@ void hare_scene_destroy(hare_scene* s)
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_oct_tail})
             dev_free(H, *p);
         for (void*& p : s->d_oct_tight) dev_free(H, p);
+        for (void*& p : s->d_kd_tight) dev_free(H, p);
         free_bounce_buffers(H, *s);
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
@@ -1348,6 +1354,7 @@ void hare_scene_destroy(hare_scene* s)
         return HARE_E_INVALID;                                  \
     }
 
+extern "C++" {
 // The TIGHT boxes of an octree over one topology: for every node, the bounding box of all polygons the lists of its subtree hold --
 // whole polygons, not clipped to anything: Octree.Shoot accepts a hit wherever it lies on the polygon ("Octree - alt.cs":224-233, F15) --
 // grown by `delta` and rounded outwards to floats.  A ray that misses that box cannot make RayXtri accept any of those polygons: an
@@ -1355,9 +1362,12 @@ void hare_scene_destroy(hare_scene* s)
 // the scene's extent -- ten million times that -- as long as the origin stays within 1 024 extents of the scene (the guard the kernels
 // apply; beyond it they test every node as before).  So K2p / K2d may skip a popped node whose box the ray misses: no accept is lost,
 // and nothing else about the walk depends on that node.  8 floats per node: lo xyz, hi xyz, two spare.
-static void make_tight_boxes(const OctreeHost& oct, const Topo& T, double delta, std::vector<float>& out)
+// (One routine for both trees: `kids(k, c)` lists node k's children into c and returns how many -- 0 for a leaf --, `leaf(k, start, count)`
+// gives a leaf's list.)
+template <class Kids, class Leaf>
+static void make_tight_boxes_of(size_t n, const std::vector<int32_t>& items, Kids kids, Leaf leaf, const Topo& T, double delta, std::vector<float>& out)
 {
-    const size_t n = oct.nodes.size();
+    out.clear();
     std::vector<double> box(n * 6);
     const double inf = std::numeric_limits<double>::infinity();
     for (size_t k = 0; k < n; ++k) {
@@ -1365,15 +1375,19 @@ static void make_tight_boxes(const OctreeHost& oct, const Topo& T, double delta,
         b[0] = b[1] = b[2] = inf;
         b[3] = b[4] = b[5] = -inf;
     }
-    // children are stored behind their parent (both builders append a node's eight children when they split it): one backward sweep
+    // children are stored behind their parent (every builder appends a node's children when it splits it): one backward sweep
     // folds every subtree into its root; a tree that is not laid out that way gets no boxes at all (out stays empty)
     for (size_t k = n; k-- > 0;) {
-        const OctNode& nd = oct.nodes[k];
         double* b = &box[k * 6];
-        if (nd.first_child < 0) {
-            for (int32_t q = 0; q < nd.item_count; ++q) {
-                const int32_t id = oct.items[(size_t)nd.item_start + (size_t)q];
-                if (id < 0 || id >= T.P) { out.clear(); return; }
+        int32_t ch[8];
+        const int nc = kids(k, ch);
+        if (nc == 0) {
+            int32_t start = 0, count = 0;
+            leaf(k, start, count);
+            if (start < 0 || count < 0 || (size_t)start + (size_t)count > items.size()) return;
+            for (int32_t q = 0; q < count; ++q) {
+                const int32_t id = items[(size_t)start + (size_t)q];
+                if (id < 0 || id >= T.P) return;
                 const double* v = &T.verts[(size_t)id * 12];
                 const int nv = T.nverts[(size_t)id] == 4 ? 4 : 3;
                 for (int c = 0; c < nv; ++c)
@@ -1385,9 +1399,9 @@ static void make_tight_boxes(const OctreeHost& oct, const Topo& T, double delta,
                     }
             }
         } else {
-            if ((size_t)nd.first_child <= k || (size_t)nd.first_child + 8 > n) { out.clear(); return; }
-            for (int c = 0; c < 8; ++c) {
-                const double* cb = &box[((size_t)nd.first_child + (size_t)c) * 6];
+            for (int c = 0; c < nc; ++c) {
+                if (ch[c] < 0 || (size_t)ch[c] <= k || (size_t)ch[c] >= n) return;
+                const double* cb = &box[(size_t)ch[c] * 6];
                 for (int a = 0; a < 3; ++a) {
                     if (cb[a] < b[a]) b[a] = cb[a];
                     if (cb[3 + a] > b[3 + a]) b[3 + a] = cb[3 + a];
@@ -1407,6 +1421,49 @@ static void make_tight_boxes(const OctreeHost& oct, const Topo& T, double delta,
         }
     }
 }
+static void make_tight_boxes(const OctreeHost& oct, const Topo& T, double delta, std::vector<float>& out)
+{
+    make_tight_boxes_of(
+        oct.nodes.size(), oct.items,
+        [&](size_t k, int32_t* c) { const int32_t fc = oct.nodes[k].first_child; if (fc < 0) return 0; for (int j = 0; j < 8; ++j) c[j] = fc + j; return 8; },
+        [&](size_t k, int32_t& st, int32_t& cn) { st = oct.nodes[k].item_start; cn = oct.nodes[k].item_count; }, T, delta, out);
+}
+static void make_tight_boxes(const KdHost& kd, const Topo& T, double delta, std::vector<float>& out)
+{
+    make_tight_boxes_of(
+        kd.nodes.size(), kd.items,
+        [&](size_t k, int32_t* c) { const KdNodeRec& nd = kd.nodes[k]; if (nd.left < 0 && nd.right < 0) return 0; c[0] = nd.left; c[1] = nd.right; return 2; },
+        [&](size_t k, int32_t& st, int32_t& cn) { st = kd.nodes[k].item_start; cn = kd.nodes[k].item_count; }, T, delta, out);
+}
+// What both trees need around them: the margin (2^-20 of the scene's extent), the boxes of every topology a query may name, and the
+// range of origins they are good for.  `tight` is freed and refilled.
+template <class Tree>
+static int upload_tight_boxes(hare_scene* s, const HipApi* H, const Tree& tree, int32_t id_count, std::vector<void*>& tight, double mid[3], double& rad)
+{
+    for (void*& p : tight) dev_free(H, p);
+    tight.assign(s->topos.size(), nullptr);
+    rad = -1;
+    if (s->topos.empty()) return HARE_OK;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = s->topos[0].mn[a]; hi[a] = s->topos[0].mx[a]; }
+    for (const Topo& T : s->topos)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], T.mn[a]); hi[a] = std::max(hi[a], T.mx[a]); }
+    double ext = 0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+    if (!(ext > 0 && std::isfinite(ext) && ext < 1e100)) return HARE_OK;
+    const double delta = std::ldexp(ext, -20);
+    for (size_t m = 0; m < s->topos.size(); ++m) {
+        if (id_count > s->topos[m].P) continue;
+        std::vector<float> tb;
+        make_tight_boxes(tree, s->topos[m], delta, tb);
+        if (tb.empty()) continue;
+        if (int rc = upload(H, &tight[m], tb.data(), tb.size() * sizeof(float))) return rc;
+    }
+    for (int a = 0; a < 3; ++a) mid[a] = 0.5 * (lo[a] + hi[a]);
+    rad = 1024.0 * ext;
+    return HARE_OK;
+}
+}  // extern "C++"
 
 // After a host build: push the partition to the device when one is available.  Builds succeed
 // without a GPU (introspection works); shooting then fails with HARE_E_NODEVICE.
@@ -1453,33 +1510,13 @@ static int sync_partition_to_device(hare_scene* s, int kind)
         rc = upload(H, &s->d_oct_nodes, dev.data(), dev.size() * sizeof(OctNode));
         if (rc) return rc;
         // the tight boxes, per topology a query may name (one whose polygon ids the lists stay inside)
-        for (void*& p : s->d_oct_tight) dev_free(H, p);
-        s->d_oct_tight.assign(s->topos.size(), nullptr);
-        s->oct_tight_rad = -1;
-        if (!s->topos.empty()) {
-            double lo[3], hi[3];
-            for (int a = 0; a < 3; ++a) { lo[a] = s->topos[0].mn[a]; hi[a] = s->topos[0].mx[a]; }
-            for (const Topo& T : s->topos)
-                for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], T.mn[a]); hi[a] = std::max(hi[a], T.mx[a]); }
-            double ext = 0;
-            for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
-            if (ext > 0 && std::isfinite(ext) && ext < 1e100) {
-                const double delta = std::ldexp(ext, -20);
-                for (size_t m = 0; m < s->topos.size(); ++m) {
-                    if (s->oct.id_count > s->topos[m].P) continue;
-                    std::vector<float> tb;
-                    make_tight_boxes(s->oct, s->topos[m], delta, tb);
-                    if (tb.empty()) continue;
-                    rc = upload(H, &s->d_oct_tight[m], tb.data(), tb.size() * sizeof(float));
-                    if (rc) return rc;
-                }
-                for (int a = 0; a < 3; ++a) s->oct_tight_mid[a] = 0.5 * (lo[a] + hi[a]);
-                s->oct_tight_rad = 1024.0 * ext;
-            }
-        }
+        rc = upload_tight_boxes(s, H, s->oct, s->oct.id_count, s->d_oct_tight, s->oct_tight_mid, s->oct_tight_rad);
+        if (rc) return rc;
         return upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
     }
     rc = upload(H, &s->d_kd_nodes, s->kd.nodes.data(), s->kd.nodes.size() * sizeof(KdNodeRec));
+    if (rc) return rc;
+    rc = upload_tight_boxes(s, H, s->kd, s->kd.id_count, s->d_kd_tight, s->kd_tight_mid, s->kd_tight_rad);
     if (rc) return rc;
     return upload(H, &s->d_kd_items, s->kd.items.data(), s->kd.items.size() * sizeof(int32_t));
 }

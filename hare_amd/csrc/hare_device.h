@@ -198,6 +198,9 @@ struct KdArgs {
     int32_t max_depth;
     const unsigned char* cull; // as in VoxelArgs (device kernels; null on the host)
     CullFrame cf;
+    const float* tight;        // as in OctreeArgs: per node the box of the polygons its subtree lists (device kernels; null on the host)
+    double tight_mid[3];
+    double tight_rad;
 };
 
 struct BuildArgs {             // Voxel_Grid construction kernels (build_kernels.hip)

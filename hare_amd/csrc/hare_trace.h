@@ -299,9 +299,36 @@ HARE_HD void trace_kdtree(const KdArgs& g, int* stack, int tid, int nt, const V3
     sp = 1;
     const double oo[3] = {o.x, o.y, o.z};
     const double dd[3] = {d.x, d.y, d.z};
+#if defined(__HIPCC__)
+    // The subtrees' tight boxes (api.cpp: make_tight_boxes; as in the octree kernels): KDTree.Shoot visits EVERY leaf and lets RayXtri
+    // say no to all but a few polygons.  A ray that misses the box of all polygons below a node -- or, holding a hit, reaches that box
+    // behind it -- cannot make RayXtri accept (t > 1e-10 && t < closestT, :233) any of them: the node is dropped, the event unchanged.
+    // Only for finite rays with the origin within the range the boxes' margin is sized for; 1/d may be infinite (a zero component):
+    // fmax / fmin then leave that slab out unless the origin lies outside it, where +-inf says miss -- which it is.
+    bool tight_ok = false;
+    double ivx = 0, ivy = 0, ivz = 0;
+    if (CULL && g.tight != nullptr) {
+        tight_ok = fabs(o.x - g.tight_mid[0]) <= g.tight_rad && fabs(o.y - g.tight_mid[1]) <= g.tight_rad && fabs(o.z - g.tight_mid[2]) <= g.tight_rad &&
+                   fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
+        ivx = 1.0 / d.x; ivy = 1.0 / d.y; ivz = 1.0 / d.z;
+    }
+#endif
     while (sp > 0) {
         --sp;
-        const KdNodeRec& cur = g.nodes[stack[sp * nt + tid]];
+        const int node = stack[sp * nt + tid];
+        const KdNodeRec& cur = g.nodes[node];
+#if defined(__HIPCC__)
+        if (CULL && tight_ok) {
+            const float4* tp = reinterpret_cast<const float4*>(g.tight) + 2 * (size_t)node;
+            const float4 tb0 = tp[0], tb1 = tp[1];
+            double ux0 = ((double)tb0.x - o.x) * ivx, ux1 = ((double)tb0.w - o.x) * ivx;
+            double uy0 = ((double)tb0.y - o.y) * ivy, uy1 = ((double)tb1.x - o.y) * ivy;
+            double uz0 = ((double)tb0.z - o.z) * ivz, uz1 = ((double)tb1.y - o.z) * ivz;
+            const double un = __builtin_fmax(__builtin_fmax(__builtin_fmin(ux0, ux1), __builtin_fmin(uy0, uy1)), __builtin_fmin(uz0, uz1));
+            const double uf = __builtin_fmin(__builtin_fmin(__builtin_fmax(ux0, ux1), __builtin_fmax(uy0, uy1)), __builtin_fmax(uz0, uz1));
+            if ((uf < un) | (uf < 0) | ((ev.hit != 0) & (closestT <= un))) continue;
+        }
+#endif
         if (COUNT) w.cells++;
         if (cur.left < 0 && cur.right < 0) {
             const int is = cur.item_start, ic = cur.item_count;

@@ -156,6 +156,8 @@ struct Scene {
     std::vector<void*> d_oct_tight;   // per topology: the box of the polygons every node's subtree lists, 8 floats per node (api.cpp: make_tight_boxes); null = none
     double oct_tight_mid[3] = {0, 0, 0}, oct_tight_rad = -1;      // ray origins the boxes may be used for: |o - mid|_inf <= rad
     void* d_kd_nodes = nullptr;
+    std::vector<void*> d_kd_tight;    // as d_oct_tight, for the kd-tree's nodes
+    double kd_tight_mid[3] = {0, 0, 0}, kd_tight_rad = -1;
     void* d_kd_items = nullptr;
     void* d_work = nullptr;                      // LaunchSlotMem[kLaunchSlots]: scratch of the persistent launches in flight
     std::atomic<unsigned> work_slot{0};

@@ -132,3 +132,56 @@ def test_the_bench_workload_with_and_without_the_boxes():
         ev, c = oc.Shoot_batch(rays)
         assert_events_equal(ev, ref, what=f"hall tight={tight}")
         assert c["hits"] == rc["hits"]
+
+
+def test_kdtree_with_and_without_the_boxes():
+    """KDTree.Shoot visits every leaf (KDTree.cs:210-216, F4); with the boxes `hare_kdtree_shoot` drops the subtrees the ray cannot hit.
+    Same events either way and from the oracle: ties and faces, a soup with quadrilaterals and exclusions, far origins, two topologies,
+    and a scene the brute-force query could not finish on the GPU in reasonable time without them (the hall, 100k polygons)."""
+    def check(kd, ko, rays, what, top=0, **kw):
+        okw = {("excl1" if k == "poly_origin1" else "excl2"): v for k, v in kw.items()}
+        ref, rc = ko.shoot(rays, top_index=top, **okw)
+        for tight in (1, 0):
+            kd.set_option("octree_tight", tight)
+            ev, c = kd.Shoot_batch(rays, top_index=top, **kw)
+            assert_events_equal(ev, ref, what=f"kd {what} tight={tight}")
+            assert c["hits"] == rc["hits"]
+        kd.set_option("octree_tight", 1)
+        return ref
+
+    v, nv, size = tie_scene()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = np.concatenate([tie_rays(v, nv, size, n=3000), face_rays(v, nv, size, n=2000)])
+    kd, ko = H.KDTree([T], 7, 6), po.KDTree([To], 7, 6)
+    ref = check(kd, ko, rays, "ties")
+    check(kd, ko, rays, "ties excl", poly_origin1=ref["poly_id"].astype(np.int32))
+
+    v, nv, size = soup(n_tri=700, n_quad=300, seed=21)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rng = np.random.default_rng(8)
+    n = 3000
+    tgt = rng.uniform(0.1, 0.9, (n, 3)) * np.asarray(size)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    far = np.concatenate([tgt - u * (6.0 * 10.0 ** rng.integers(1, 10, n).astype(np.float64))[:, None], u], 1)
+    near = soup_rays(5000, size, seed=12)
+    near[::5, 3] = 1e-17; near[1::5, 4] = 0.0; near[2::5, 5] = -0.0; near[3::25, 3:] *= 1e-200; near[4::25, 3:] *= 1e200
+    rays = np.ascontiguousarray(np.concatenate([near, far, face_rays(v, nv, size, n=2000, seed=5)]))
+    e1 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+    for depth, maxp in ((6, 8), (12, 1), (0, 4)):
+        kd, ko = H.KDTree([T], depth, maxp), po.KDTree([To], depth, maxp)
+        check(kd, ko, rays, f"soup {depth}/{maxp}")
+        check(kd, ko, rays, f"soup {depth}/{maxp} excl", poly_origin1=e1)
+
+    v0, n0, size = soup()
+    v1, n1, _ = soup(n_tri=300, n_quad=80, seed=9, size=(5.0, 4.5, 3.5))
+    kd, ko = H.KDTree([H.Topology(v0, n0), H.Topology(v1, n1)], 6, 8), po.KDTree([po.Topology(v0, n0), po.Topology(v1, n1)], 6, 8)
+    for top in (0, 1):
+        check(kd, ko, soup_rays(4000, size), f"two topologies top {top}", top=top)
+
+    m = H.scenes.hall()
+    rays = H.scenes.burst_rays(1 << 20, m.size)[::512]              # 2 048 rays: the oracle's query is 100k polygons per ray
+    kd, ko = H.KDTree([H.Topology(m.verts, m.nverts)], 16, 8), po.KDTree([po.Topology(m.verts, m.nverts)], 16, 8)
+    ref, rc = ko.shoot(rays, nthreads=32)
+    ev, c = kd.Shoot_batch(rays)
+    assert_events_equal(ev, ref, what="kd hall")
+    assert c["hits"] == rc["hits"] == len(rays)
