@@ -123,6 +123,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_vb_sort_small", &m->vb_sort_small},
         {"hare_vb_sort_block", &m->vb_sort_block},
         {"hare_vb_finalize", &m->vb_finalize},
+        {"hare_cell_boxes", &m->cell_boxes},
         {"hare_vb_find_big", &m->vb_find_big},
         {"hare_vb_fill_big", &m->vb_fill_big},
         {"hare_ob_count", &m->ob_count},
@@ -362,6 +363,41 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
     return HARE_OK;
 }
 
+// The voxels' tight boxes (hare_cell_boxes, build_kernels.hip), per topology, from the grid as it stands on the device -- behind either
+// builder.  Margin 2^-20 of the scene's extent; good for ray origins within 1 024 extents of the scene (the kernel's guard).  A grid
+// without them (no kernel in the code object, a degenerate extent) is simply traced as before.
+int upload_cell_boxes(Scene& s, const HipApi* H)
+{
+    for (void*& p : s.d_cellbox) dev_free(H, p);
+    s.d_cellbox.assign(s.topos.size(), nullptr);
+    s.cellbox_rad = -1;
+    if (!s.module || !s.module->cell_boxes || !s.vox.built || s.d_cells.size() != s.topos.size() || s.d_polys.size() != s.topos.size()) return HARE_OK;
+    double ext = 0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, s.vox.omax[a] - s.vox.omin[a]);
+    for (const Topo& T : s.topos)
+        for (int a = 0; a < 3; ++a) ext = std::max(ext, T.mx[a] - T.mn[a]);
+    if (!(ext > 0 && std::isfinite(ext) && ext < 1e100)) return HARE_OK;
+    const double delta = std::ldexp(ext, -20);
+    const long long ncell = (long long)s.vox.ct * s.vox.ct * s.vox.ct;
+    for (size_t m = 0; m < s.topos.size(); ++m) {
+        if (!s.d_cells[m] || !s.d_items[m] || !s.d_polys[m]) continue;
+        HIP_TRY(H->Malloc(&s.d_cellbox[m], (size_t)ncell * 8 * sizeof(float)));
+        const void* cells = s.d_cells[m];
+        const void* items = s.d_items[m];
+        const void* polys = s.d_polys[m];
+        const void* quads = s.d_quads[m];
+        long long nc = ncell;
+        double dl = delta;
+        void* out = s.d_cellbox[m];
+        void* args[] = {&cells, &items, &polys, &quads, &nc, &dl, &out};
+        if (int rc = launch(H, s.module->cell_boxes, (unsigned)((ncell + 255) / 256), 256, 0, nullptr, args)) return rc;
+    }
+    HIP_TRY(H->StreamSynchronize(nullptr));
+    for (int a = 0; a < 3; ++a) s.cellbox_mid[a] = 0.5 * (s.vox.omin[a] + s.vox.omax[a]);
+    s.cellbox_rad = 1024.0 * ext;
+    return HARE_OK;
+}
+
 // One persistent launch (K1p, K1q, K2p, K2q) on the next slot of the scene's launch-slot ring.  The slot holds the launch's
 // ticket word, done counters and counter shards (LaunchSlotMem); the launch's own last wave leaves it zeroed, so nothing is
 // enqueued in front of the kernel or behind it.  A slot comes round again after kLaunchSlots launches, possibly on another
@@ -492,6 +528,7 @@ void read_env_options(SceneOptions& o)
     if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : (strcmp(k, "dense") == 0 ? 4 : 0)));
     if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
     if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
+    if (const char* t = getenv("HARE_VOXEL_TIGHT")) o.voxel_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
     if (const char* t = getenv("HARE_K2P_TAIL_MAX")) o.k2p_tail_max = atoi(t);
     if (const char* t = getenv("HARE_K2P_TAIL_PATIENCE")) o.k2p_tail_patience = atoi(t);
@@ -721,6 +758,11 @@ static void fill_voxel_args(const Scene& s, int32_t top, VoxelArgs& g)
     g.occ_words = s.occ_words;
     g.occ_shift = s.occ_shift;
     g.occ_cd = s.occ_cd;
+    if (s.opt.voxel_tight && (size_t)top < s.d_cellbox.size() && s.cellbox_rad > 0) {
+        g.cellbox = (const float*)s.d_cellbox[(size_t)top];
+        for (int a = 0; a < 3; ++a) g.cellbox_mid[a] = s.cellbox_mid[a];
+        g.cellbox_rad = s.cellbox_rad;
+    }
     for (int a = 0; a < 3; ++a) {
         g.omin[a] = s.vox.omin[a];
         g.omax[a] = s.vox.omax[a];
@@ -922,23 +964,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return HARE_E_STATE;
         }
         VoxelArgs g;
-        memset(&g, 0, sizeof g);
-        g.polys = (const PolyRec*)s.d_polys[top];
-        g.cull = (const unsigned char*)s.d_cull[top];
-        g.cf = s.cull_frames[(size_t)top];
-        g.quads = (const QuadRec*)s.d_quads[top];
-        g.cells = (const CellRec*)s.d_cells[top];
-        g.items = (const int32_t*)s.d_items[top];
-        g.occ = (const uint32_t*)s.d_occ[top];
-        g.ct = s.vox.ct;
-        g.occ_words = s.occ_words;
-        g.occ_shift = s.occ_shift;
-        g.occ_cd = s.occ_cd;
-        for (int a = 0; a < 3; ++a) {
-            g.omin[a] = s.vox.omin[a];
-            g.omax[a] = s.vox.omax[a];
-            g.vd[a] = s.vox.vd[a];
-        }
+        fill_voxel_args(s, top, g);
         const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
         if (!kc.f || (kc.k == Kern::VoxelAudit && quads)) {
             set_error(kc.k == Kern::VoxelAudit ? "hare_shoot: cull audit needs an all-triangle topology and the audit kernel"
@@ -1315,7 +1341,7 @@ void hare_scene_destroy(hare_scene* s)
     if (H && (s->module || s->stream)) {
         DeviceGuard dev_guard(H, s->device);   // act on the scene's device, leave the caller's current device as it was
         if (s->stream) (void)H->StreamSynchronize(s->stream);
-        for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ})
+        for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ, &s->d_cellbox})
             for (void*& p : *v) dev_free(H, p);
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_oct_tail})
             dev_free(H, *p);
@@ -1477,7 +1503,10 @@ static int sync_partition_to_device(hare_scene* s, int kind)
     if (rc) return rc;
     rc = upload_polys(*s, H);
     if (rc) return rc;
-    if (kind == HARE_KIND_VOXEL) return upload_voxel(*s, H);
+    if (kind == HARE_KIND_VOXEL) {
+        rc = upload_voxel(*s, H);
+        return rc ? rc : upload_cell_boxes(*s, H);
+    }
     if (kind == HARE_KIND_OCTREE) {
         // the device copy of a leaf carries its first two list entries; that of an interior node the mask of its children that are
         // EMPTY leaves, by octant (OctNode, hare_device.h): popping one has no effect, so K2p / K2d never push it
@@ -1555,7 +1584,7 @@ int hare_voxel_build(hare_scene* s, int32_t domain)
     free_host_mirror(*s);
     int rc = try_gpu_voxel_build(s, domain, 0, 0, &on_gpu);
     if (rc) return rc;
-    if (on_gpu) return HARE_OK;
+    if (on_gpu) return upload_cell_boxes(*s, hip_api(nullptr));
     rc = build_voxel_fixed(*s, domain);
     if (rc) return rc;
     return sync_partition_to_device(s, HARE_KIND_VOXEL);
@@ -1578,7 +1607,7 @@ int hare_voxel_build_adaptive(hare_scene* s, int32_t max_domain, int32_t avg_pol
     free_host_mirror(*s);
     int rc = try_gpu_voxel_build(s, 0, max_domain, avg_polys, &on_gpu);
     if (rc) return rc;
-    if (on_gpu) return HARE_OK;
+    if (on_gpu) return upload_cell_boxes(*s, hip_api(nullptr));
     rc = build_voxel_adaptive(*s, max_domain, avg_polys);
     if (rc) return rc;
     return sync_partition_to_device(s, HARE_KIND_VOXEL);
@@ -2190,6 +2219,7 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"octree_kernel", &SceneOptions::octree_kernel, 0, 4},
         {"octree_tail", &SceneOptions::octree_tail, 0, 2},
         {"octree_tight", &SceneOptions::octree_tight, 0, 1},
+        {"voxel_tight", &SceneOptions::voxel_tight, 0, 1},
         {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},
         {"k2p_tail_max", &SceneOptions::k2p_tail_max, 0, 64},
         {"k2p_tail_patience", &SceneOptions::k2p_tail_patience, -1, 100000},

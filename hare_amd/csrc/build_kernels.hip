@@ -328,6 +328,41 @@ __global__ __launch_bounds__(256) void hare_ob_fill(BuildArgs b, const OctTask* 
     octree_task<true>(b, tasks, pitems, nullptr, oitems);
 }
 
+// The voxels' TIGHT boxes (api.cpp: upload_cell_boxes; used by K1q, voxel_pool.hip): per voxel the bounding box of ALL polygons its list
+// holds -- whole polygons, not clipped to the voxel: Voxel_Grid.Shoot records a hit wherever it lies on the polygon (Voxel_Grid.cs:691-699)
+// -- grown by `delta` and rounded outwards to floats.  8 floats per voxel: lo xyz, hi xyz, two spare; an empty voxel gets an empty box.
+__global__ __launch_bounds__(256) void hare_cell_boxes(const CellRec* cells, const int32_t* items, const PolyRec* polys, const QuadRec* quads,
+                                                       long long ncell, double delta, float* out)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const CellRec cr = cells[c];
+    const double inf = __builtin_huge_val();
+    double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (uint32_t q = 0; q < cr.count; ++q) {
+        const int i = items[cr.start + q];
+        const PolyRec& p = polys[i];
+        auto corner = [&](const double* v) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double x = v[a];
+                if (!(x == x)) { lo[a] = -inf; hi[a] = inf; }            // a NaN corner: the box is everything
+                else { lo[a] = x < lo[a] ? x : lo[a]; hi[a] = x > hi[a] ? x : hi[a]; }
+            }
+        };
+        corner(p.v0); corner(p.v1); corner(p.v2);
+        if (quads && quads[i].nverts == 4) corner(quads[i].v3);
+    }
+    float* o = out + 8 * c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o[a] = __double2float_rd(lo[a] - delta);
+        o[3 + a] = __double2float_ru(hi[a] + delta);
+    }
+    o[6] = 0.0f; o[7] = 0.0f;
+}
+
+
 // cell records (start, count, first two entries inlined) + occupancy bitmap (zeroed beforehand)
 __global__ __launch_bounds__(256) void hare_vb_finalize(const uint32_t* start, const int32_t* items, CellRec* cells,
                                                         uint32_t* occ, long long ncell, unsigned long long* stats,

@@ -75,6 +75,10 @@ struct VoxelArgs {
     double vd[3];              // VoxelDims
     const unsigned char* cull; // the pre-cull's dense records, kCullStride bytes per polygon
     CullFrame cf;
+    const float* cellbox;      // nullable: per voxel {lo xyz, hi xyz, 0, 0}: the box of ALL polygons its list holds, grown by a margin and rounded
+                               // outwards (build_kernels.hip: hare_cell_boxes).  A ray that misses it cannot hit any of them (K1q, voxel_pool.hip)
+    double cellbox_mid[3];     // ... for origins with |o - cellbox_mid|_inf <= cellbox_rad only (the margin is sized for those)
+    double cellbox_rad;
 };
 
 struct OctNode {               // 64 bytes

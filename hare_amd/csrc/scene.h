@@ -40,6 +40,7 @@ struct SceneOptions {
     int k2p_static_rays = 0;
     int bounce_fused = 0;      // 1: the bounce loop of a Voxel_Grid runs as ONE launch where the pool kernel serves (hare_voxel_bounce_*); 0 (default): a launch
                                // per cast -- measured: the hall +2.5 %, the cathedral -0 ... -10 % (a chip that works on all casts at once loses the L2 locality of one band)
+    int voxel_tight = 1;       // 1: K1q sends a ray on past an occupied voxel whose polygons it cannot hit (the voxels' tight boxes, api.cpp: upload_cell_boxes); 0: every list the reference scans (A/B)
     int octree_tight = 1;      // 1: K2d / K2p skip a popped node whose subtree's polygons the ray cannot hit (the tight boxes of api.cpp); 0: every node the reference visits (A/B)
     int octree_tail = 2;       // what finishes the rays K2p gives up: 0 nothing (every lane finishes its own), 1 K2t (a wave per ray, a wave's last 16), 2 K2g-tail (eight lanes per ray, all of them)
     int k2p_tail_max = 0;      // developer sweeps: hand over once at most this many rays are alive in a wave (0 = the rule) ...
@@ -103,7 +104,7 @@ struct DeviceModule {
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
     hipFunction_t vb_count = nullptr, vb_fill = nullptr, vb_level_count = nullptr, vb_level_fill = nullptr;
-    hipFunction_t scan_block = nullptr, scan_add = nullptr, vb_sort_small = nullptr, vb_sort_block = nullptr, vb_finalize = nullptr;
+    hipFunction_t scan_block = nullptr, scan_add = nullptr, vb_sort_small = nullptr, vb_sort_block = nullptr, vb_finalize = nullptr, cell_boxes = nullptr;
     hipFunction_t vb_find_big = nullptr, vb_fill_big = nullptr;
     hipFunction_t ob_count = nullptr, ob_fill = nullptr;
     int cu_count = 0;
@@ -149,6 +150,8 @@ struct Scene {
     std::vector<CullFrame> cull_frames;          // per topo: how those records decode
     std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
+    std::vector<void*> d_cellbox;                // per topo: the voxels' tight boxes, 8 floats per voxel (api.cpp: upload_cell_boxes); null = none
+    double cellbox_mid[3] = {0, 0, 0}, cellbox_rad = -1;   // ray origins they may be used for: |o - mid|_inf <= rad
     int32_t occ_words = 0;                       // words of the occupancy bitmap the persistent kernel stages in LDS
     int32_t occ_shift = 0, occ_cd = 0;           // bitmap resolution: one bit per (2^occ_shift)^3 voxels, occ_cd blocks per axis
     void* d_oct_nodes = nullptr;

@@ -187,6 +187,26 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                                     : (uint32_t)cell;
         return (locc[bit >> 5] >> (bit & 31)) & 1u;
     };
+    // The voxel's tight box (hare_cell_boxes; api.cpp: upload_cell_boxes): does the ray (origin as the walk uses it, i.e. moved) miss the box
+    // of ALL polygons of the voxel's list?  Then the exact test cannot accept any of them and scanning the list would leave the ray as
+    // it is.  FP64 slab test on reciprocals refined once (2^-47); the box is grown by 2^-20 of the scene's extent, a million times the
+    // rounding of either test; rays that are not finite or start beyond 1 024 extents of the scene are never said to miss.  fmax / fmin
+    // drop a NaN operand: a slab whose 1/d is infinite says nothing unless the origin lies outside it, where both products are the same
+    // infinity and the ray is rightly found to miss.
+    auto misses_cell_box = [&](int cell, double ox, double oy, double oz, double dx, double dy, double dz) -> bool {
+        const float4* bp = reinterpret_cast<const float4*>(g.cellbox) + 2 * (size_t)cell;
+        const float4 b0 = bp[0], b1 = bp[1];
+        auto recip = [](double d) { const double y = __builtin_amdgcn_rcp(d); return __builtin_fma(y, __builtin_fma(-d, y, 1.0), y); };
+        const double ix = recip(dx), iy = recip(dy), iz = recip(dz);
+        const double x0 = ((double)b0.x - ox) * ix, x1 = ((double)b0.w - ox) * ix;
+        const double y0 = ((double)b0.y - oy) * iy, y1 = ((double)b1.x - oy) * iy;
+        const double z0 = ((double)b0.z - oz) * iz, z1 = ((double)b1.y - oz) * iz;
+        const double tn = __builtin_fmax(__builtin_fmax(__builtin_fmin(x0, x1), __builtin_fmin(y0, y1)), __builtin_fmin(z0, z1));
+        const double tf = __builtin_fmin(__builtin_fmin(__builtin_fmax(x0, x1), __builtin_fmax(y0, y1)), __builtin_fmax(z0, z1));
+        const bool near_scene = fabs(ox - g.cellbox_mid[0]) <= g.cellbox_rad && fabs(oy - g.cellbox_mid[1]) <= g.cellbox_rad &&
+                                fabs(oz - g.cellbox_mid[2]) <= g.cellbox_rad && fabs(dx) < 1e300 && fabs(dy) < 1e300 && fabs(dz) < 1e300;
+        return near_scene && ((tf < tn) | (tf < 0));
+    };
     // one DDA step, Voxel_Grid.cs:713-759 written with selects (same booleans, same order; see K1p)
 #define HARE_K1Q_STEP()                                                                          \
     {                                                                                            \
@@ -576,9 +596,25 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             unsigned q = 0, qe = 0;
             int idx = -1, nexti = -1;
             if (to_cull) {
-                const CellRec c = g.cells[(X * ct + Y) * ct + Z];
+                const int cell = (X * ct + Y) * ct + Z;
+                const CellRec c = g.cells[cell];
                 q = c.start; qe = c.start + c.count; idx = c.i0; nexti = c.i1;
                 if (COARSE && c.count == 0) { to_cull = false; walking = true; }   // the block is occupied, this voxel is not: walk on
+                // the voxel's tight box (above): the ray cannot hit anything of this list -- it walks on as if the voxel were empty.  (A wall
+                // next to the ray's path: its polygons lie in the voxels the ray crosses, but their box is a thin slab the ray never
+                // reaches -- two in five of the list entries a reflected ray scans in the cathedral.)  Only here, where a ray without
+                // a hit meets an occupied voxel in the pool's ordinary walk: the same test in the wide walk of the drain and in the
+                // cooperative tail was measured and is worth nothing (C4 shard -2.5 % with it in the tail; k1q_box_variants.log).
+                if (g.cellbox != nullptr && to_cull) {
+                    const unsigned ray = L_ray[slot];
+                    const RayRec r = io.rays[ray];
+                    double ox = r.x, oy = r.y, oz = r.z;
+                    if ((xf & F_MOVED) && !writeback) {
+                        const double ts = reinterpret_cast<const double*>(&io.out[ray])[1];
+                        ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
+                    }
+                    if (misses_cell_box(cell, ox, oy, oz, r.dx, r.dy, r.dz)) { to_cull = false; walking = true; }
+                }
             }
             if (act && !exited) {
                 L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
