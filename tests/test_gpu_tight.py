@@ -185,3 +185,90 @@ def test_kdtree_with_and_without_the_boxes():
     ev, c = kd.Shoot_batch(rays)
     assert_events_equal(ev, ref, what="kd hall")
     assert c["hits"] == rc["hits"] == len(rays)
+
+
+# ---------------------------------------------------------------------------------------------------------------- Voxel_Grid
+def voxel_both_ways(g, o, rays, what, **kw):
+    """K1q with the voxels' tight boxes on and off against the oracle (scene option voxel_tight)."""
+    okw = {("excl1" if k == "poly_origin1" else "excl2"): v for k, v in kw.items()}
+    ref, rc = o.shoot(rays, **okw)
+    for tight in (1, 0):
+        g.set_option("voxel_tight", tight)
+        ev, c = g.Shoot_batch(rays, **kw)
+        assert_events_equal(ev, ref, what=f"voxel {what} tight={tight}")
+        assert c["hits"] == rc["hits"]
+    g.set_option("voxel_tight", 1)
+    return ref
+
+
+def test_voxel_tight_boxes_change_nothing():
+    """A ray without a hit that meets an occupied voxel whose polygons it cannot hit walks on without scanning the list (voxel_pool.hip).
+    Ties / faces / planes, a soup with quadrilaterals, exclusions, origins outside the grid (AABB.Intersect moves them: the box test uses
+    the moved origin) with and without the origin write-back, far origins and degenerate directions, one voxel ... a coarse bitmap."""
+    v, nv, size = tie_scene()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = np.concatenate([tie_rays(v, nv, size, n=5000), face_rays(v, nv, size)])
+    for D in (1, 8, 21, 64):
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        assert g.kernel_name(len(rays)).startswith("hare_voxel_pool")
+        ref = voxel_both_ways(g, o, rays, f"ties D={D}")
+        voxel_both_ways(g, o, rays, f"ties D={D} excl", poly_origin1=ref["poly_id"].astype(np.int32))
+
+    v, nv, size = soup(n_tri=700, n_quad=300, seed=21)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rng = np.random.default_rng(8)
+    n = 6000
+    tgt = rng.uniform(0.1, 0.9, (n, 3)) * np.asarray(size)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    far = np.concatenate([tgt - u * (6.0 * 10.0 ** rng.integers(1, 10, n).astype(np.float64))[:, None], u * 2.0 ** rng.integers(-30, 30, n)[:, None]], 1)
+    near = soup_rays(30_000, size, seed=4)
+    near[::5, 3] = 1e-17; near[1::5, 4] = 0.0; near[2::5, 5] = -0.0; near[3::25, 3:] *= 1e-200; near[4::25, 3:] *= 1e200
+    rays = np.ascontiguousarray(np.concatenate([near, far, face_rays(v, nv, size, n=6000, seed=9)]))
+    e1 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+    e2 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+    for D in (5, 12, 31, 128):                 # 128: one occupancy bit per block of voxels (the `_g` kernels)
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        voxel_both_ways(g, o, rays, f"soup D={D}")
+        voxel_both_ways(g, o, rays, f"soup D={D} excl", poly_origin1=e1, poly_origin2=e2)
+        refm, _, moved = o.shoot(rays, mutate=True)
+        for tight in (1, 0):
+            g.set_option("voxel_tight", tight)
+            r = rays.copy()
+            ev, _ = g.Shoot_batch(r, writeback_origin=True)
+            assert_events_equal(ev, refm, what=f"soup D={D} write-back tight={tight}")
+            assert np.array_equal(r.view(np.int64), moved.view(np.int64))
+        g.set_option("voxel_tight", 1)
+
+
+def test_voxel_tight_boxes_in_the_bounce_loop_and_over_two_topologies():
+    """Reflected rays start ON a polygon -- inside its voxel's box -- and skim their wall: where the boxes reject most.  Cast by cast
+    against the oracle's loop, boxes on and off, a launch per cast and the one-launch loop; then a grid over two topologies."""
+    from tests.helpers import oracle_bounce_loop
+    m = H.scenes.hall()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    rays = H.scenes.burst_rays(120_000, m.size)
+    g, o = H.Voxel_Grid([T], 64), po.VoxelGrid([To], domain=64)
+    ref, rc = oracle_bounce_loop(po, To, o, rays, 6)
+    for tight in (1, 0):
+        g.set_option("voxel_tight", tight)
+        for fused in (0, 1):
+            g.set_option("bounce_fused", fused)
+            ev, c, pcs = g.Bounce_batch(rays, 6, per_cast=True, all_casts=True)         # every cast's events (a launch per cast, packing)
+            for b in range(6):
+                assert_events_equal(ev[b], ref[b], what=f"bounce cast {b} tight={tight} fused={fused}")
+            assert [(p["rays"], p["hits"]) for p in pcs] == [(p["rays"], p["hits"]) for p in rc]
+            last, c, pcs = g.Bounce_batch(rays, 6, per_cast=True)                       # the last cast only (one launch when fused)
+            assert last.tobytes() == ref[5].tobytes(), (tight, fused)
+            assert [(p["rays"], p["hits"]) for p in pcs] == [(p["rays"], p["hits"]) for p in rc]
+    g.set_option("bounce_fused", 0); g.set_option("voxel_tight", 1)
+
+    v0, n0, size = soup()
+    v1, n1, _ = soup(n_tri=300, n_quad=80, seed=9, size=(5.0, 4.5, 3.5))
+    g = H.Voxel_Grid([H.Topology(v0, n0), H.Topology(v1, n1)], 10)
+    o = po.VoxelGrid([po.Topology(v0, n0), po.Topology(v1, n1)], domain=10)
+    rays = soup_rays(20_000, size)
+    for top in (0, 1):
+        ref, _ = o.shoot(rays, top_index=top)
+        for tight in (1, 0):
+            g.set_option("voxel_tight", tight)
+            assert_events_equal(g.Shoot_batch(rays, top_index=top)[0], ref, what=f"voxel two topologies top {top} tight={tight}")
