@@ -583,6 +583,11 @@ def measure(w, env):
                                  "T_tests": round(ctr["tests"] / max(casts, 1), 2)},
                     # what the counters say actually bounds the kernel: the scene is cache-resident, HBM is a few % busy
                     "measured_bound": "valu issue + dependent-load latency (not HBM)",
+                    # `achieved` prices the REFERENCE algorithm's cells / list entries / tests per ray (counted by the
+                    # oracle).  The kernels skip lists and subtrees whose polygons the ray provably cannot hit (the tight boxes,
+                    # DESIGN.md 5), so they touch fewer bytes than that and `frac` can pass 1.0 on the trees: it is a rate in units of
+                    # the reference's work, not bytes moved -- those are `traffic`.
+                    "numerator": "the reference algorithm's bytes per ray (oracle counters); tight boxes skip part of that work",
                     "issue_side": issue,
                     "hbm_busy_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1)}
