@@ -170,10 +170,10 @@ HARE_API void hare_scene_destroy(hare_scene *s);
 /* Diagnostics and A/B switches of ONE scene, for tests, profiling and tools; production callers never need them.  A scene takes
  * its defaults from the environment ONCE, inside hare_scene_create (HARE_BUILD=host; and, only in a process that opted in with
  * HARE_DEV=1, HARE_VOXEL_KERNEL = pool|persist, HARE_OCTREE_KERNEL = dense|group|persist|pool, HARE_TICKET, HARE_K1P_STATIC_RAYS, HARE_K2P_STATIC_RAYS,
- * HARE_BATCH_CHUNKS, HARE_TUNE): no call reads the environment afterwards.  Options:
+ * HARE_BATCH_CHUNKS, HARE_OCTREE_TIGHT, HARE_VOXEL_TIGHT, HARE_TUNE): no call reads the environment afterwards.  Options:
  *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
- *   "octree_kernel"   0: the library's rule (K2g below 426k rays on a 256-CU part, K2d above), 1: hare_octree_persist (K2p, one lane per ray),
+ *   "octree_kernel"   0: the library's rule (K2g below 196 608 rays on a 256-CU part, K2d from there), 1: hare_octree_persist (K2p, one lane per ray),
  *                     2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray), 4: hare_octree_dense (K2d: K2p with its leaf
  *                     entries spread densely over the wave and its exact tests deferred)
  *   "bounce_fused"    1: hare_bounce_device / hare_bounce_batch (last cast's events only) run a Voxel_Grid's bounce loop as ONE launch where they can; 0 (default): a launch per cast
@@ -184,6 +184,10 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
  *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per
  *                     ray: its candidates four per lane, the occupied voxels ahead one per lane); 0: off.  Results never depend on it
+ *   "octree_tight"    1 (default): the octree and kd-tree kernels drop a node whose subtree's polygons the ray cannot hit -- per node the box of
+ *                     all polygons its subtree lists, built when the tree goes to the device; 0: every node the reference visits.  Results never
+ *                     depend on it (an X_Event is the reference's bit for bit either way)
+ *   "voxel_tight"     the same per voxel: a ray without a hit walks on past an occupied voxel whose polygons it cannot hit; 1 (default) / 0
  *   "dev"             1: developer flag bits of hare_shoot_* (timeline, phase profile, cull audit) pass
  * Single-caller like the build calls: not to be changed while shoots are in flight on the scene. */
 HARE_API int hare_scene_set_option(hare_scene *s, const char *name, int64_t value);
