@@ -272,3 +272,36 @@ def test_voxel_tight_boxes_in_the_bounce_loop_and_over_two_topologies():
         for tight in (1, 0):
             g.set_option("voxel_tight", tight)
             assert_events_equal(g.Shoot_batch(rays, top_index=top)[0], ref, what=f"voxel two topologies top {top} tight={tight}")
+
+
+def test_rays_that_graze_polygon_boxes_by_less_than_the_margin():
+    """Where the boxes have the least room: targets ON polygon edges and corners (= on the faces and corners of the polygons' boxes) moved
+    by 0, 1e-15 ... 1e-3 in a random direction, from origins up to a thousand extents away (the range the margin of 2^-20 of the extent is
+    sized for; the rounding of the exact test grows with that distance) and with directions of every magnitude.  Whether such a ray hits
+    is the exact test's business; the boxes must never decide it.  Octree (all kernels), kd-tree and Voxel_Grid against the oracle."""
+    v, nv, size = tie_scene()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rng = np.random.default_rng(77)
+    n = 24_000
+    p = rng.integers(0, len(nv), n)
+    k0 = rng.integers(0, 3, n); k1 = (k0 + 1) % 3
+    A, B = v[p, k0], v[p, k1]
+    w = rng.choice([0.0, 0.25, 0.5, 1.0], n)[:, None]
+    eps = rng.choice([0.0, 1e-15, 1e-13, 1e-11, 1e-9, 1e-7, 1e-5, 1e-3], n)[:, None]
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    tgt = A + (B - A) * w + u * eps
+    dist = np.asarray(size).max() * rng.choice([0.3, 1.0, 10.0, 100.0, 1000.0], n)[:, None]
+    e = rng.normal(size=(n, 3)); e /= np.linalg.norm(e, axis=1, keepdims=True)
+    o = tgt - e * dist
+    d = (tgt - o) * 2.0 ** rng.integers(-20, 20, n)[:, None].astype(np.float64)
+    rays = np.ascontiguousarray(np.concatenate([o, d], 1))
+    oc, oo = H.Octree([T], 6, 4), po.Octree([To], 6, 4)
+    ref = both_ways(oc, oo, rays, "grazing octree")
+    assert 0.3 * n < (ref["hit"] != 0).sum() < n
+    kd, ko = H.KDTree([T], 8, 4), po.KDTree([To], 8, 4)
+    kref, krc = ko.shoot(rays[:8000])
+    for tight in (1, 0):
+        kd.set_option("octree_tight", tight)
+        assert_events_equal(kd.Shoot_batch(rays[:8000])[0], kref, what=f"grazing kd tight={tight}")
+    for D in (8, 32):
+        voxel_both_ways(H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D), rays, f"grazing D={D}")
