@@ -372,12 +372,19 @@ int upload_cell_boxes(Scene& s, const HipApi* H)
     s.d_cellbox.assign(s.topos.size(), nullptr);
     s.cellbox_rad = -1;
     if (!s.module || !s.module->cell_boxes || !s.vox.built || s.d_cells.size() != s.topos.size() || s.d_polys.size() != s.topos.size()) return HARE_OK;
-    double ext = 0;
-    for (int a = 0; a < 3; ++a) ext = std::max(ext, s.vox.omax[a] - s.vox.omin[a]);
+    double ext = 0, mag = 0;
+    for (int a = 0; a < 3; ++a) {
+        ext = std::max(ext, s.vox.omax[a] - s.vox.omin[a]);
+        mag = std::max(mag, std::max(std::fabs(s.vox.omin[a]), std::fabs(s.vox.omax[a])));
+    }
     for (const Topo& T : s.topos)
-        for (int a = 0; a < 3; ++a) ext = std::max(ext, T.mx[a] - T.mn[a]);
-    if (!(ext > 0 && std::isfinite(ext) && ext < 1e100)) return HARE_OK;
-    const double delta = std::ldexp(ext, -20);
+        for (int a = 0; a < 3; ++a) {
+            ext = std::max(ext, T.mx[a] - T.mn[a]);
+            mag = std::max(mag, std::max(std::fabs(T.mn[a]), std::fabs(T.mx[a])));
+        }
+    if (!(ext > 0 && std::isfinite(ext) && ext < 1e100 && std::isfinite(mag))) return HARE_OK;
+    // 2^-20 of the extent, or of the largest coordinate for a scene far from the origin of its coordinates (as for the trees' boxes)
+    const double delta = std::ldexp(std::max(ext, mag), -20);
     const long long ncell = (long long)s.vox.ct * s.vox.ct * s.vox.ct;
     for (size_t m = 0; m < s.topos.size(); ++m) {
         if (!s.d_cells[m] || !s.d_items[m] || !s.d_polys[m]) continue;
@@ -1474,10 +1481,15 @@ static int upload_tight_boxes(hare_scene* s, const HipApi* H, const Tree& tree, 
     for (int a = 0; a < 3; ++a) { lo[a] = s->topos[0].mn[a]; hi[a] = s->topos[0].mx[a]; }
     for (const Topo& T : s->topos)
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], T.mn[a]); hi[a] = std::max(hi[a], T.mx[a]); }
-    double ext = 0;
-    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
-    if (!(ext > 0 && std::isfinite(ext) && ext < 1e100)) return HARE_OK;
-    const double delta = std::ldexp(ext, -20);
+    double ext = 0, mag = 0;
+    for (int a = 0; a < 3; ++a) {
+        ext = std::max(ext, hi[a] - lo[a]);
+        mag = std::max(mag, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    if (!(ext > 0 && std::isfinite(ext) && ext < 1e100 && std::isfinite(mag))) return HARE_OK;
+    // the margin: 2^-20 of the scene's extent -- or of its largest coordinate when the scene lies far from the origin of its coordinates,
+    // where the rounding of the exact test (and of this one) is that of the COORDINATES, not of the extent
+    const double delta = std::ldexp(std::max(ext, mag), -20);
     for (size_t m = 0; m < s->topos.size(); ++m) {
         if (id_count > s->topos[m].P) continue;
         std::vector<float> tb;

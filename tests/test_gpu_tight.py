@@ -305,3 +305,26 @@ def test_rays_that_graze_polygon_boxes_by_less_than_the_margin():
         assert_events_equal(kd.Shoot_batch(rays[:8000])[0], kref, what=f"grazing kd tight={tight}")
     for D in (8, 32):
         voxel_both_ways(H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D), rays, f"grazing D={D}")
+
+
+def test_a_scene_far_from_the_origin_of_its_coordinates():
+    """The boxes' margin is 2^-20 of the scene's extent OR of its largest coordinate, whichever is larger: a model placed at 1e6 or 1e9
+    (coordinates on the 2^-8 lattice stay exact there) has the rounding of its coordinates in every test, exact or not.  Same events with
+    the boxes on, off and from the oracle, on every partition."""
+    v, nv, size = soup(n_tri=600, n_quad=150, seed=31)
+    rays0 = np.concatenate([soup_rays(12_000, size, seed=6), face_rays(v, nv, size, n=3000, seed=7)])
+    for shift in ((2.0 ** 20, -2.0 ** 21, 2.0 ** 19), (2.0 ** 30, 2.0 ** 30, -2.0 ** 29)):
+        sh = np.asarray(shift)
+        vs = v.copy()
+        for p in range(len(nv)):
+            vs[p, :nv[p]] += sh
+        rays = rays0.copy(); rays[:, :3] += sh
+        T, To = H.Topology(vs, nv), po.Topology(vs, nv)
+        for D in (6, 20):
+            voxel_both_ways(H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D), rays, f"shifted {shift[0]:.0e} D={D}")
+        both_ways(H.Octree([T], 5, 6), po.Octree([To], 5, 6), rays, f"shifted {shift[0]:.0e} octree")
+        kd, ko = H.KDTree([T], 7, 8), po.KDTree([To], 7, 8)
+        kref, _ = ko.shoot(rays[:6000])
+        for tight in (1, 0):
+            kd.set_option("octree_tight", tight)
+            assert_events_equal(kd.Shoot_batch(rays[:6000])[0], kref, what=f"shifted {shift[0]:.0e} kd tight={tight}")
