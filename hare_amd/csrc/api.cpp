@@ -692,7 +692,7 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             // Octree.Shoot has two production kernels (measured on MI355X, hall, 8 levels; profiles/r04_experiments/k2d_*.log, k2_crossover.log):
             //   K2g (octree_group.hip, eight lanes per ray): a ray lives < 100 us, so a launch has next to no drain -- 2.1x K2p at 65k rays --
             //       but it spends 1.5x K2p's instructions per ray: steady state 335 Mrays/s;
-            //   K2d (hare_octree_dense: one lane per ray, leaf entries spread densely over the wave, exact tests deferred) from 425 984 rays:
+            //   K2d (hare_octree_dense: one lane per ray, leaf entries spread densely over the wave, exact tests deferred) from 425 984 rays (first half of round 4; see below):
             //       K2d / K2g Mrays/s at 262k 235 / 256, 393k 271 / 281, 524k 350 / 301, 786k 441 / 312, 1M 493 / 319, 4M 656 / 337.
             //   K2p (hare_octree_persist) is K2d's predecessor: the A/B baseline (octree_kernel = 1) and the fall-back where K2d's LDS does not fit.
             // The threshold scales with the CU count.
