@@ -32,6 +32,15 @@ namespace Hare
             /// shards (hare_shoot_batch_sharded): the in-process way to use all GPUs of a node.</summary>
             public static int[] Devices = null;
 
+            /// <summary>Opt-in, default off: reproduce the reference's Ray_ID == 0 rule.  Voxel_Grid.Shoot and KDTree.Shoot skip a
+            /// polygon whose mailbox entry equals R.Ray_ID (Voxel_Grid.cs:687-689, KDTree.cs:224-229) and the mailbox starts out all
+            /// zero, so a ray with Ray_ID == 0 finds every polygon "already tested" and the reference returns X_Event() -- after
+            /// moving an outside origin like for any ray.  The GPU classes keep no mailbox and return the hit; with this switch on,
+            /// Shoot(R, ...) and Shoot(Ray[], ...) return X_Event() for rays whose Ray_ID is 0 (Voxel_Grid and KDTree; the live
+            /// Octree has no mailbox, "Octree - alt.cs":221-222).  The reference's rule is stateful (a polygon another ray of the
+            /// same ThreadID tested since is no longer skipped); this reproduces the fresh-mailbox case.</summary>
+            public bool MailboxRayId0 = false;
+
             protected IntPtr scene = IntPtr.Zero;                 // replica 0 (== scenes[0])
             protected IntPtr[] scenes = new IntPtr[0];            // all replicas, in shard order
             protected abstract int Kind { get; }
@@ -116,7 +125,9 @@ namespace Hare
                 for (int i = 0; i < n; i++)
                 {
                     rays[i].x = r[i].x; rays[i].y = r[i].y; rays[i].z = r[i].z;       // F11: the reference mutates R
-                    results[i] = ev[i].hit != 0
+                    bool id0 = MailboxRayId0 && Kind != HareHip.HARE_KIND_OCTREE && rays[i].Ray_ID == 0;
+                    if (id0 && ev[i].hit != 0) ctr.hits--;
+                    results[i] = (ev[i].hit != 0 && !id0)
                         ? new X_Event(new Point(ev[i].x, ev[i].y, ev[i].z), ev[i].u, ev[i].v, ev[i].t, ev[i].poly_id)
                         : new X_Event();
                 }
@@ -184,6 +195,7 @@ namespace Hare
                 hare_xevent ev;
                 HareHip.Check(HareHip.hare_shoot_one(scene, Kind, top_index, ref r, poly_origin1, poly_origin2, out ev));
                 R.x = r.x; R.y = r.y; R.z = r.z;                                  // F11: the reference mutates R
+                if (MailboxRayId0 && Kind != HareHip.HARE_KIND_OCTREE && R.Ray_ID == 0) { Ret_event = new X_Event(); return false; }
                 Ret_event = ev.hit != 0 ? new X_Event(new Point(ev.x, ev.y, ev.z), ev.u, ev.v, ev.t, ev.poly_id) : new X_Event();
                 return Ret_event.Hit;
             }

@@ -994,6 +994,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(128, (per_wave + 7) / 8 * 8));
             if (s.opt.k1p_static_rays > 0) io.static_rays = std::max(8, std::min(1024, s.opt.k1p_static_rays / 8 * 8));   // developer sweeps (tools/k1q_ticket_sweep.py)
             io.ticket_rays = ticket_rays_for(s, n, true);
+            if (s.opt.dev && s.opt.dev_order_ptr) io.order = (const uint32_t*)(uintptr_t)s.opt.dev_order_ptr;
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }
         // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
@@ -2242,6 +2243,10 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},
         {"wide_drain", &SceneOptions::wide_drain, 0, 1},
     };
+    if (strcmp(name, "dev_order_ptr") == 0) {       // developer experiments: see SceneOptions::dev_order_ptr
+        s->opt.dev_order_ptr = (long long)value;
+        return HARE_OK;
+    }
     for (auto& t : table)
         if (strcmp(t.name, name) == 0) {
             if (value < t.lo || value > t.hi) {

@@ -377,6 +377,8 @@ struct ShootIO {
     XEventRec* out_all;        // nullable: bounce_casts x out_stride records, cast-major: every cast's final X_Event (pre-filled with miss records)
     int64_t out_stride;
     unsigned long long* ctr_casts;   // nullable: bounce_casts counter blocks (rays = rays that started the cast, hits), accumulated
+    const uint32_t* order;     // K1q, nullable: the ORDER in which the launch takes the batch's rays -- position k of the static chunks / tickets is ray
+                               // order[k] (a permutation of 0 .. n-1; rays, events and exclusions stay where the caller has them)
     unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
     int32_t oct_spill_cap;
 };

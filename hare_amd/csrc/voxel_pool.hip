@@ -24,10 +24,21 @@
 // .x .y .z = that hit's point, the {Hit, Poly_id} word = its polygon, .u = t_start of a ray whose origin
 // AABB.Intersect moved (the moved origin itself is o + d * t_start, the expression of AABB_Main.cs:254-256).
 // INVARIANT: that scratch (and, with origin write-back, the ray record) is written by one lane of the wave with plain stores
-// and read in a later phase by whichever lane pops the ray.  All of a wave's accesses go through its CU's one L1 in program
-// order, so the value is there; what states the ordering to the compiler is the wavefront-scope fence in front of every
-// phase (no instruction in hardware).  It holds only while no OTHER wave touches those bytes: the host refuses calls whose
-// rays / events / exclusion buffers overlap (api.cpp).
+// and read in a later phase by whichever lane pops the ray -- a store -> load hand-over between LANES OF ONE WAVEFRONT, never between
+// waves.  What it rests on (LLVM AMDGPU backend user guide, "Memory Model", the GFX90A / GFX942 family sections, which gfx950 shares):
+//   * the hardware description there: every CU has ONE vector L1, write-through, and a wavefront's vector-memory operations are
+//     performed in order through it; "no special action is required for coherence between the lanes of a single wavefront, or for
+//     coherence between wavefronts in the same work-group" (work-groups not in tgsplit mode -- these kernels are built without
+//     -mtgsplit);
+//   * the code-sequence table of the same section: `fence acq_rel` at syncscope "wavefront" expands to NO instruction (no s_waitcnt,
+//     no buffer_inv / buffer_wbl2), i.e. program order of the wave's own loads and stores is all the memory model asks for there.
+// So the fence in front of every phase (HARE_K1Q_PHASE_FENCE) is there for the COMPILER -- it may not move the scratch loads of a
+// phase above the scratch stores of the previous one, nor keep a stale copy in registers -- and costs nothing at run time.  The
+// loads that follow are ordinary global_loads, and the s_waitcnt vmcnt the compiler puts in front of their first use is the only
+// wait involved; the earlier store needs none of its own, because the later load of the same wave queues behind it in the same L1.
+// The invariant holds only while no OTHER wave touches those bytes (another CU's L1 is never refreshed by this one's stores: that
+// would need the agent-scope forms): the host refuses calls whose rays / events / exclusion buffers overlap (api.cpp), and a ray
+// belongs to exactly one wave from its set-up to its final event.
 #ifndef HARE_K1Q_WALK_STEPS
 #define HARE_K1Q_WALK_STEPS 16    // DDA steps per walk task at most
 #endif
@@ -317,7 +328,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const unsigned slot = Q_free[(hF + (act ? lane : 0u)) & SM];
                 hF = (hF + m) & SM;
                 nF -= m;
-                const unsigned ray = cn + lane;
+                const unsigned ray = (io.order != nullptr && act) ? io.order[cn + lane] : cn + lane;
                 cn += m;
                 bool to_walk = false, to_cull = false, freed = false;
                 if (act) {

@@ -155,6 +155,15 @@ class Spatial_Partition:
 
     _kind = -1
 
+    #: Opt-in (default off): reproduce the reference's `Ray_ID == 0` rule.  Voxel_Grid.Shoot and KDTree.Shoot skip a polygon whose
+    #: mailbox entry equals R.Ray_ID (Voxel_Grid.cs:687-689, KDTree.cs:224-229) and the mailbox starts out all zero, so a ray with
+    #: Ray_ID == 0 finds every polygon "already tested" and the reference returns X_Event() -- after moving an outside origin as for
+    #: any ray.  The GPU classes keep no mailbox and return the hit; with this switch on, Shoot(R) with
+    #: R.Ray_ID == 0 and Shoot_batch(..., ray_ids=) entries equal to 0 return the miss record on Voxel_Grid and KDTree.  (The
+    #: reference's rule is stateful -- a polygon some OTHER ray of the same ThreadID tested since is no longer skipped; the switch
+    #: reproduces the fresh-mailbox case, which is the one a caller that forgot to assign ids meets.)  Octree has no mailbox.
+    mailbox_ray_id0 = False
+
     def __init__(self, Model_in: Sequence[Topology], device: int = 0):
         self.Model = list(Model_in)
         self.Char_Step = 0.0
@@ -188,6 +197,8 @@ class Spatial_Partition:
         ev = np.zeros(1, XEVENT_DTYPE)
         check(lib.hare_shoot_one(self._h, self._kind, int(top_index), ptr(ray), int(poly_origin1), int(poly_origin2), ptr(ev)))
         R.x, R.y, R.z = (float(c) for c in ray[:3])       # the reference moves R when it starts outside (F11)
+        if self.mailbox_ray_id0 and self._kind != KIND_OCTREE and int(getattr(R, "Ray_ID", 1)) == 0:
+            return False, X_Event()                      # Voxel_Grid.cs:687-689 / KDTree.cs:224-229 on a fresh mailbox
         e = X_Event.from_record(ev[0])
         return e.Hit, e
 
@@ -221,11 +232,13 @@ class Spatial_Partition:
                                        d_counters or None, stream or None))
 
     def Shoot_batch(self, rays, top_index: int = 0, poly_origin1=None, poly_origin2=None,
-                    writeback_origin: bool = False, count_work: bool = False, simple_kernel: bool = False, slim: bool = False):
+                    writeback_origin: bool = False, count_work: bool = False, simple_kernel: bool = False, slim: bool = False,
+                    ray_ids=None):
         """n rays [n,6] through the HIP kernel (host buffers).  Returns (events, counters dict).
         With writeback_origin the rays array is updated in place like the reference mutates R.
         slim=True: the events come back as slim records (capi.SLIM_DTYPE for Voxel_Grid, SLIM_UV_DTYPE for the trees; 16 / 32
-        bytes over the host link instead of 56); expand_events(rays, records) rebuilds the X_Events bit for bit."""
+        bytes over the host link instead of 56); expand_events(rays, records) rebuilds the X_Events bit for bit.
+        ray_ids (optional, one Ray_ID per ray) only matters with `mailbox_ray_id0` on: entries equal to 0 come back as miss records."""
         if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
             rays = np.array(rays, np.float64, order="C")
         rays = rays.reshape(-1, 6)
@@ -241,7 +254,17 @@ class Spatial_Partition:
         ctr = capi.Counters()
         check(lib.hare_shoot_batch(self._h, self._kind, int(top_index), n, ptr(rays), ptr(e1), ptr(e2), flags,
                                    ptr(out), C.addressof(ctr)))
-        return out, ctr.as_dict()
+        ctr = ctr.as_dict()
+        if self.mailbox_ray_id0 and ray_ids is not None and self._kind != KIND_OCTREE:
+            zero = np.asarray(ray_ids).reshape(-1) == 0
+            if zero.shape != (n,):
+                raise ValueError("ray_ids must have one entry per ray")
+            if zero.any():
+                ctr["hits"] -= int(np.count_nonzero(out["hit"][zero]))
+                miss = np.zeros(1, out.dtype)
+                miss["poly_id"] = -1
+                out[zero] = miss[0]
+        return out, ctr
 
     def _slim_dtype(self):
         return capi.SLIM_DTYPE if self._kind == KIND_VOXEL else capi.SLIM_UV_DTYPE

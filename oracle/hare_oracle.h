@@ -133,6 +133,11 @@ const char *ho_last_error(void);
 void ho_set_error(const char *msg);
 /* grow *p to `bytes` (realloc); 0 = ok, -1 = failed (*p unchanged, error set) */
 int ho_grow(void **p, size_t bytes);
+void *ho_alloc(size_t bytes);                 /* malloc that reports through ho_set_error (and honours the test hook below) */
+/* test hooks: make the k-th following allocation fail; start the traversal stacks small (ho_prims.c) */
+void ho_test_fail_alloc_after(int k);
+void ho_test_stack_cap(int c);
+int ho_initial_stack_cap(int usual);
 
 /* ---------- Octree ("Octree - alt.cs") ---------- */
 typedef struct ho_octree ho_octree;

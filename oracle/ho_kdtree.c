@@ -231,9 +231,10 @@ int ho_kdtree_shoot(const ho_kdtree *k, const ho_topology *models, const ho_ray 
     int hit = 0;
     double closestT = DBL_MAX;
 
-    int scap = k->max_depth + 8;
-    int32_t *stack = (int32_t *)malloc((size_t)scap * sizeof(int32_t));
-    if (!stack) { ho_set_error("oracle: out of memory"); return -1; }     /* an ERROR, not a miss (out holds the miss record, not to be compared) */
+    int scap = ho_initial_stack_cap(k->max_depth + 8);
+    if (scap < 2) scap = 2;
+    int32_t *stack = (int32_t *)ho_alloc((size_t)scap * sizeof(int32_t));
+    if (!stack) return -1;     /* an ERROR, not a miss (out holds the miss record, not to be compared) */
     int sp = 0;
     stack[sp++] = 0;
     const double o[3] = {ray->x, ray->y, ray->z};
@@ -283,11 +284,11 @@ int ho_kdtree_shoot(const ho_kdtree *k, const ho_topology *models, const ho_ray 
                 else { first = cur->right; second = cur->left; }
             }
             if (sp + 2 > scap) {
-                if (ho_grow((void **)&stack, (size_t)scap * 2 * sizeof(int32_t))) {       /* cannot continue this ray: report the failure as a miss */
+                if (ho_grow((void **)&stack, (size_t)scap * 2 * sizeof(int32_t))) {       /* cannot continue this ray: an ERROR (-1), never a miss */
                     free(stack);
                     memset(out, 0, sizeof *out);
                     out->poly_id = -1;
-                    return 0;
+                    return -1;
                 }
                 scap *= 2;
             }

@@ -242,9 +242,9 @@ int ho_octree_shoot(const ho_octree *o, const ho_topology *models, const ho_ray 
                     order[i++] = (ix << 2) | (iy << 1) | iz;
     }
 
-    int scap = 8 * (o->max_depth + 2);
-    sentry *stack = (sentry *)malloc((size_t)scap * sizeof(sentry));
-    if (!stack) { ho_set_error("oracle: out of memory"); miss(out); return -1; }      /* an ERROR, not a miss: callers must not compare this record */
+    int scap = ho_initial_stack_cap(8 * (o->max_depth + 2));
+    sentry *stack = (sentry *)ho_alloc((size_t)scap * sizeof(sentry));
+    if (!stack) { miss(out); return -1; }      /* an ERROR, not a miss: callers must not compare this record */
     int sp = 0;
     stack[sp].node = 0;
     stack[sp].tmin = tmin;

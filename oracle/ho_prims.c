@@ -617,13 +617,33 @@ void ho_set_error(const char *msg)
     strncpy(ho_err, msg ? msg : "", sizeof ho_err - 1);
     ho_err[sizeof ho_err - 1] = 0;
 }
+/* Test hooks (tests/test_tree_budget.py): the checker's own failure paths must be reachable without exhausting the machine.
+ *   ho_test_fail_alloc_after(k)  the k-th following ho_grow / ho_alloc of ANY thread fails (k = 0: the next one); negative: off
+ *   ho_test_stack_cap(c)         the traversal stacks of Octree.Shoot / KDTree.Shoot start with c entries (0: their usual size), so
+ *                                that the growth path runs on an ordinary tree */
+static volatile int ho_fail_countdown = -1;
+static volatile int ho_stack_cap_override = 0;
+void ho_test_fail_alloc_after(int k) { ho_fail_countdown = k; }
+void ho_test_stack_cap(int c) { ho_stack_cap_override = c; }
+int ho_initial_stack_cap(int usual) { return ho_stack_cap_override > 0 ? ho_stack_cap_override : usual; }
+static int ho_alloc_must_fail(void)
+{
+    if (ho_fail_countdown < 0) return 0;
+    return __sync_fetch_and_sub(&ho_fail_countdown, 1) == 0;
+}
 int ho_grow(void **p, size_t bytes)
 {
-    void *q = realloc(*p, bytes ? bytes : 1);
+    void *q = ho_alloc_must_fail() ? NULL : realloc(*p, bytes ? bytes : 1);
     if (!q) {
         ho_set_error("oracle: out of memory");
         return -1;
     }
     *p = q;
     return 0;
+}
+void *ho_alloc(size_t bytes)
+{
+    void *q = ho_alloc_must_fail() ? NULL : malloc(bytes ? bytes : 1);
+    if (!q) ho_set_error("oracle: out of memory");
+    return q;
 }

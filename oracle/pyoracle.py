@@ -84,6 +84,8 @@ def lib():
         L.ho_voxel_pool_free.argtypes = [vp]
         L.ho_voxel_pool_shoot.argtypes = [vp, vp, i32, i32, i32, i32, vp]
         L.ho_last_error.restype = C.c_char_p
+        L.ho_test_fail_alloc_after.argtypes = [C.c_int]
+        L.ho_test_stack_cap.argtypes = [C.c_int]
         L.ho_last_error.argtypes = []
         L.ho_octree_build.restype = vp
         L.ho_octree_build.argtypes = [vp, i32, i32, i32]

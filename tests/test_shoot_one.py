@@ -168,3 +168,43 @@ def test_shoot_one_rate_from_compiled_code(tmp_path, monkeypatch):
     # (no scaling bar: this container's 8 CPUs do not deliver 4 threads' worth of cycles even to the oracle's
     #  embarrassingly parallel loop; the 4-thread pass is here for the result check above -- same bytes, no lock)
     assert float(vals["mrays_4t"]) > 0, out
+
+
+def test_mailbox_ray_id0_option(shoebox, monkeypatch):
+    """Voxel_Grid.cs:687-689 / KDTree.cs:224-229: the mailbox starts out all zero, so the reference returns X_Event() for a ray
+    whose Ray_ID is 0.  The GPU classes keep no mailbox; `mailbox_ray_id0` (default off) reproduces the rule on Voxel_Grid and
+    KDTree -- checked against the oracle's faithful mailbox (first_ray_id = 0: the first ray of the call carries id 0)."""
+    monkeypatch.setenv("HARE_BUILD", "host")
+    m, T = shoebox
+    ot = po.Topology(m.verts, m.nverts)
+    ray = np.array([[3.1, 2.9, 1.5, 0.6, 0.64, 0.48]])
+    for part, orc in ((H.Voxel_Grid([T], D), po.VoxelGrid([ot], domain=D)), (H.KDTree([T], KDD, KDP), po.KDTree([ot], KDD, KDP))):
+        ref_id1, _ = orc.shoot(ray, first_ray_id=1)
+        ref_id0, _ = orc.shoot(ray, first_ray_id=0)
+        assert ref_id1["hit"][0] == 1 and ref_id0["hit"][0] == 0 and ref_id0["poly_id"][0] == -1   # the reference's rule, as the oracle restates it
+        R0 = H.Ray(*ray[0], 0, 0)
+        hit, ev = part.Shoot(R0, 0)
+        assert hit and ev.Poly_id == ref_id1["poly_id"][0]            # default: no mailbox, the hit (INTEGRATION.md 3)
+        part.mailbox_ray_id0 = True
+        hit, ev = part.Shoot(H.Ray(*ray[0], 0, 0), 0)
+        assert not hit and ev.Poly_id == -1 and ev.t == 0.0 and ev.X_Point is None
+        hit, ev = part.Shoot(H.Ray(*ray[0], 0, 7), 0)                # any other id: the hit
+        assert hit and ev.t == ref_id1["t"][0]
+    oc = H.Octree([T], OD, OP)
+    oc.mailbox_ray_id0 = True                                        # the live Octree has no mailbox ("Octree - alt.cs":221-222)
+    assert oc.Shoot(H.Ray(*ray[0], 0, 0), 0)[0]
+
+
+@pytest.mark.gpu
+def test_mailbox_ray_id0_option_on_batches(shoebox):
+    m, T = shoebox
+    g = H.Voxel_Grid([T], D)
+    rays = H.scenes.random_rays(512, m.size)
+    ids = np.arange(512) % 4                                         # every fourth ray carries Ray_ID 0
+    plain, c0 = g.Shoot_batch(rays, ray_ids=ids)
+    g.mailbox_ray_id0 = True
+    ev, c1 = g.Shoot_batch(rays, ray_ids=ids)
+    z = ids == 0
+    assert plain["hit"][z].sum() > 0 and ev["hit"][z].sum() == 0 and (ev["poly_id"][z] == -1).all() and (ev["t"][z] == 0).all()
+    assert ev[~z].tobytes() == plain[~z].tobytes()
+    assert c1["hits"] == c0["hits"] - int(plain["hit"][z].sum())

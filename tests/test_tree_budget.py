@@ -34,3 +34,34 @@ def test_oracle_builders_report_failure_instead_of_crashing():
     with pytest.raises(MemoryError):
         po.KDTree([T], 40, 0)                          # every polygon straddles some split: lists double per level
     assert po.KDTree([T], 6, 4).n_nodes > 1
+
+
+@pytest.mark.parametrize("kind", ["kdtree", "octree"])
+@pytest.mark.parametrize("where", ["first allocation", "stack growth"])
+def test_a_failed_traversal_allocation_raises_and_is_never_a_miss_record(kind, where):
+    """oracle/ho_kdtree.c and ho_octree.c: a ray whose traversal stack cannot be allocated or grown is an ERROR (-1), and
+    pyoracle.shoot raises -- a checker that wrote a miss record there could pass an allocation failure off as a result."""
+    L = po.lib()
+    v, nv, _ = soup(n_tri=80, n_quad=0, seed=3)
+    T = po.Topology(v, nv)
+    tree = po.KDTree([T], 8, 2) if kind == "kdtree" else po.Octree([T], 4, 2)
+    rays = H.scenes.random_rays(64, (6.0, 5.0, 4.0))
+    ref, _ = tree.shoot(rays)
+    assert ref["hit"].sum() > 0
+    try:
+        if where == "stack growth":
+            L.ho_test_stack_cap(2 if kind == "kdtree" else 1)    # the stack must grow on the first interior node
+            grown, _ = tree.shoot(rays)                          # ... and a stack that CAN grow changes nothing
+            for f in ref.dtype.names:
+                assert np.array_equal(grown[f], ref[f])
+            L.ho_test_fail_alloc_after(1)                        # the stack itself is allocated; its first growth fails
+        else:
+            L.ho_test_fail_alloc_after(0)
+        with pytest.raises(MemoryError):
+            tree.shoot(rays)
+    finally:
+        L.ho_test_fail_alloc_after(-1)
+        L.ho_test_stack_cap(0)
+    again, _ = tree.shoot(rays)
+    for f in ref.dtype.names:
+        assert np.array_equal(again[f], ref[f])

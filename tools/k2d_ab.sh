@@ -1,12 +1,13 @@
 #!/bin/bash
+mkdir -p "${GRAFT_REPO_ROOT:-.}/gpurun_out"   # the failing command's stderr is kept there (ERRLOG)
 # Developer A/B: K2d (hare_octree_dense) against K2p, both with the K2g tail, over batch sizes; variant builds optional.  GPU box.
 cd "$(dirname "$0")/.."
 for lib in "${@:-base}"; do
   L=""; [ "$lib" != base ] && L="HARE_LIB=$PWD/hare_amd/libhare_hip_$lib.so"
   for k in persist dense; do
     for n in 524288 1048576 4194304; do
-      env HARE_DEV=1 HARE_OCTREE_KERNEL=$k $L timeout -k 10 120 python bench.py --kind octree --rays $n --steps 6 --warmup 2 --no-e2e --no-cpu-baseline 2>/dev/null |
-        python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$lib $k n=$n', j['value'], j['ms_per_step'])" || echo "$lib $k FAILED"
+      env HARE_DEV=1 HARE_OCTREE_KERNEL=$k $L timeout -k 10 120 python bench.py --kind octree --rays $n --steps 6 --warmup 2 --no-e2e --no-cpu-baseline 2>>"${ERRLOG:=${GRAFT_REPO_ROOT:-.}/gpurun_out/tools_stderr.log}" |
+        python -c "import sys,json; j=json.loads(sys.stdin.read()); print('$lib $k n=$n', j['value'], j['ms_per_step'])" || { echo "$lib $k FAILED -- stderr tail:"; tail -n 8 "${ERRLOG:=${GRAFT_REPO_ROOT:-.}/gpurun_out/tools_stderr.log}"; }
     done
   done
 done
