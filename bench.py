@@ -20,6 +20,8 @@ parity flag and (N = 1) cpu_baseline:
                              the 1M-triangle cathedral, contiguous shards over the N ranks ("scaling": "strong"), hit counters
                              all-reduced (RCCL), max-over-ranks timing, every rank's X_Events checked against the oracle
     c3, c4_shard, c5_shard   N = 1 only: config 3, and one GPU's share of configs 4 / 5 at N = 8 (2M rays; 1M rays x 8)
+    c2_quads                 N = 1 only: the headline workload on `hall_quads` -- the hall with its flat lattices un-split, 39k planar
+                             quadrilaterals + 22k triangles: the quadrilateral build of the voxel kernel (hare_voxel_pool_quad)
 (--no-extra-configs skips them).  --force-dist runs the torch.distributed code path (init, per-step async all-reduce of
 the counters, all-gather of the timings) even at N = 1, so that the RCCL branch can be exercised on a one-GPU box.
 
@@ -58,7 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=1 << 20, help="rays per GPU per step")
     ap.add_argument("--domain", type=int, default=64, help="Voxel_Grid Domain")
-    ap.add_argument("--scene", default="hall", choices=["hall", "cathedral", "shoebox"])
+    ap.add_argument("--scene", default="hall", choices=["hall", "cathedral", "shoebox", "hall_quads"])
     ap.add_argument("--kind", default="voxel", choices=["voxel", "octree", "kdtree"])
     ap.add_argument("--bounces", type=int, default=1,
                     help="casts per step: >1 = device-resident specular bounce loop (BASELINE config 5)")
@@ -173,8 +175,16 @@ def load_traffic(workload_key: str):
         return None
 
 
-GPU_CLOCK_HZ = 2.4e9      # MI355X peak shader clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs
-N_SIMDS = 1024
+N_SIMDS = 1024            # 256 CUs x 4 SIMDs
+# What a wave64 VALU instruction costs a SIMD, by class: ns per instruction per SIMD with four waves resident, MEASURED on the MI355X
+# box with tools/valu_rate.hip (independent instructions; profiles/r05_experiments/valu_rate.log).  FP64 runs at half the FP32 / integer
+# rate (16 lanes per clock and SIMD), v_rcp_f64 at a sixth.  `roofline.issue` prices the PMC instruction counts with these.
+VALU_NS = {"add_f64": 1.98, "mul_f64": 2.32, "fma_f64": 2.61, "trans_f64": 6.95, "other": 1.30}
+
+
+def kd_params(scene: str):
+    """KDTree(maxDepth, maxPolygonsPerNode) per scene: the shoebox as round 4 measured it; the 100k-polygon scenes 16 / 8."""
+    return (12, 16) if scene == "shoebox" else (16, 8)
 
 
 class Env:
@@ -203,7 +213,8 @@ class Env:
             elif kind == "octree":
                 part, kdesc = H.Octree([topo], 8, 16, device=self.device), "Octree maxDepth=8 maxPolys=16"
             else:
-                part, kdesc = H.KDTree([topo], 12, 16, device=self.device), "KDTree maxDepth=12 maxPolys=16"
+                kd_d, kd_p = kd_params(scene)
+                part, kdesc = H.KDTree([topo], kd_d, kd_p, device=self.device), f"KDTree maxDepth={kd_d} maxPolys={kd_p}"
             self.parts[key] = (part, kdesc, time.time() - t0)
         return self.parts[key]
 
@@ -219,7 +230,7 @@ class Env:
             elif kind == "octree":
                 og, ref_name = po.Octree([ot], 8, 16), "Octree.Shoot"
             else:
-                og, ref_name = po.KDTree([ot], 12, 16), "KDTree.Shoot"
+                og, ref_name = po.KDTree([ot], *kd_params(scene)), "KDTree.Shoot"
             self.oracles[key] = (ot, og, ref_name)
         return self.oracles[key]
 
@@ -384,15 +395,17 @@ def measure(w, env):
         cast_pass(0, evs[r])
     torch.cuda.synchronize()
     loop_ms = sum(evs[r][0].elapsed_time(evs[r][1]) for r in range(nrep)) / nrep      # one shoot launch, or the whole bounce loop
-    per_cast_ms = [loop_ms / B] * B
-    kern_ms = loop_ms / B                     # average per cast; an event pair around every call
-    kern_ms_pairs = kern_ms
+    kern_ms_pairs = loop_ms / B               # average per cast; an event pair around every call
+    # ONE estimator of the kernel's duration, stated in the line (ADVICE, round 4: not the smaller of two):
+    #   one rank, one cast per step: a timed step IS one shoot launch and nothing else (the counters run on, no reset kernel), so the two
+    #   HIP events around the K timed launches give the average launch duration over the timed region itself -- what the contract asks
+    #   for, and what rocprofv3's average for the kernel agrees with (profiles/);
+    #   anything else (a reduce per step, a bounce loop): the event pair around every call.
     if B == 1 and dist is None:
-        # one rank, one cast per step: a timed step IS one shoot launch and nothing else (the counters run on, no reset kernel), so the
-        # two events around the K timed launches measure the same launches without an event pair between them -- the average launch
-        # duration "over the timed region"; rocprofv3's average for the kernel agrees with it (profiles/)
-        kern_ms = min(kern_ms, dev_ms / steps)
-        per_cast_ms = [kern_ms]
+        kern_ms, kern_src = dev_ms / steps, "HIP events around the timed region / steps"
+    else:
+        kern_ms, kern_src = kern_ms_pairs, "HIP event pair around every call"
+    per_cast_ms = [kern_ms] * B
     events_dev = out_sets[state["set"]].cpu().numpy().tobytes() if B == 1 else None   # the bench buffers themselves, for the parity check
 
     # measured device-copy bandwidth (what "HBM peak" means in practice on this box) and the host-buffer (PCIe-inclusive) rate
@@ -521,7 +534,14 @@ def measure(w, env):
         # How many threads serve this workload best is measured, not assumed: every worker of the port keeps a mailbox of P entries
         # (as the reference's pool does per ThreadID), so on the 1M-triangle scene 256 threads are slower than 64.  A short sample at
         # a few thread counts picks the count the timed passes use; `cores` reports it beside the box's core count.
-        if world == 1 and not os.environ.get("HARE_CPU_THREADS") and cores > 32:
+        # KDTree.Shoot tests EVERY polygon for every ray in the reference (F4): on a scene of more than a few thousand polygons the
+        # oracle gets every 2^k-th ray of the batch (at most 65 536, all polar bands of the burst) -- parity on those, the reference's
+        # C / L / T scaled up to the batch (they are the same for every ray: the whole tree), the CPU baseline timed on them
+        samp = None
+        if kind == "kdtree" and mesh.P > 5000 and n > 65536 and B == 1:
+            samp = np.arange(0, n, n // 65536)
+        rays_o = rays_h if samp is None else np.ascontiguousarray(rays_h[samp])
+        if world == 1 and not os.environ.get("HARE_CPU_THREADS") and cores > 32 and samp is None:
             ns = min(n, 262144)
             trial = {}
             for nt in sorted({cores, max(32, cores // 2), max(32, cores // 4), 32}, reverse=True):
@@ -537,67 +557,109 @@ def measure(w, env):
         ref = ctr = links = None
         while reps < max_reps and (reps < 1 or time.time() < budget):
             c0 = time.perf_counter()
-            ref, ctr, links = oracle_pass(rays_h, cores)
+            ref, ctr, links = oracle_pass(rays_o, cores)
             dt = time.perf_counter() - c0
             best = dt if best is None else min(best, dt)
             reps += 1
+        cpu_casts = ctr["rays"]
+        if samp is not None:
+            ctr = {k: v * n // len(samp) for k, v in ctr.items()}
         casts = ctr["rays"]
         unit = "Mrays/s" if B == 1 else "Mcasts/s"
         if world == 1:
-            n1 = min(n, (100000 if kind == "voxel" else 20000) // B)
+            n1 = min(n, (100000 if kind == "voxel" else (20000 if samp is None else 256)) // B)
             c0 = time.perf_counter()
             _, c1ctr, _ = oracle_pass(rays_h[:n1], 1)
             dt1 = time.perf_counter() - c0
-            cpu = {"value": round(casts / best / 1e6, 3), "unit": unit, "cores": cores, "kind": "port",
+            cpu = {"value": round(cpu_casts / best / 1e6, 3), "unit": unit, "cores": cores, "kind": "port",
                    # the box: cores this process may run on / logical CPUs of the host; `cores` = threads the timed passes used
                    "affinity_cores": affinity, "host_cores": os.cpu_count(),
                    "value_1thread": round(c1ctr["rays"] / dt1 / 1e6, 3),
-                   "sample": f"{n} rays of this workload" + (f" x {B} casts ({casts} live casts)" if B > 1 else "")
-                             + f", best of {reps} passes on {cores} threads; 1 thread: {c1ctr['rays'] / dt1 / 1e6:.3f} {unit} on {n1} rays. "
-                             f"C restatement of Hare {ref_name} (oracle/, per-thread mailbox, no per-candidate allocation): an upper "
-                             f"bound on the C# reference, which cannot be run here"}
+                   "sample": (f"{n} rays of this workload" if samp is None else f"every {n // len(samp)}th ray of this workload ({len(samp)} rays)")
+                             + (f" x {B} casts ({casts} live)" if B > 1 else "")
+                             + f", best of {reps} passes, {cores} threads; 1 thread on {n1} rays. C restatement of Hare {ref_name} "
+                             f"(oracle/): an upper bound on the C# reference, which cannot be run here"}
+        # parity check of the bench buffers themselves (not timed): every ray of this rank's shard, all eight fields, bit for bit --
+        # BEFORE anything else is cast into them
+        got = device_events(n)
+        if samp is not None:
+            got = got[samp]
+        parity = bool(all(np.array_equal(got[f], ref[f]) for f in fields))
+        del got
         bytes_pass = algorithmic_bytes(ctr, kind, links)
-        achieved = bytes_pass / (sum(per_cast_ms) * 1e-3) / 1e9
+        pass_s = kern_ms * B * 1e-3                     # one pass of the hot path: B casts
+        achieved = bytes_pass / pass_s / 1e9
         wkey = f"{scene}-{kind}-" + (f"D{domain}-" if kind == "voxel" else "") + f"n{n}" + (f"-b{B}" if B > 1 else "")
         prof = load_traffic(wkey)
         traffic = None if prof is None else prof.get("hbm_bytes_per_launch")
+        # ---- roofline.own: the bytes THIS kernel's algorithm has to touch, counted by the counting build of the production kernel
+        # itself (HARE_SHOOT_COUNT_OWN: the same launch geometry, the same events) on the same rays, once, after the timed region:
+        #   104 B per cast (ray in, X_Event out) + 8 B per voxel walked into (64 B per tree node record fetched) + 4 B per list entry
+        #   scanned + 32 B per candidate put through the FP32 pre-cull (its cull record) + 128 B per exact test (the polygon record)
+        #   + 28 B per bounce.  The tight boxes, the pre-cull and the skipped empty leaves are IN this figure (the reference-priced
+        #   `frac` charges 96 B for every intersect call of the reference, most of which the kernels never make), so it cannot pass 1
+        #   unless the kernel moves fewer bytes than its own algorithm needs.
+        own = None
+        try:
+            octr = torch.zeros(8, dtype=torch.int64, device="cuda")
+            if B > 1:
+                d_rays.copy_(d_rays0)
+                part.bounce_device(n, d_rays.data_ptr(), B, d_excl.data_ptr(), d_events_last=d_out.data_ptr(), d_counters=octr.data_ptr(), stream=sp,
+                                   flags=H.capi.SHOOT_COUNT_OWN)
+            else:
+                part.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=octr.data_ptr(), stream=sp, flags=H.capi.SHOOT_COUNT_OWN)
+            torch.cuda.synchronize()
+            oc = [int(x) for x in octr.cpu()]
+            got_own = np.frombuffer(d_out[:n * 56].cpu().numpy().tobytes(), dtype=H.capi.XEVENT_DTYPE)
+            if samp is not None:
+                got_own = got_own[samp]
+            own_parity = bool(all(np.array_equal(got_own[f], ref[f]) for f in fields))     # the counting build returns the same events
+            del got_own
+            if oc[0] == casts and own_parity:
+                cw = 8 if kind == "voxel" else 64
+                own_bytes = 104 * oc[0] + cw * oc[2] + 4 * oc[3] + 32 * oc[5] + 128 * oc[4] + 28 * links
+                own = {"frac": round(own_bytes / pass_s / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(own_bytes / pass_s / 1e9, 1),
+                       "bytes_per_launch": own_bytes // B, "bytes_per_cast": round(own_bytes / max(casts, 1), 1),
+                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), "L": round(oc[3] / max(casts, 1), 2),
+                                    "K": round(oc[5] / max(casts, 1), 2), "T": round(oc[4] / max(casts, 1), 2)},
+                       "formula": f"104 + {cw} C' + 4 L' + 32 K' + 128 T' (+28 per bounce); counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}
+        except Exception as e:       # a batch whose kernel has no counting build (HARE_E_UNSUPPORTED): the line says so
+            own = {"frac": None, "why": str(e)[:120]}
+        # ---- roofline.issue: the bound the counters name (VALU issue), as a fraction: PMC wave-instruction counts by class x the measured
+        # cost of a class on a SIMD (VALU_NS), over the SIMDs' time in the kernel.  A LOWER bound on how busy the vector issue is: FP64
+        # compares, selects and conversions are priced as "other", and an instruction with idle lanes costs what a full one does.
         issue = None
         if prof is not None and prof.get("SQ_INSTS_VALU"):
-            # issue side, as a number: wave-level VALU instructions x 4 cycles (one wave64 FP32/integer instruction on a SIMD-32;
-            # FP64 ones take 8) over every SIMD's cycles in the kernel's duration -- a LOWER bound on how busy the vector issue is
-            issue = {"valu_insts_per_launch": int(prof["SQ_INSTS_VALU"]),
-                     "valu_issue_frac": round(prof["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * GPU_CLOCK_HZ * kern_ms * 1e-3), 4),
-                     "sq_active_inst_any_frac": prof.get("sq_active_inst_any_frac"), "sq_wait_any_frac": prof.get("sq_wait_any_frac"),
-                     "ta_busy_frac": prof.get("ta_busy_frac"), "l1_accesses_per_ray": prof.get("l1_accesses_per_ray"),
-                     # lanes that execute per vector instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64): measured lane occupancy
-                     "valu_lane_util": prof.get("valu_lane_util"),
-                     "vmem_rd_insts": prof.get("vmem_rd_insts"), "vmem_wr_insts": prof.get("vmem_wr_insts"),
-                     "tcc_read_req": prof.get("tcc_read_req"), "tcc_write_req": prof.get("tcc_write_req"),
-                     "source": "profiles/traffic.json (rocprofv3 PMC passes on this kernel source)"}
+            valu = float(prof["SQ_INSTS_VALU"])
+            f64 = {k: float(prof.get(k2) or 0) for k, k2 in (("add_f64", "SQ_INSTS_VALU_ADD_F64"), ("mul_f64", "SQ_INSTS_VALU_MUL_F64"),
+                                                            ("fma_f64", "SQ_INSTS_VALU_FMA_F64"), ("trans_f64", "SQ_INSTS_VALU_TRANS_F64"))}
+            have_f64 = prof.get("SQ_INSTS_VALU_FMA_F64") is not None
+            ns = sum(f64[k] * VALU_NS[k] for k in f64) + max(0.0, valu - sum(f64.values())) * VALU_NS["other"]
+            issue = {"frac": round(ns / N_SIMDS / (kern_ms * 1e6), 4), "valu_insts": int(valu),
+                     "f64_insts": int(sum(f64.values())) if have_f64 else None, "lane_util": prof.get("valu_lane_util"),
+                     "wait_frac": prof.get("sq_wait_any_frac"), "ta_busy": prof.get("ta_busy_frac"),
+                     "l1_per_ray": prof.get("l1_accesses_per_ray")}
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": kernel_name, "kernel_ms": round(kern_ms, 4), "kernel_ms_event_pair_per_launch": round(kern_ms_pairs, 4),
+                    "kernel": kernel_name, "kernel_ms": round(kern_ms, 4), "kernel_ms_source": kern_src,
+                    "kernel_ms_event_pair_per_launch": round(kern_ms_pairs, 4),
                     "algorithmic_bytes_per_launch": bytes_pass // B,
                     "bytes_per_cast": round(bytes_pass / max(casts, 1), 1),
-                    "per_cast": {"C_cells": round(ctr["cells"] / max(casts, 1), 2), "L_entries": round(ctr["entries"] / max(casts, 1), 2),
-                                 "T_tests": round(ctr["tests"] / max(casts, 1), 2)},
-                    # what the counters say actually bounds the kernel: the scene is cache-resident, HBM is a few % busy
-                    "measured_bound": "valu issue + dependent-load latency (not HBM)",
-                    # `achieved` prices the REFERENCE algorithm's cells / list entries / tests per ray (counted by the
-                    # oracle).  The kernels skip lists and subtrees whose polygons the ray provably cannot hit (the tight boxes,
-                    # DESIGN.md 5), so they touch fewer bytes than that and `frac` can pass 1.0 on the trees: it is a rate in units of
-                    # the reference's work, not bytes moved -- those are `traffic`.
-                    "numerator": "the reference algorithm's bytes per ray (oracle counters); tight boxes skip part of that work",
-                    "issue_side": issue,
+                    "per_cast": {"C": round(ctr["cells"] / max(casts, 1), 2), "L": round(ctr["entries"] / max(casts, 1), 2),
+                                 "T": round(ctr["tests"] / max(casts, 1), 2)},
+                    # `frac` prices the REFERENCE algorithm's cells / list entries / tests per ray (counted by the oracle):
+                    # a rate in units of the reference's work.  `own.frac` prices what the kernel itself touches; `issue.frac` is the
+                    # fraction of the bound the counters name.
+                    "own": own, "issue": issue, "measured_bound": "valu issue + dependent-load latency (not HBM)",
                     "hbm_busy_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1)}
+        if roofline["frac"] > 1.0:
+            roofline["warning"] = ("frac > 1: the numerator is the reference algorithm's bytes (SURVEY 8(d)); the kernel skips part of that "
+                                   "work (tight boxes, pre-cull) -- not a fraction of a hardware bound; read own.frac / issue.frac")
         if B > 1:
             roofline["bounce_loop_ms"] = round(loop_ms, 4)
             roofline["bounce_loop"] = "hare_bounce_device: " + (part.bounce_kernel_name(n, B) or "a launch per cast")
             roofline["live_casts_per_pass"] = casts
-        # parity check of the bench buffers themselves (not timed): every ray of this rank's shard, all eight fields, bit for bit
-        got = device_events(n)
-        parity = bool(all(np.array_equal(got[f], ref[f]) for f in fields))
         if bounce_batch is not None:
             bb_ev = bounce_batch.pop("events")
             bounce_batch["parity_vs_oracle"] = bool(all(np.array_equal(bb_ev[f], ref[f]) for f in fields)) and bounce_batch["casts"] == casts
@@ -663,6 +725,7 @@ PARITY_SAMPLE_RAYS = 65536      # what ranks 1..N-1 pass through the oracle (ran
 #               and the CPU baseline -- the per-GPU kernels' figures, comparable round to round.
 EXTRA_CONFIGS = (
     ("c3", {"scene": "hall", "kind": "octree", "domain": 64, "rays": 1 << 20, "bounces": 1, "steps": 5, "warmup": 1, "only_n1": True}),
+    ("c2_quads", {"scene": "hall_quads", "kind": "voxel", "domain": 64, "rays": 1 << 20, "bounces": 1, "steps": 8, "warmup": 2, "only_n1": True}),
     ("c4_shard", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 21, "bounces": 1, "steps": 8, "warmup": 2,
                   "only_n1": True}),
     ("c5_shard", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays": 1 << 20, "bounces": 8, "steps": 3, "warmup": 1,
@@ -670,9 +733,55 @@ EXTRA_CONFIGS = (
     ("c4", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays_total": 1 << 24, "bounces": 1, "steps": 5, "warmup": 1}),
     ("c5", {"scene": "cathedral", "kind": "voxel", "domain": 128, "rays_total": 1 << 23, "bounces": 8, "steps": 2, "warmup": 1}),
 )
-EXTRA_KEYS = ("value", "unit", "n_gpus", "scaling", "steps", "warmup", "ms_per_step", "ms_per_step_per_rank", "dtype", "config",
-              "kernel_only_mrays_s", "hits", "rays", "build_s", "x_event_parity_vs_oracle", "parity_per_rank", "parity_sample",
-              "ranks_seen_in_reduce", "roofline", "cpu_baseline", "bounce_batch")
+LINE_BUDGET = 7400      # the driver keeps the last 8 KB of stdout: the ONE line, with every config in it, must fit (round 4's was 12.5 KB
+                        # and lost "c3" to the cut)
+
+
+def compact_sub(sub: dict) -> dict:
+    """An appended config as it goes into the line: the numbers, the kernel, the three fractions, parity -- no prose (the headline
+    entry carries the explanations once)."""
+    rf = sub.get("roofline") or {}
+    own, issue, cpu = rf.get("own") or {}, rf.get("issue") or {}, sub.get("cpu_baseline")
+    out = {k: sub[k] for k in ("value", "unit", "n_gpus", "scaling", "steps", "warmup", "ms_per_step", "kernel_only_mrays_s", "hits", "rays",
+                               "x_event_parity_vs_oracle", "parity_per_rank", "ranks_seen_in_reduce") if k in sub}
+    out["config"] = {k: sub["config"][k] for k in ("workload", "rays_per_gpu", "rays_total", "backend")}
+    r = {k: rf.get(k) for k in ("frac", "achieved", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "bytes_per_cast", "per_cast")}
+    if rf.get("warning"):
+        r["warning"] = "frac > 1: reference-priced numerator, not a hardware fraction; see own / issue"
+    r["own"] = {k: own.get(k) for k in ("frac", "bytes_per_cast", "per_cast", "why") if own.get(k) is not None} if own else None
+    r["issue"] = {k: issue.get(k) for k in ("frac", "lane_util")} if issue else None
+    for k in ("live_casts_per_pass", "bounce_loop_ms"):
+        if k in rf:
+            r[k] = rf[k]
+    out["roofline"] = r
+    out["cpu_baseline"] = None if not cpu else {k: cpu[k] for k in ("value", "unit", "cores", "kind", "host_cores", "value_1thread") if k in cpu}
+    if "bounce_batch" in sub:
+        out["bounce_batch"] = sub["bounce_batch"]
+    return out
+
+
+def fit_line(line: dict) -> str:
+    """The one JSON line, within LINE_BUDGET: what is dropped first is prose, never a number."""
+    dumps = lambda o: json.dumps(o, separators=(",", ":"))
+    txt = dumps(line)
+    drops = [("roofline", "own", "formula"), ("cpu_baseline", "sample"), ("roofline", "kernel_ms_source"), ("roofline", "warning"),
+             ("parity_sample",), ("config", "sharding"), ("config", "partition")]
+    for path in drops:
+        if len(txt) <= LINE_BUDGET:
+            break
+        d = line
+        for k in path[:-1]:
+            d = d.get(k) or {}
+        if isinstance(d, dict):
+            d.pop(path[-1], None)
+        txt = dumps(line)
+    for name in list((line.get("configs") or {}).keys()):
+        if len(txt) <= LINE_BUDGET:
+            break
+        line["configs"][name]["config"].pop("workload", None)
+        line["configs"][name]["roofline"].pop("warning", None)
+        txt = dumps(line)
+    return txt
 
 
 def main() -> None:
@@ -748,13 +857,13 @@ def main() -> None:
             t0 = time.time()
             sub = measure(w, env)
             if rank == 0:
-                sub = {k: sub[k] for k in EXTRA_KEYS if k in sub}
+                sub = compact_sub(sub)
                 sub["wall_s"] = round(time.time() - t0, 1)
                 configs[name] = sub
         if rank == 0:
             line["configs"] = configs
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        print(fit_line(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -152,6 +152,7 @@ public:
         return c.hits;
     }
     void SetOption(const char* name, int64_t value) { check(hare_scene_set_option(scene_, name, value)); }
+    int64_t GetOption(const char* name) const { int64_t v = 0; check(hare_scene_get_option(scene_, name, &v)); return v; }
     hare_scene* native() const { return scene_; }
 
 protected:

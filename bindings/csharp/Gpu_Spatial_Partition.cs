@@ -266,6 +266,14 @@ namespace Hare
                 foreach (IntPtr s in scenes) HareHip.Check(HareHip.hare_scene_set_option(s, name, value));
             }
 
+            /// <summary>An option of replica 0 read back, or "voxel_tight_bytes" / "octree_scratch_bytes" (hare_scene_get_option).</summary>
+            public long GetOption(string name)
+            {
+                long v;
+                HareHip.Check(HareHip.hare_scene_get_option(scene, name, out v));
+                return v;
+            }
+
             void Release()
             {
                 for (int k = 0; k < scenes.Length; k++)

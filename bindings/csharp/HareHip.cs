@@ -96,6 +96,7 @@ namespace Hare
             public const int HARE_KIND_VOXEL = 0, HARE_KIND_OCTREE = 1, HARE_KIND_KDTREE = 2;
             public const uint HARE_SHOOT_WRITEBACK_ORIGIN = 1;
             public const uint HARE_SHOOT_RETIRED_RAYS = 8;   // device-resident bounce loop only (hare_shoot_device)
+            public const uint HARE_SHOOT_COUNT_OWN = 64;     // measurement: the production kernel's counting build (its own cells / entries / pre-culls / tests)
             public const uint HARE_SHOOT_BOUNCE_LOOP = 32;   // hare_shoot_kernel_name only
             public const uint HARE_SHOOT_SLIM_EVENTS = 16;   // host-buffer batches: hare_slim_event records come back (16 B per ray, not 56)
 
@@ -141,6 +142,9 @@ namespace Hare
             /// <summary>Diagnostics / A-B switch of one scene ("voxel_kernel", "octree_kernel", "build_host", ...: include/hare_hip.h).</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl, CharSet = CharSet.Ansi)]
             public static extern int hare_scene_set_option(IntPtr scene, string name, long value);
+            /// <summary>An option read back, or "voxel_tight_bytes" / "octree_scratch_bytes": device memory of the accelerators (include/hare_hip.h).</summary>
+            [DllImport(Lib, CallingConvention = CallingConvention.Cdecl, CharSet = CharSet.Ansi)]
+            public static extern int hare_scene_get_option(IntPtr scene, string name, out long value);
             /// <summary>Spatial_Partition.Shoot for ONE ray on the calling thread (host trace, no GPU round trip, lock-free):
             /// what the single-ray overrides call.  ray is updated like the reference moves R (AABB_Main.cs:254-257).</summary>
             [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)]

@@ -17,6 +17,7 @@ HARE_OK = 0
 HARE_E_INVALID, HARE_E_NOMEM, HARE_E_HIP, HARE_E_NODEVICE, HARE_E_STATE, HARE_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 KIND_VOXEL, KIND_OCTREE, KIND_KDTREE = 0, 1, 2
 SHOOT_WRITEBACK_ORIGIN, SHOOT_COUNT_WORK, SHOOT_SIMPLE_KERNEL, SHOOT_RETIRED_RAYS, SHOOT_SLIM_EVENTS, SHOOT_BOUNCE_LOOP = 1, 2, 4, 8, 16, 32
+SHOOT_COUNT_OWN = 64
 
 RAY_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("dx", "<f8"), ("dy", "<f8"), ("dz", "<f8")])
 XEVENT_DTYPE = np.dtype(
@@ -39,7 +40,9 @@ class Counters(C.Structure):
                 ("tests", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k in ("rays", "hits", "cells", "entries", "tests")}
+        d = {k: int(getattr(self, k)) for k in ("rays", "hits", "cells", "entries", "tests")}
+        d["culls"] = int(self.reserved[0])       # HARE_SHOOT_COUNT_OWN: candidates pre-culled
+        return d
 
 
 class TopologyDesc(C.Structure):
@@ -71,6 +74,7 @@ SYMBOLS = {
     "hare_scene_create": (C.c_int, [_vp, _i32, _i32, _vp]),
     "hare_scene_destroy": (None, [_vp]),
     "hare_scene_set_option": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "hare_scene_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "hare_voxel_build": (C.c_int, [_vp, _i32]),
     "hare_voxel_build_adaptive": (C.c_int, [_vp, _i32, _i32]),
     "hare_octree_build": (C.c_int, [_vp, _i32, _i32]),

@@ -84,6 +84,11 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_pool_quad", &m->voxel_pool_quad},
         {"hare_voxel_pool_tri_g", &m->voxel_pool_tri_g},
         {"hare_voxel_pool_quad_g", &m->voxel_pool_quad_g},
+        {"hare_voxel_pool_tri_own", &m->voxel_pool_tri_own},
+        {"hare_voxel_pool_quad_own", &m->voxel_pool_quad_own},
+        {"hare_voxel_pool_tri_g_own", &m->voxel_pool_tri_g_own},
+        {"hare_voxel_pool_quad_g_own", &m->voxel_pool_quad_g_own},
+        {"hare_octree_dense_own", &m->octree_dense_own},
         {"hare_voxel_bounce_tri", &m->voxel_bounce_tri},
         {"hare_voxel_bounce_quad", &m->voxel_bounce_quad},
         {"hare_voxel_bounce_tri_g", &m->voxel_bounce_tri_g},
@@ -364,13 +369,25 @@ int launch(const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsi
 }
 
 // The voxels' tight boxes (hare_cell_boxes, build_kernels.hip), per topology, from the grid as it stands on the device -- behind either
-// builder.  Margin 2^-20 of the scene's extent; good for ray origins within 1 024 extents of the scene (the kernel's guard).  A grid
-// without them (no kernel in the code object, a degenerate extent) is simply traced as before.
+// builder.  Margin 2^-20 of the scene's extent; good for ray origins within 1 024 extents of the scene (the kernel's guard).
+// They are an ACCELERATION, never a precondition, and cost 32 B per voxel and topology (twice the CellRec array: 4.3 GB at D = 512),
+// so they exist only where they are used:
+//   * the option voxel_tight is on (hare_scene_set_option("voxel_tight", 1) on a grid built without them builds them then);
+//   * the pool kernel K1q, the only kernel that reads them, can serve the grid (pool_can_serve: ct <= 512, bitmap + pools fit LDS);
+//   * they fit the budget `voxel_tight_max_mb` (0 = no budget) -- and an allocation that fails is "no boxes", not a failed build:
+//     what was allocated is freed, cellbox_rad stays -1, the grid is traced exactly as before (every list scanned).
+// Returns an error only for a kernel launch / synchronisation failure (the device is then in trouble whatever we do).
+bool pool_can_serve(const Scene& s)
+{
+    const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
+    return lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= 160u * 1024u && s.vox.ct <= 512;
+}
 int upload_cell_boxes(Scene& s, const HipApi* H)
 {
     for (void*& p : s.d_cellbox) dev_free(H, p);
     s.d_cellbox.assign(s.topos.size(), nullptr);
     s.cellbox_rad = -1;
+    if (!s.opt.voxel_tight || !pool_can_serve(s)) return HARE_OK;
     if (!s.module || !s.module->cell_boxes || !s.vox.built || s.d_cells.size() != s.topos.size() || s.d_polys.size() != s.topos.size()) return HARE_OK;
     double ext = 0, mag = 0;
     for (int a = 0; a < 3; ++a) {
@@ -386,9 +403,23 @@ int upload_cell_boxes(Scene& s, const HipApi* H)
     // 2^-20 of the extent, or of the largest coordinate for a scene far from the origin of its coordinates (as for the trees' boxes)
     const double delta = std::ldexp(std::max(ext, mag), -20);
     const long long ncell = (long long)s.vox.ct * s.vox.ct * s.vox.ct;
+    const size_t bytes = (size_t)ncell * 8 * sizeof(float);
+    size_t live = 0;
+    for (size_t m = 0; m < s.topos.size(); ++m)
+        if (s.d_cells[m] && s.d_items[m] && s.d_polys[m]) ++live;
+    auto give_up = [&]() {
+        for (void*& p : s.d_cellbox) dev_free(H, p);
+        s.cellbox_rad = -1;
+        return HARE_OK;
+    };
+    if (s.opt.voxel_tight_max_mb > 0 && (double)bytes * (double)live > (double)s.opt.voxel_tight_max_mb * 1048576.0) return give_up();
     for (size_t m = 0; m < s.topos.size(); ++m) {
         if (!s.d_cells[m] || !s.d_items[m] || !s.d_polys[m]) continue;
-        HIP_TRY(H->Malloc(&s.d_cellbox[m], (size_t)ncell * 8 * sizeof(float)));
+        if (s.opt.dev_fail_cellbox_alloc || H->Malloc(&s.d_cellbox[m], bytes) != hipSuccess) {     // out of memory (or the test hook): no boxes
+            s.d_cellbox[m] = nullptr;
+            (void)H->GetLastError();
+            return give_up();
+        }
         const void* cells = s.d_cells[m];
         const void* items = s.d_items[m];
         const void* polys = s.d_polys[m];
@@ -397,9 +428,9 @@ int upload_cell_boxes(Scene& s, const HipApi* H)
         double dl = delta;
         void* out = s.d_cellbox[m];
         void* args[] = {&cells, &items, &polys, &quads, &nc, &dl, &out};
-        if (int rc = launch(H, s.module->cell_boxes, (unsigned)((ncell + 255) / 256), 256, 0, nullptr, args)) return rc;
+        if (int rc = launch(H, s.module->cell_boxes, (unsigned)((ncell + 255) / 256), 256, 0, nullptr, args)) { give_up(); return rc; }
     }
-    HIP_TRY(H->StreamSynchronize(nullptr));
+    if (hipError_t e = H->StreamSynchronize(nullptr); e != hipSuccess) { give_up(); return hip_fail(H, e, "hipStreamSynchronize"); }
     for (int a = 0; a < 3; ++a) s.cellbox_mid[a] = 0.5 * (s.vox.omin[a] + s.vox.omax[a]);
     s.cellbox_rad = 1024.0 * ext;
     return HARE_OK;
@@ -453,7 +484,8 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
         const size_t need = rec_bytes + spill_bytes;
         tail_lk.lock();                      // held until the launch (and the tail behind it) is enqueued and the block's event recorded
         if (need > s.oct_tail_block_bytes) {
-            // larger blocks (first use, or a deeper tree since): launches in flight may still use the old ones
+            // larger blocks: only when reserve_oct_scratch could not allocate at build time (it sizes the ring for the largest launch
+            // this tree can get); launches in flight may still use the old ones
             if (s.d_oct_tail) {
                 HIP_TRY(H->DeviceSynchronize());
                 dev_free(H, s.d_oct_tail);
@@ -516,8 +548,11 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
 // counters block into a buffer the developer tools size for it, or leave `out` unwritten) only pass on a scene whose
 // `dev` option is set (HARE_DEV=1 when the scene was created, or hare_scene_set_option), so a stray bit from a caller can
 // never reach a kernel.
+// HARE_SHOOT_BOUNCE_LOOP is NOT among them: it is a question to hare_shoot_kernel_name (which reads it from the raw flags), never a mode
+// of a cast, and must not travel into ShootIO::flags where a device-side bit 32 would one day collide with it (ADVICE, round 4).
 constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS | HARE_SHOOT_SLIM_EVENTS |
-                                 HARE_SHOOT_BOUNCE_LOOP;
+                                 HARE_SHOOT_COUNT_OWN;
+static_assert((kPublicFlags & HARE_SHOOT_BOUNCE_LOOP) == 0, "the kernel-name query bit never reaches a kernel");
 uint32_t sanitize_flags(const Scene& s, uint32_t flags)
 {
     return flags & (kPublicFlags | (s.opt.dev ? 0xF000u : 0u));
@@ -536,6 +571,8 @@ void read_env_options(SceneOptions& o)
     if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
     if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_TIGHT")) o.voxel_tight = atoi(t) != 0;
+    if (const char* t = getenv("HARE_VOXEL_TIGHT_MAX_MB")) o.voxel_tight_max_mb = std::max(0, atoi(t));
+    if (const char* t = getenv("HARE_FAIL_CELLBOX_ALLOC")) o.dev_fail_cellbox_alloc = atoi(t) != 0;
     if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
     if (const char* t = getenv("HARE_K2P_TAIL_MAX")) o.k2p_tail_max = atoi(t);
     if (const char* t = getenv("HARE_K2P_TAIL_PATIENCE")) o.k2p_tail_patience = atoi(t);
@@ -614,6 +651,9 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
 {
     KernChoice c;
     const bool count = (flags & HARE_SHOOT_COUNT_WORK) != 0, simple = (flags & HARE_SHOOT_SIMPLE_KERNEL) != 0;
+    // HARE_SHOOT_COUNT_OWN: the production kernel's counting build (K1q, K2d, the kd-tree kernel); a batch another kernel would serve
+    // has none -> no kernel (the caller reports HARE_E_UNSUPPORTED)
+    const bool own = (flags & HARE_SHOOT_COUNT_OWN) != 0 && !count && !simple && !flags_only;
     const bool quads = s.topos[top].has_quads;
     const bool huge = n >= 0x7FFFFF00ll;                  // the persistent kernels index rays with 32 bits
     const int cus = (M && M->cu_count > 0) ? M->cu_count : 256;
@@ -664,8 +704,15 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         if (pool_wanted && pool_fits && have(pf)) {
             pick(Kern::VoxelPool, !coarse ? (quads ? "hare_voxel_pool_quad" : "hare_voxel_pool_tri")
                                           : (quads ? "hare_voxel_pool_quad_g" : "hare_voxel_pool_tri_g"), pf);
+            if (own) {         // HARE_SHOOT_COUNT_OWN: the counting build of the SAME kernel, same launch geometry
+                hipFunction_t DeviceModule::*of = !coarse ? (quads ? &DeviceModule::voxel_pool_quad_own : &DeviceModule::voxel_pool_tri_own)
+                                                           : (quads ? &DeviceModule::voxel_pool_quad_g_own : &DeviceModule::voxel_pool_tri_g_own);
+                pick(Kern::VoxelPool, !coarse ? (quads ? "hare_voxel_pool_quad_own" : "hare_voxel_pool_tri_own")
+                                              : (quads ? "hare_voxel_pool_quad_g_own" : "hare_voxel_pool_tri_g_own"), of);
+            }
             return c;
         }
+        if (own) { c = KernChoice(); return c; }          // no counting build of K1p
         if ((flags & 0x4000u) && have(&DeviceModule::voxel_persist_prof) && (!M || M->voxel_persist_prof) && !coarse && !quads) {
             pick(Kern::VoxelProf, "hare_voxel_persist_prof", &DeviceModule::voxel_persist_prof);
             return c;
@@ -703,13 +750,19 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             //  the crossover is a ray for every lane of K2d's grid, 768 per CU)
             const int64_t group_below = (int64_t)cus * 768;           // 196 608 rays on the 256-CU part
             const bool group_wanted = s.opt.octree_kernel == 3 || (s.opt.octree_kernel == 0 && (n < group_below || !fits_p));
-            if (group_wanted && group_ok) { pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group); return c; }
+            if (group_wanted && group_ok) {
+                if (own) { c = KernChoice(); return c; }          // no counting build of K2g: the caller is told so
+                pick(Kern::OctGroup, "hare_octree_group", &DeviceModule::octree_group);
+                return c;
+            }
             // K2d (K2p's DENSE build) wherever it exists and its LDS fits; K2p (octree_kernel = 1) is the A/B baseline and the fall-back
             if ((s.opt.octree_kernel == 4 || s.opt.octree_kernel == 0) && (unsigned)levels * 256u * 20u + kOctDenseExtra <= kLdsMax &&
                 have(&DeviceModule::octree_dense)) {
                 pick(Kern::OctDense, "hare_octree_dense", &DeviceModule::octree_dense);
+                if (own) pick(Kern::OctDense, "hare_octree_dense_own", &DeviceModule::octree_dense_own);
                 return c;
             }
+            if (own) { c = KernChoice(); return c; }
             if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_persist)) {
                 pick(Kern::OctPersist, "hare_octree_persist", &DeviceModule::octree_persist);
                 return c;
@@ -720,6 +773,7 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
     }
     if (kind == HARE_KIND_KDTREE) {
         if (count) pick(Kern::KdCount, "hare_kdtree_shoot_count", &DeviceModule::kdtree_count);
+        else if (own) return c;                      // (no counting build of the one-ray-per-lane kd kernel)
         else pick(Kern::KdSimple, "hare_kdtree_shoot", &DeviceModule::kdtree);
     }
     return c;
@@ -741,6 +795,43 @@ int32_t octree_levels(const OctreeHost& o)
         for (int c = 0; c < 8; ++c) st.emplace_back(nd.first_child + c, d + 1);
     }
     return std::max(best, 1);
+}
+
+// The octree kernels' scratch ring (launch_on_slot: hand-over records K2p / K2d -> tail kernel, stack spill of K2g / K2g-tail), sized ONCE,
+// when the tree goes to the device, for the largest launch this tree can get on this device: a full K2g grid, or a full K2p / K2d grid
+// whose every wave hands over 64 rays to a full K2g-tail grid.  A shoot then never allocates -- round 4 grew the ring inside the launch
+// path under hipDeviceSynchronize, a device-wide stall in a call documented as stream-ordered (ADVICE).  Cost, kOctTailRing = 8 blocks:
+// about 0.7 GB for an 8-level tree on the 256-CU part, about 1.2 GB at 24 levels (hare_scene_get_option "octree_scratch_bytes";
+// INTEGRATION.md).  A failed allocation here is not an error: the launch path still grows the ring on demand, as before.
+void reserve_oct_scratch(Scene& s, const HipApi* H)
+{
+    if (!s.module || !H) return;
+    const size_t cus = (size_t)std::max(1, s.module->cu_count);
+    const size_t levels = (size_t)std::max(1, s.oct_levels);
+    const size_t spill_entries = (size_t)std::max(0, 7 * (int)levels + 8 - kGroupStack);
+    const size_t glds = 4u * (size_t)kGroupWaveBytes;
+    const size_t g_per_cu = std::min<size_t>((size_t)HARE_K2G_WAVES_PER_EU, std::max<size_t>(1, kLdsMax / glds));
+    const size_t need_group = cus * g_per_cu * 4u * 8u * spill_entries * 24u;
+    const size_t plds = levels * 256u * 20u;
+    const size_t p_per_cu = std::min<size_t>((size_t)HARE_K2P_WAVES_PER_EU, std::max<size_t>(1, kLdsMax / plds));
+    const size_t stride = ((size_t)kOctTailHead + 20u * levels + 15u) & ~(size_t)15u;
+    const size_t rec_bytes = (cus * p_per_cu * 4u * 64u * stride + 255u) & ~(size_t)255u;
+    const size_t tail_spill = cus * (size_t)HARE_K2G_WAVES_PER_EU * 4u * 8u * spill_entries * 24u;
+    const size_t need = std::max(need_group, rec_bytes + tail_spill);
+    std::lock_guard<std::mutex> lk(s.oct_tail_mu);
+    if (need <= s.oct_tail_block_bytes) return;
+    if (s.d_oct_tail) {
+        if (H->DeviceSynchronize() != hipSuccess) { (void)H->GetLastError(); return; }     // a build call: nothing of this scene is in flight by contract
+        dev_free(H, s.d_oct_tail);
+    }
+    s.oct_tail_block_bytes = 0;
+    if (H->Malloc(&s.d_oct_tail, (size_t)Scene::kOctTailRing * need) != hipSuccess) {
+        (void)H->GetLastError();
+        s.d_oct_tail = nullptr;
+        return;
+    }
+    s.oct_tail_block_bytes = need;
+    for (bool& u : s.oct_tail_used) u = false;
 }
 
 // [a, a + na) and [b, b + nb) share a byte
@@ -802,7 +893,7 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
         set_error("hare_bounce: batch too large");
         return HARE_E_INVALID;
     }
-    flags = sanitize_flags(s, flags) & (HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL);
+    flags = sanitize_flags(s, flags) & (HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_COUNT_OWN);
     const DeviceModule& M = *s.module;
     hare_xevent* const all = (hare_xevent*)d_all;
     hare_xevent* const last = d_last ? (hare_xevent*)d_last : all + (size_t)(casts - 1) * (size_t)n;
@@ -961,6 +1052,11 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     }
     const bool quads = s.topos[top].has_quads;
     const DeviceModule& M = *s.module;
+    auto no_own_build = [&]() {
+        set_error("hare_shoot: HARE_SHOOT_COUNT_OWN -- the kernel this batch gets has no counting build (the pool kernel of Voxel_Grid, "
+                  "hare_octree_dense from 768 rays per CU, the kd-tree kernel have one)");
+        return HARE_E_UNSUPPORTED;
+    };
     const unsigned block = 256;
     const unsigned grid = (unsigned)((n + block - 1) / block);
     const unsigned cus = (unsigned)std::max(1, M.cu_count);
@@ -973,6 +1069,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         VoxelArgs g;
         fill_voxel_args(s, top, g);
         const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
+        if (!kc.f && (flags & HARE_SHOOT_COUNT_OWN)) return no_own_build();
         if (!kc.f || (kc.k == Kern::VoxelAudit && quads)) {
             set_error(kc.k == Kern::VoxelAudit ? "hare_shoot: cull audit needs an all-triangle topology and the audit kernel"
                                                : "hare_shoot: kernel missing from code object");
@@ -1052,6 +1149,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             return HARE_E_UNSUPPORTED;
         }
         const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
+        if (!kc.f && (flags & HARE_SHOOT_COUNT_OWN)) return no_own_build();
         if (!kc.f) {
             set_error("hare_shoot: octree kernel missing from code object");
             return HARE_E_STATE;
@@ -1129,14 +1227,14 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
             // 20 bytes x levels x 256 lanes per workgroup (interval + child word); the dense build: + its pending survivors and tables
-            const unsigned plds = (unsigned)g.max_depth * 256u * 20u + (f == M.octree_dense && f != nullptr ? kOctDenseExtra : 0u);
+            const bool dense_k = f != nullptr && (f == M.octree_dense || f == M.octree_dense_own);
+            const unsigned plds = (unsigned)g.max_depth * 256u * 20u + (dense_k ? kOctDenseExtra : 0u);
             unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = cus * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;
             // an octree ray costs ~10x a voxel ray: ticket atomics never bind.  K2p: 32 rays; K2d finishes rays sooner and likes 16
             // (8 / 16 / 24 / 32 rays per ticket: 1M rays 478 / 502 / 466 / 489 Mrays/s, 1.5M 553 / 570 / 569 / 563, 524k 353 / 354 / 348 / 346)
-            const bool dense_k = f == M.octree_dense && f != nullptr;
             sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : (dense_k ? 16 : 32);
             sub.static_rays = static_chunk_rays(m, pgrid, true, dense_k);    // K2p: 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336; K2d: half
                                                                              // the share (393k rays 338 -> 418 Mrays/s, 524k 421 -> 474, 655k 393 -> 515)
@@ -1196,6 +1294,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             g.tight_rad = s.kd_tight_rad;
         }
         hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only).f;
+        if (!f && (flags & HARE_SHOOT_COUNT_OWN)) return no_own_build();
         if (!f) {
             set_error("hare_shoot: kd-tree kernel missing from code object");
             return HARE_E_STATE;
@@ -1554,7 +1653,10 @@ static int sync_partition_to_device(hare_scene* s, int kind)
         // the tight boxes, per topology a query may name (one whose polygon ids the lists stay inside)
         rc = upload_tight_boxes(s, H, s->oct, s->oct.id_count, s->d_oct_tight, s->oct_tight_mid, s->oct_tight_rad);
         if (rc) return rc;
-        return upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
+        rc = upload(H, &s->d_oct_items, s->oct.items.data(), s->oct.items.size() * sizeof(int32_t));
+        if (rc) return rc;
+        reserve_oct_scratch(*s, H);            // the launch path never allocates (nor synchronises the device) after this
+        return HARE_OK;
     }
     rc = upload(H, &s->d_kd_nodes, s->kd.nodes.data(), s->kd.nodes.size() * sizeof(KdNodeRec));
     if (rc) return rc;
@@ -2142,7 +2244,7 @@ const char* hare_shoot_kernel_name(const hare_scene* s, int32_t kind, int32_t to
 {
     if (!s || top_index < 0 || top_index >= (int32_t)s->topos.size() || kind < HARE_KIND_VOXEL || kind > HARE_KIND_KDTREE) return "";
     // the launcher's own selection (choose_kernel), fall-backs included
-    const KernChoice kc = choose_kernel(*s, s->module, kind, (size_t)top_index, n, sanitize_flags(*s, flags) & ~HARE_SHOOT_BOUNCE_LOOP);
+    const KernChoice kc = choose_kernel(*s, s->module, kind, (size_t)top_index, n, sanitize_flags(*s, flags));
     if ((flags & HARE_SHOOT_BOUNCE_LOOP) && kc.k == Kern::VoxelPool && s->opt.bounce_fused && (flags & (HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL)) == 0) {
         // hare_bounce_device (<= 16 casts): the fused build of the pool kernel, where it exists and fits (bounce_device_impl's rule)
         const bool quads = s->topos[(size_t)top_index].has_quads, coarse = s->occ_shift > 0;
@@ -2219,13 +2321,9 @@ int hare_expand_events(const hare_scene* s, int32_t kind, int64_t n, const hare_
 }
 
 // Diagnostics / A-B switches of one scene (SceneOptions, scene.h).  Not thread-safe against shoots in flight on the scene.
-int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
-{
-    if (!s || !name) {
-        set_error("hare_scene_set_option: null argument");
-        return HARE_E_INVALID;
-    }
-    struct { const char* name; int SceneOptions::*field; int64_t lo, hi; } table[] = {
+namespace {
+struct OptionEntry { const char* name; int SceneOptions::*field; int64_t lo, hi; };
+const OptionEntry kOptionTable[] = {
         {"dev", &SceneOptions::dev, 0, 1},
         {"build_host", &SceneOptions::build_host, 0, 1},
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
@@ -2233,6 +2331,8 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"octree_tail", &SceneOptions::octree_tail, 0, 2},
         {"octree_tight", &SceneOptions::octree_tight, 0, 1},
         {"voxel_tight", &SceneOptions::voxel_tight, 0, 1},
+        {"voxel_tight_max_mb", &SceneOptions::voxel_tight_max_mb, 0, 1 << 30},
+        {"dev_fail_cellbox_alloc", &SceneOptions::dev_fail_cellbox_alloc, 0, 1},
         {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},
         {"k2p_tail_max", &SceneOptions::k2p_tail_max, 0, 64},
         {"k2p_tail_patience", &SceneOptions::k2p_tail_patience, -1, 100000},
@@ -2242,18 +2342,67 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
         {"batch_chunks", &SceneOptions::batch_chunks, 0, 16},
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},
         {"wide_drain", &SceneOptions::wide_drain, 0, 1},
-    };
+};
+}  // namespace
+
+int hare_scene_get_option(const hare_scene* s, const char* name, int64_t* value)
+{
+    if (!s || !name || !value) {
+        set_error("hare_scene_get_option: null argument");
+        return HARE_E_INVALID;
+    }
+    if (strcmp(name, "voxel_tight_bytes") == 0) {
+        int64_t bytes = 0;
+        if (s->cellbox_rad > 0)
+            for (void* p : s->d_cellbox)
+                if (p) bytes += (int64_t)s->vox.ct * s->vox.ct * s->vox.ct * 8 * (int64_t)sizeof(float);
+        *value = bytes;
+        return HARE_OK;
+    }
+    if (strcmp(name, "octree_scratch_bytes") == 0) {
+        *value = s->d_oct_tail ? (int64_t)Scene::kOctTailRing * (int64_t)s->oct_tail_block_bytes : 0;
+        return HARE_OK;
+    }
+    for (const OptionEntry& t : kOptionTable)
+        if (strcmp(t.name, name) == 0) {
+            *value = s->opt.*(t.field);
+            return HARE_OK;
+        }
+    set_error(std::string("hare_scene_get_option: unknown option ") + name);
+    return HARE_E_INVALID;
+}
+
+int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
+{
+    if (!s || !name) {
+        set_error("hare_scene_set_option: null argument");
+        return HARE_E_INVALID;
+    }
     if (strcmp(name, "dev_order_ptr") == 0) {       // developer experiments: see SceneOptions::dev_order_ptr
         s->opt.dev_order_ptr = (long long)value;
         return HARE_OK;
     }
-    for (auto& t : table)
+    for (const OptionEntry& t : kOptionTable)
         if (strcmp(t.name, name) == 0) {
             if (value < t.lo || value > t.hi) {
                 set_error(std::string("hare_scene_set_option: value out of range for ") + name);
                 return HARE_E_INVALID;
             }
             s->opt.*(t.field) = (int)value;
+            // the voxels' tight boxes exist only while the option asks for them (upload_cell_boxes): switching it on for a grid that is
+            // on the device without them builds them now; a changed budget (or the test hook) re-decides.  Like every build call this
+            // is not thread-safe against shoots on the same scene.
+            const bool box_option = t.field == &SceneOptions::voxel_tight || t.field == &SceneOptions::voxel_tight_max_mb ||
+                                    t.field == &SceneOptions::dev_fail_cellbox_alloc;
+            if (box_option && s->vox.built && !s->d_cells.empty() && s->module) {
+                const bool rebuild = t.field == &SceneOptions::voxel_tight ? (value != 0 && s->cellbox_rad <= 0) : true;
+                if (rebuild) {
+                    const HipApi* H = hip_api(nullptr);
+                    if (!H) return HARE_OK;
+                    DeviceGuard dev_guard(H, s->device);
+                    return upload_cell_boxes(*s, H);
+                }
+            }
             return HARE_OK;
         }
     set_error(std::string("hare_scene_set_option: unknown option ") + name);

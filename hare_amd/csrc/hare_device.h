@@ -37,7 +37,9 @@ enum : uint32_t {
 };
 
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)
-enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_WORDS = 8 };
+enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_CULLS = 5 /* HARE_SHOOT_COUNT_OWN: candidates pre-culled */, CTR_WORDS = 8 };
+// what one lane of a counting build (HARE_SHOOT_COUNT_OWN, the *_own kernels) has seen its rays do
+struct OwnWork { unsigned cells = 0, entries = 0, culls = 0, tests = 0; };
 
 // The FP32 pre-cull's operands (v0, e1f, e2f) live in a dense array of their own, apart from the 128-byte records the exact test
 // reads.  Cell and leaf lists hold runs of consecutive polygon ids (82 % of neighbouring entries differ by one in the bench scenes,

@@ -126,6 +126,19 @@ __device__ __forceinline__ void launch_epilogue(const ShootIO& io, unsigned int 
     }
 }
 
+// HARE_SHOOT_COUNT_OWN: what a lane of a counting build (the *_own kernels) saw its rays do; summed over the wave into words 2 .. 5
+__device__ __forceinline__ void flush_own(unsigned long long* ctr, const OwnWork& w)
+{
+    if (!ctr) return;
+    const unsigned long long c = wave_sum_u32(w.cells), e = wave_sum_u32(w.entries), k = wave_sum_u32(w.culls), t = wave_sum_u32(w.tests);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&ctr[CTR_CELLS], c);
+        atomicAdd(&ctr[CTR_ENTRIES], e);
+        atomicAdd(&ctr[CTR_TESTS], t);
+        atomicAdd(&ctr[CTR_CULLS], k);
+    }
+}
+
 // Per-wave accumulation of the batch counters: one atomic per counter per wave.
 __device__ __forceinline__ void flush_counters(unsigned long long* ctr, bool valid, bool hit, const Work& w, bool detailed)
 {
@@ -800,9 +813,12 @@ __device__ __forceinline__ int wave_scan_max(int v)   // values >= -1
 // Knobs (hare_device.h): HARE_K2D_PEND survivors a lane may hold before it has to wait for the exact phase; HARE_K2D_CAP list entries of one
 // leaf that go into one round's dense passes; HARE_K2D_EXACT_MIN lanes holding a survivor that make the exact phase run (or one that
 // cannot go on); HARE_K2D_STEPS pop steps per round.
-template <bool OCC, bool DENSE = false>
+// OWN (hare_octree_dense_own; flag HARE_SHOOT_COUNT_OWN): the same kernel counting ITS OWN work -- node records fetched (pops and the
+// root), list entries put through the dense pre-cull, exact tests -- into words 2 .. 5 of the counters block (bench.py: `roofline.own`).
+template <bool OCC, bool DENSE = false, bool OWN = false>
 __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const ShootIO& io)
 {
+    OwnWork ownw;
     int tail_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int nt = 256;          // the launch's block size (api.cpp: launch_persist): frame indices are shifts, not 32-bit multiplies (quarter rate)
@@ -1079,6 +1095,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         if (invDy < 0) { const double s = ty0; ty0 = ty1; ty1 = s; }
                         if (invDz < 0) { const double s = tz0; tz0 = tz1; tz1 = s; }
                         const double rmin = omax(omax(tx0, ty0), tz0), rmax = omin(omin(tx1, ty1), tz1);   // :182-183
+                        if (OWN) ownw.cells++;                                // the root's record
                         if (rmax < rmin || rmax < 0) finish();               // :185 (and the identical pop test :207)
                         else visit(root, rmin, rmax, std::false_type{});
                         // (Sending the root through the pop phase instead -- a level-0 frame with node 0 as its only child -- takes the
@@ -1147,6 +1164,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         // the whole 64-byte record in ONE batch of loads: left to itself the compiler fetches the last four words -- child
                         // index, list words -- in the branches that use them, a second and a third wait per pop
                         OctNode nd = g.nodes[c];
+                        if (OWN) ownw.cells++;
                         // ... and, in the same batch, the box of the polygons its subtree lists (api.cpp: make_tight_boxes)
                         float4 tb0 = make_float4(0, 0, 0, 0), tb1 = tb0;
                         if (FAST && g.tight != nullptr) {
@@ -1235,6 +1253,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 if (valid) {
                     i = g.items[rel_o + base + lane];
                     surv = !cull_test(g, cr, cull_load(g, i));
+                    if (OWN) { ownw.entries++; ownw.culls++; }
                 }
                 const unsigned long long sb = __ballot(surv);
                 // owner side: the survivors of its segment, in list order, as far as its pending list has room
@@ -1288,6 +1307,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         const PolyRec& p = g.polys[i];
                         const double* v3 = (g.quads && g.quads[i].nverts == 4) ? g.quads[i].v3 : nullptr;
                         double t, u, v;
+                        if (OWN) ownw.tests++;
                         const bool ok = poly_full(p, v3, o, d, t, u, v) && t > kTMin;                  // :224
                         if (w < 0) cur_skip = hit && closestT <= lk;              // a new leaf: :210 as at its pop (no accept lies in between)
                         if (ok && !cur_skip && t < closestT) {                                          // :225
@@ -1420,6 +1440,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         for (int k = 0; k < 14; ++k) atomicAdd(&io.prof[k], v[k]);
     }
 #endif
+    if (OWN) flush_own(io.ctr, ownw);
     launch_epilogue(io, nrays, nhits, 4u);
 }
 
@@ -1571,6 +1592,8 @@ __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(O
 // K2d: K2p with its leaf entries spread densely over the wave and its exact tests deferred (octree_persist_body<.., DENSE>);
 // dynamic LDS = K2p's frames + kOctDenseExtra bytes per workgroup
 __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense(OctreeArgs g, ShootIO io) { octree_persist_body<false, true>(g, io); }
+// ... and its counting build (HARE_SHOOT_COUNT_OWN)
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense_own(OctreeArgs g, ShootIO io) { octree_persist_body<false, true, true>(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }

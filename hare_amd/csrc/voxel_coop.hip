@@ -28,7 +28,7 @@ constexpr uint32_t kTF_NX = 1u << 27, kTF_NY = 1u << 28, kTF_NZ = 1u << 29, kTF_
 // are the returned hit (t measured from the origin the walk uses: the moved one when kTF_MOVED).  Every lane returns the same.
 template <bool QUADS, bool COARSE>
 __device__ __forceinline__ bool coop_trace(const VoxelArgs& g, const ShootIO& io, const uint32_t* locc, unsigned ray, uint32_t xf,
-                                           double tMaxX, double tMaxY, double tMaxZ, double& tmin, int& pid)
+                                           double tMaxX, double tMaxY, double tMaxZ, double& tmin, int& pid, OwnWork* own = nullptr)
 {
     const unsigned lane = threadIdx.x & 63u;
     const int ct = g.ct;
@@ -60,8 +60,10 @@ __device__ __forceinline__ bool coop_trace(const VoxelArgs& g, const ShootIO& io
                 int i = -1;
                 if (valid) i = k == 0 ? c.i0 : (k == 1 ? c.i1 : g.items[c.start + k]);
                 bool test = valid && i != e1 && i != e2;
+                if (own) { own->entries += valid ? 1u : 0u; own->culls += test ? 1u : 0u; }
                 if (test) test = !cull_test(g, cray, cull_load(g, i));
                 double t = kDblMax;
+                if (own) own->tests += test ? 1u : 0u;
                 if (test) {
                     const PolyRec& p = g.polys[i];
                     const double v0[3] = {p.v0[0], p.v0[1], p.v0[2]}, v1[3] = {p.v1[0], p.v1[1], p.v1[2]};
@@ -121,6 +123,7 @@ __device__ __forceinline__ bool coop_trace(const VoxelArgs& g, const ShootIO& io
         tMaxY = sy ? nY : tMaxY;
         tMaxZ = sz ? nZ : tMaxZ;
         if (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct)) break;   // leaving the grid: miss (F12)
+        if (own && lane == 0) own->cells++;
     }
     pid = -1;
     return false;

@@ -92,9 +92,14 @@ namespace {
 // rays are carried, no packing.  Per ray the sequence of operations is that of the launch-per-cast loop; the events of every cast
 // are identical to it (tests).  The event slot io.out[ray] is the ray's scratch through all its casts and ends up holding the last
 // cast's X_Event (a miss record once the ray has died); io.out_all, if given, receives every cast's final event.
-template <bool QUADS, bool COARSE, bool BOUNCE = false>
+//
+// OWN (hare_voxel_pool_*_own, round 5; flag HARE_SHOOT_COUNT_OWN): the same kernel counting ITS OWN work per lane -- voxels it walked into,
+// list entries it scanned, candidates it pre-culled, exact tests it made -- into words 2 .. 5 of the counters block: the numerator of
+// bench.py's `roofline.own` (the reference-priced figure counts voxels, entries and tests this kernel skips).  Events are identical.
+template <bool QUADS, bool COARSE, bool BOUNCE = false, bool OWN = false>
 __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootIO& io)
 {
+    OwnWork own;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr unsigned S = kPoolSlots, R = kPoolRing, SM = kPoolRing - 1;   // slots; queue (ring) capacity and its mask
     uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);
@@ -344,6 +349,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         arm(slot, ray, o, d, to_walk, to_cull, freed);
                     }
                 }
+                if (OWN && (to_walk || to_cull)) own.cells++;            // the voxel the ray starts in
                 push(Q_walk, hW, nW, to_walk, slot);
                 push(Q_cull, hC, nC, to_cull, slot);
                 push(Q_free, hF, nF, freed, slot);
@@ -392,6 +398,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     nrays++;
                     const V3 o2 = {nr.x, nr.y, nr.z}, d2 = {nr.dx, nr.dy, nr.dz};
                     arm(slot, ray, o2, d2, to_walk, to_cull, freed);
+                    if (OWN && (to_walk || to_cull)) own.cells++;
                 } else {
                     freed = true;                                               // its last cast: the event is where it belongs
                 }
@@ -473,6 +480,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 if (walking) {
                     HARE_K1Q_STEP();
                     const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
+                    if (OWN && !out && sub == 0u) own.cells++;                // the group's lanes run the same walk: counted once
                     if (out) {
                         exited = true;
                         walking = false;
@@ -524,6 +532,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if (__ballot(scanning) == 0) break;
                     if (scanning) {
                         const int it0 = n0, it1 = n1, it2 = n2, it3 = n3;
+                        if (OWN) { const unsigned m4 = cnt - base < 4u ? cnt - base : 4u; own.entries += m4; own.culls += m4; }
                         if (base + 4u < cnt) entries(base + 4u);
                         const CullRaw r0 = cull_load(g, it0), r1 = cull_load(g, it1), r2 = cull_load(g, it2), r3 = cull_load(g, it3);
                         auto keep = [&](unsigned k, int it, const CullRaw& rr) {
@@ -599,6 +608,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     const int cell = out ? 0 : (X * ct + Y) * ct + Z;
                     const bool occ = occupied(out ? 0 : X, out ? 0 : Y, out ? 0 : Z, cell);
                     walking = !out && !occ;
+                    if (OWN && !out) own.cells++;
                 }
             }
             const bool exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
@@ -690,6 +700,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 s1 = keep(k0 + 1u, it1, r1);
                 s2 = keep(k0 + 2u, it2, r2);
                 s3 = keep(k0 + 3u, it3, r3);
+                if (OWN) { const unsigned m4 = k0 >= qe ? 0u : (qe - k0 < 4u ? qe - k0 : 4u); own.entries += m4; own.culls += m4; }
             }
             const unsigned long long b0 = __ballot(s0), b1 = __ballot(s1), b2 = __ballot(s2), b3 = __ballot(s3);
             const unsigned sh = grp << gsh;
@@ -789,6 +800,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     const bool step = culling && valid && !keep;                // consumed
                     done1 = (step && !sk) ? c : done1;                          // a certain miss counts as tested
                     consumed += step ? 1u : 0u;
+                    if (OWN) { own.entries += (step || keep) ? 1u : 0u; own.culls += ((step || keep) && !sk) ? 1u : 0u; }
                     parked = parked || keep;
                     culling = culling && valid && !keep;
                 }
@@ -911,6 +923,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #pragma unroll
                 for (int m = 0; m < 3; ++m) { a[m] = side ? v0[m] : v2[m]; c[m] = side ? v2[m] : v0[m]; }
                 double t = 0;
+                if (OWN) own.tests++;
                 bool ok = tri_fast(o, d, a, v1, c, t);
                 if (QUADS) {
                     const double v3[3] = {q3x, q3y, q3z};
@@ -980,6 +993,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
                         const int cell = out ? 0 : (X * ct + Y) * ct + Z;
                         const bool occ = occupied(out ? 0 : X, out ? 0 : Y, out ? 0 : Z, cell);
+                        if (OWN && !out) own.cells++;
                         exited = out;                                       // leaving the grid: miss, even with the hit pending (F12)
                         to_cull = !out && occ;
                         walking = !out && !occ;
@@ -1039,7 +1053,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 int pid = -1;
                 double* sc = reinterpret_cast<double*>(&io.out[ray]);              // the ray's scratch: this wave wrote it
                 if (xf & F_HIT) { tmin = sc[0]; pid = __double2loint(sc[6]); }
-                const bool hit = coop_trace<QUADS, COARSE>(g, io, locc, ray, xf, L_tmx[slot], L_tmy[slot], L_tmz[slot], tmin, pid);
+                const bool hit = coop_trace<QUADS, COARSE>(g, io, locc, ray, xf, L_tmx[slot], L_tmy[slot], L_tmz[slot], tmin, pid, OWN ? &own : nullptr);
                 ++helped;
                 if (lane == 0) {
                     XEventRec ev;
@@ -1100,6 +1114,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         }
     }
 
+    if (OWN) flush_own(io.ctr, own);
     launch_epilogue(io, nrays, nhits, (unsigned)kPoolWaves);     // batch counters + the launch slot left zeroed
 }
 
@@ -1110,6 +1125,11 @@ __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_tri(Voxel
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_quad(VoxelArgs g, ShootIO io) { voxel_pool_body<true, false>(g, io); }
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_tri_g(VoxelArgs g, ShootIO io) { voxel_pool_body<false, true>(g, io); }
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_quad_g(VoxelArgs g, ShootIO io) { voxel_pool_body<true, true>(g, io); }
+// the counting builds (HARE_SHOOT_COUNT_OWN): the same events, plus the kernel's own voxels / list entries / pre-culls / exact tests
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_tri_own(VoxelArgs g, ShootIO io) { voxel_pool_body<false, false, false, true>(g, io); }
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_quad_own(VoxelArgs g, ShootIO io) { voxel_pool_body<true, false, false, true>(g, io); }
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_tri_g_own(VoxelArgs g, ShootIO io) { voxel_pool_body<false, true, false, true>(g, io); }
+__global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_pool_quad_g_own(VoxelArgs g, ShootIO io) { voxel_pool_body<true, true, false, true>(g, io); }
 // the whole specular bounce loop of every ray in one launch (BOUNCE, above): dynamic LDS = bitmap + waves x (kPoolWaveBytes + kPoolBounceExtra)
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_bounce_tri(VoxelArgs g, ShootIO io) { voxel_pool_body<false, false, true>(g, io); }
 __global__ __launch_bounds__(64 * HARE_K1Q_WAVES) void hare_voxel_bounce_quad(VoxelArgs g, ShootIO io) { voxel_pool_body<true, false, true>(g, io); }

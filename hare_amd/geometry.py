@@ -178,6 +178,12 @@ class Spatial_Partition:
         check(lib.hare_scene_set_option(self._h, name.encode(), int(value)))
         return self
 
+    def get_option(self, name: str) -> int:
+        """hare_scene_get_option: an option read back, or "voxel_tight_bytes" / "octree_scratch_bytes" (device memory of the accelerators)."""
+        v = C.c_int64()
+        check(lib.hare_scene_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def close(self):
         if getattr(self, "_h", None):
             lib.hare_scene_destroy(self._h)

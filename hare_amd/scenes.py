@@ -9,7 +9,9 @@ Rules that make the inputs safe for exact parity:
     no two distinct lattice points share a Hash2 1 mm sub-cell (Hare_Geometry_Primitives.cs:237-250);
   * the shell's min corner is the origin, so the Octree root-box quirk
     ("Octree - alt.cs":78-82, `max + min / 2`) still covers the model;
-  * meshes are all triangles, polygon index = generation order.
+  * the BASELINE meshes (shoebox, hall, cathedral) are all triangles, polygon index = generation order; `hall_quads` is the hall with
+    its flat lattices left UN-SPLIT: planar quadrilaterals (Hare_Geometry_Polygons.cs:731-823) beside the triangles of the two
+    displaced surfaces -- what a Pachyderm model looks like (round 5).
 
 Mesh format: verts float64 [P, 4, 3] (corner 3 zero for triangles), nverts int32 [P].
 """
@@ -39,9 +41,14 @@ class Mesh:
         return int(self.verts.shape[0])
 
 
+_QUADS = False      # set by hall_quads() while it generates: flat patches come back as quadrilaterals [n,4,3] instead of triangle pairs
+
+
 def _patch(origin, eu, ev, nu, nv, disp=None):
     """Triangulated rectangle origin + s*eu + t*ev, nu x nv quads, each split along the same
-    diagonal.  disp(points[N,3]) -> displaced points, applied before snapping."""
+    diagonal.  disp(points[N,3]) -> displaced points, applied before snapping.  (hall_quads: a patch
+    without displacement -- every cell of it exactly planar on the lattice -- is left un-split, corners
+    p00, p10, p11, p01: the diagonal the triangles use is the one Quadrilateral.Intersect tries first.)"""
     origin = np.asarray(origin, np.float64)
     eu = np.asarray(eu, np.float64)
     ev = np.asarray(ev, np.float64)
@@ -56,6 +63,8 @@ def _patch(origin, eu, ev, nu, nv, disp=None):
     p10 = pts[1:, :-1]
     p11 = pts[1:, 1:]
     p01 = pts[:-1, 1:]
+    if _QUADS and disp is None:
+        return np.stack([p00, p10, p11, p01], axis=2).reshape(-1, 4, 3)
     ta = np.stack([p00, p10, p11], axis=2)   # [nu,nv,3,3]
     tb = np.stack([p00, p11, p01], axis=2)
     tris = np.stack([ta, tb], axis=2).reshape(-1, 3, 3)  # face-major, row-major, A then B
@@ -90,16 +99,19 @@ def _box(lo, hi, edge, skip=()):
 
 
 def _finish(name, parts, size):
-    tris = np.concatenate(parts, axis=0)
-    # drop degenerate triangles a snap could create (none expected; guard anyway)
-    e1 = tris[:, 1] - tris[:, 0]
-    e2 = tris[:, 2] - tris[:, 0]
-    area2 = np.linalg.norm(np.cross(e1, e2), axis=1)
-    tris = tris[area2 > 0]
-    P = tris.shape[0]
-    verts = np.zeros((P, 4, 3), np.float64)
-    verts[:, :3, :] = tris
-    return Mesh(name, np.ascontiguousarray(verts), np.full(P, 3, np.int32), size)
+    vs, ns = [], []
+    for part in parts:                       # generation order is kept: polygon index = position
+        k = part.shape[1]                    # 3 or 4 corners
+        v = np.zeros((part.shape[0], 4, 3), np.float64)
+        v[:, :k, :] = part
+        vs.append(v)
+        ns.append(np.full(part.shape[0], k, np.int32))
+    verts, nverts = np.concatenate(vs, axis=0), np.concatenate(ns, axis=0)
+    # drop degenerate polygons a snap could create (none expected; guard anyway)
+    e1 = verts[:, 1] - verts[:, 0]
+    e2 = verts[:, 2] - verts[:, 0]
+    keep = np.linalg.norm(np.cross(e1, e2), axis=1) > 0
+    return Mesh(name, np.ascontiguousarray(verts[keep]), np.ascontiguousarray(nverts[keep]), size)
 
 
 def shoebox(nface: int = 9, size=(10.0, 7.0, 4.0)) -> Mesh:
@@ -186,7 +198,20 @@ def cathedral(edge: float = 51.0 / 256.0, size=(90.0, 40.0, 35.0)) -> Mesh:
     return _finish("cathedral-1M", parts, tuple(size))
 
 
-SCENES = {"shoebox": shoebox, "hall": hall, "cathedral": cathedral}
+def hall_quads(edge: float = 83.0 / 256.0, size=(40.0, 25.0, 18.0)) -> Mesh:
+    """The hall with its flat lattices un-split: 39,263 planar quadrilaterals (walls, floor, balconies, columns, stage, riser) + the
+    22,382 triangles of the displaced ceiling and the raked floor = 61,645 polygons covering exactly the surfaces of `hall`."""
+    global _QUADS
+    _QUADS = True
+    try:
+        m = hall(edge, size)
+    finally:
+        _QUADS = False
+    m.name = "hall-quads-62k"
+    return m
+
+
+SCENES = {"shoebox": shoebox, "hall": hall, "cathedral": cathedral, "hall_quads": hall_quads}
 
 
 # ---------------------------------------------------------------- rays

@@ -69,6 +69,12 @@ extern "C" {
                                        /* HARE_SHOOT_WRITEBACK_ORIGIN (HARE_E_INVALID): hare_expand_events redoes the origin move from    */
                                        /* the rays as they were passed in, which the write-back would have overwritten                   */
 
+#define HARE_SHOOT_COUNT_OWN 64u       /* measurement: run the COUNTING BUILD of the production kernel the batch would get (the pool kernel of   */
+                                       /* Voxel_Grid, hare_octree_dense, the kd-tree kernel) -- same events, slower -- and fill hare_counters     */
+                                       /* with the work THAT kernel did: cells = voxels walked into / node records fetched, entries = list         */
+                                       /* entries scanned, reserved[0] = candidates pre-culled, tests = exact polygon tests.  (COUNT_WORK counts   */
+                                       /* the REFERENCE algorithm's work with a diagnostic kernel.)  HARE_E_UNSUPPORTED for a batch another        */
+                                       /* kernel would serve.  No reference counterpart                                                            */
 #define HARE_SHOOT_BOUNCE_LOOP 32u     /* hare_shoot_kernel_name only: name the kernel hare_bounce_device (<= 16 casts) launches for n rays           */
 
 /* Hare.Geometry.Ray (Hare_Geometry_Primitives.cs:393-429): origin + direction.  Ray_ID/ThreadID
@@ -187,10 +193,23 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "octree_tight"    1 (default): the octree and kd-tree kernels drop a node whose subtree's polygons the ray cannot hit -- per node the box of
  *                     all polygons its subtree lists, built when the tree goes to the device; 0: every node the reference visits.  Results never
  *                     depend on it (an X_Event is the reference's bit for bit either way)
- *   "voxel_tight"     the same per voxel: a ray without a hit walks on past an occupied voxel whose polygons it cannot hit; 1 (default) / 0
+ *   "voxel_tight"     the same per voxel: a ray without a hit walks on past an occupied voxel whose polygons it cannot hit; 1 (default) / 0.
+ *                     The boxes cost 32 B per voxel and topology and exist only while this is on and the pool kernel serves the grid (up to
+ *                     512 voxels a side); switching it on later builds them then
+ *   "voxel_tight_max_mb"  budget for those boxes in MiB (0, the default: none).  Over budget -- or out of device memory -- the grid is
+ *                     built and traced without them: never an error, never a different result
  *   "dev"             1: developer flag bits of hare_shoot_* (timeline, phase profile, cull audit) pass
  * Single-caller like the build calls: not to be changed while shoots are in flight on the scene. */
 HARE_API int hare_scene_set_option(hare_scene *s, const char *name, int64_t value);
+
+/* Read an option back (any name hare_scene_set_option takes), or one of the read-only figures a host sizes its memory by:
+ *   "voxel_tight_bytes"     device bytes the voxels' tight boxes take on this scene (32 B per voxel and topology; 0: none -- the option is
+ *                           off, the grid is one the pool kernel does not serve, over "voxel_tight_max_mb", or their allocation failed:
+ *                           the grid is then traced without them, same results)
+ *   "octree_scratch_bytes"  device bytes of the octree kernels' scratch ring (hand-over records and stack spill; 0 before the first
+ *                           octree launch that needs one)
+ * No reference counterpart: Hare has no device memory to account for. */
+HARE_API int hare_scene_get_option(const hare_scene *s, const char *name, int64_t *value);
 
 /* ---- partition constructors ----
  * The voxel grid and the octree (of a single topology) are built on the GPU when one is present (environment

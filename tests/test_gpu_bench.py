@@ -22,6 +22,7 @@ def _bench(*args):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    assert len(lines[0]) < 8000, len(lines[0])         # the driver keeps the last 8 KB of stdout: the whole line must survive
     return json.loads(lines[0])
 
 
@@ -103,8 +104,8 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
     one GPU's share of the 8-GPU configs (c4_shard, c5_shard) and the whole configs (c4, c5: the N = 1 point of the strong-scaling
     curve); each carries value, roofline, cpu_baseline and the parity flag."""
     j = _bench("--rays", "32768", "--steps", "2", "--warmup", "1", "--extra-configs", "--extra-rays", "32768")
-    assert set(j["configs"]) == {"c3", "c4_shard", "c5_shard", "c4", "c5"}
-    want = {"c3": OCTREE_KERNEL, "c4_shard": "hare_voxel_pool_tri_g", "c5_shard": "hare_voxel_pool_tri_g",
+    assert set(j["configs"]) == {"c3", "c2_quads", "c4_shard", "c5_shard", "c4", "c5"}
+    want = {"c3": OCTREE_KERNEL, "c2_quads": "hare_voxel_pool_quad", "c4_shard": "hare_voxel_pool_tri_g", "c5_shard": "hare_voxel_pool_tri_g",
             "c4": "hare_voxel_pool_tri_g", "c5": "hare_voxel_pool_tri_g"}
     for name, sub in j["configs"].items():
         assert sub["x_event_parity_vs_oracle"] is True, name
@@ -114,6 +115,11 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
         assert sub["scaling"] == ("strong" if name in ("c4", "c5") else "weak")
     assert j["configs"]["c5"]["roofline"]["live_casts_per_pass"] > 32768 * 7
     assert j["configs"]["c5_shard"]["bounce_batch"]["parity_vs_oracle"] is True
+    for name in ("c2_quads", "c4_shard", "c5_shard", "c4", "c5"):        # the pool kernel has a counting build: the kernel's OWN bytes, which cannot pass the peak
+        own = j["configs"][name]["roofline"]["own"]
+        assert 0 < own["frac"] <= 1.0 and own["per_cast"]["T"] > 0 and own["per_cast"]["C"] > 0, (name, own)
+    assert j["configs"]["c3"]["roofline"]["own"].get("frac") is None      # 32 768 rays go to hare_octree_group, which has none: the line says why
+    assert "counting build" in j["configs"]["c3"]["roofline"]["own"]["why"]
     assert j["metric"].startswith("Mrays/s") and j["x_event_parity_vs_oracle"] is True     # the headline fields are untouched
 
 
@@ -131,3 +137,8 @@ def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert rf["algorithmic_bytes_per_launch"] > 104 * j["config"]["rays_per_gpu"] * 0.5
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+    assert "timed region" in rf["kernel_ms_source"] or "event pair" in rf["kernel_ms_source"]     # ONE estimator, named
+    if "octree" not in extra:
+        own = rf["own"]          # counted by the counting build of the kernel that was timed, on the same rays
+        assert 0 < own["frac"] <= 1.0 and own["bytes_per_launch"] >= 104 * j["config"]["rays_per_gpu"]
+        assert own["per_cast"]["L"] >= own["per_cast"]["K"] >= own["per_cast"]["T"] > 0

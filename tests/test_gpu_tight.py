@@ -328,3 +328,47 @@ def test_a_scene_far_from_the_origin_of_its_coordinates():
         for tight in (1, 0):
             kd.set_option("octree_tight", tight)
             assert_events_equal(kd.Shoot_batch(rays[:6000])[0], kref, what=f"shifted {shift[0]:.0e} kd tight={tight}")
+
+
+def test_a_grid_without_its_tight_boxes_is_built_and_traced_all_the_same(monkeypatch):
+    """ADVICE (round 4): the boxes cost 32 B per voxel and topology and are an acceleration, not a precondition.  They are built only while
+    `voxel_tight` is on and the pool kernel serves the grid; over the budget `voxel_tight_max_mb`, or when their allocation fails (the
+    hook `dev_fail_cellbox_alloc` / HARE_FAIL_CELLBOX_ALLOC), the build SUCCEEDS, the scene holds no boxes and every X_Event is the same."""
+    v, nv, size = soup(n_tri=600, n_quad=100, seed=5)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = soup_rays(20_000, size, seed=6)
+    D = 24
+    ref, _ = po.VoxelGrid([To], domain=D).shoot(rays)
+    g = H.Voxel_Grid([T], D)
+    full = D * D * D * 32
+    assert g.get_option("voxel_tight_bytes") == full                     # built with the grid
+    assert_events_equal(g.Shoot_batch(rays)[0], ref, what="boxes built")
+    g.set_option("voxel_tight_max_mb", 0)
+    g.set_option("dev_fail_cellbox_alloc", 1)                            # "out of memory": the call succeeds, no boxes
+    assert g.get_option("voxel_tight_bytes") == 0
+    assert_events_equal(g.Shoot_batch(rays)[0], ref, what="allocation failed")
+    g.set_option("dev_fail_cellbox_alloc", 0)                            # memory is back: they are rebuilt
+    assert g.get_option("voxel_tight_bytes") == full
+    g2 = H.Voxel_Grid([T], 128)                                          # 64 MiB of boxes against a budget of 1 MiB
+    g2.set_option("voxel_tight_max_mb", 1)
+    assert g2.get_option("voxel_tight_bytes") == 0
+    ref128, _ = po.VoxelGrid([To], domain=128).shoot(rays)
+    assert_events_equal(g2.Shoot_batch(rays)[0], ref128, what="over budget")
+    g2.set_option("voxel_tight_max_mb", 0)
+    assert g2.get_option("voxel_tight_bytes") == 128 ** 3 * 32
+    assert_events_equal(g2.Shoot_batch(rays)[0], ref128, what="budget lifted")
+    # a grid BUILT while the allocation fails (the environment is read when the scene is created; developer variables need HARE_DEV)
+    monkeypatch.setenv("HARE_DEV", "1")
+    monkeypatch.setenv("HARE_FAIL_CELLBOX_ALLOC", "1")
+    g3 = H.Voxel_Grid([T], D)
+    assert g3.get_option("voxel_tight_bytes") == 0
+    assert_events_equal(g3.Shoot_batch(rays)[0], ref, what="built without boxes")
+    monkeypatch.delenv("HARE_FAIL_CELLBOX_ALLOC")
+    # switched off before the build: nothing is allocated; switched on later: built then
+    monkeypatch.setenv("HARE_VOXEL_TIGHT", "0")
+    g4 = H.Voxel_Grid([T], D)
+    assert g4.get_option("voxel_tight") == 0 and g4.get_option("voxel_tight_bytes") == 0
+    assert_events_equal(g4.Shoot_batch(rays)[0], ref, what="option off")
+    g4.set_option("voxel_tight", 1)
+    assert g4.get_option("voxel_tight_bytes") == full
+    assert_events_equal(g4.Shoot_batch(rays)[0], ref, what="option on after the build")

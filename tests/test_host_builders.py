@@ -113,6 +113,12 @@ def test_scene_options_are_range_checked_without_a_gpu():
         g.set_option(name, {"coop_tail": 1, "wide_drain": 1, "octree_tail": 2}.get(name, 0))
     with pytest.raises(H.HareError):
         g.set_option("no_such_option", 1)
+    # hare_scene_get_option: every option reads back; the memory figures are 0 on a scene that never saw a device
+    g.set_option("ticket_rays", 96)
+    assert g.get_option("ticket_rays") == 96 and g.get_option("voxel_tight") == 1 and g.get_option("voxel_tight_max_mb") == 0
+    assert g.get_option("voxel_tight_bytes") == 0 and g.get_option("octree_scratch_bytes") == 0
+    with pytest.raises(H.HareError):
+        g.get_option("no_such_option")
 
 
 def test_octree_child_boxes_follow_from_the_parent_box():

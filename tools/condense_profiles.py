@@ -12,9 +12,10 @@ import bench  # noqa: E402  (kernel_source_sha)
 SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_octree_dense", "hare_octree_group", "hare_octree_tail", "hare_kdtree",
          "hare_reflect")
 NSHOOT = len(SHOOT) - 1          # the kernels a shoot consists of (hare_reflect is listed in the summary, not priced)
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r05")
 KEYS = {"c2": "hall-voxel-D64-n1048576", "c2_4M": "hall-voxel-D64-n4194304", "c3": "hall-octree-n1048576", "c3_262k": "hall-octree-n262144",
-        "c4shard": "cathedral-voxel-D128-n2097152", "c5": "cathedral-voxel-D128-n1048576-b8", "kd": "shoebox-kdtree-n1048576"}
+        "c4shard": "cathedral-voxel-D128-n2097152", "c5": "cathedral-voxel-D128-n1048576-b8", "kd": "shoebox-kdtree-n1048576",
+        "kd_hall": "hall-kdtree-n1048576", "c2_quads": "hall_quads-voxel-D64-n1048576"}
 
 
 def counters(d):
@@ -68,13 +69,15 @@ def main(src):
             with open(os.path.join(out, f"{ROUND}_{tag}_kernel_stats.csv"), "w") as f:
                 f.write("\n".join(lines[:9]) + "\n")
         per = {}
-        for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2", "TA"):
+        for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2", "TA", "F64"):
             for k, cs in counters(os.path.join(src, f"{tag}_{cset}")).items():
                 if not k.startswith(SHOOT):
                     continue
                 for c, v in cs.items():
                     if cset == "SQ2" and c == "SQ_ACTIVE_INST_VALU":
                         c = "SQ_ACTIVE_INST_VALU_pass2"      # measured again beside SQ_THREAD_CYCLES_VALU, so that the ratio is of one pass
+                    if cset == "F64" and c == "SQ_INSTS_VALU":
+                        c = "SQ_INSTS_VALU_pass_f64"         # the FP64 instruction classes of round 5 (bench.py: roofline.issue) and the total beside them
                     rows.append((tag, k, c, "%.6g" % (sum(v) / len(v)), len(v)))
                     per.setdefault(k, {})[c] = sum(v) / len(v)
         # a shoot may be two kernels on the stream (K2p + its tail): the launch's figures are their sums; `kernel` names the longer one
@@ -92,6 +95,8 @@ def main(src):
                 traffic[key] = {"kernel": k, "kernels": sorted(shoot), "FETCH_SIZE_KB": cs["FETCH_SIZE"], "WRITE_SIZE_KB": cs["WRITE_SIZE"],
                                 "hbm_bytes_per_launch": int((2 * cs["FETCH_SIZE"] + cs["WRITE_SIZE"]) * 1024),
                                 "SQ_INSTS_VALU": cs.get("SQ_INSTS_VALU"), "kernel_sha16": bench.kernel_source_sha(),
+                                **{c: cs.get(c) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
+                                   if cs.get(c) is not None},
                                 **issue_side(cs, key),
                                 "note": "separate --pmc passes (rocprofv3); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH doubled per "
                                         "MI355X_MICROARCH.md (gfx950 tallies 128-B reads at 64 B; calibrated for wide coalesced reads, so an "

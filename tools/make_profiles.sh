@@ -1,9 +1,9 @@
-# Round-4 profiles (run on the MI355X box): rocprofv3 kernel-trace stats and PMC passes for the bench configurations.
+# Round-5 profiles (run on the MI355X box): rocprofv3 kernel-trace stats and PMC passes for the bench configurations.
 # FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), the SQ counters in two more, TA / TCP in a fifth; never combined with other
-# trace domains.  Condensed into profiles/r04_* by tools/condense_profiles.py (ROUND=r04).
+# trace domains.  Condensed into profiles/r05_* by tools/condense_profiles.py (ROUND=r05).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04prof
+O=$R/gpurun_out/r05prof
 mkdir -p $O
 pmc() {  # tag, pass name, counters..., then "--", bench args
   tag=$1; name=$2; shift 2
@@ -24,6 +24,8 @@ prof() {  # tag, bench args...
     # lane-level VALU utilisation = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64; vector-memory instructions by direction
     pmc $tag SQ2 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES -- "$@"
     pmc $tag TA TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum -- "$@"
+    # wave-level VALU instructions by FP64 class: what bench.py's roofline.issue prices with the measured cost of each class (tools/valu_rate.hip)
+    pmc $tag F64 SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 -- "$@"
   fi
   # the bench line of the same command, un-profiled, with the oracle (roofline, cpu_baseline, parity)
   python3 $R/bench.py "$@" --no-extra-configs > $O/${tag}_bench.json 2> $O/${tag}_bench.err
@@ -35,4 +37,4 @@ prof c3_262k --kind octree --rays 262144 --steps 8 --warmup 2
 prof c4shard --scene cathedral --domain 128 --rays 2097152 --steps 8 --warmup 2
 prof c5 --scene cathedral --domain 128 --bounces 8 --steps 3 --warmup 1
 KT_ONLY=1 prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
-ROUND=r04 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
+ROUND=r05 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
