@@ -49,7 +49,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_SOURCES = ("hare_amd/csrc/kernels.hip", "hare_amd/csrc/voxel_pool.hip", "hare_amd/csrc/voxel_coop.hip", "hare_amd/csrc/octree_pool.hip",
-                  "hare_amd/csrc/octree_coop.hip", "hare_amd/csrc/octree_group.hip", "hare_amd/csrc/hare_math.h",
+                  "hare_amd/csrc/octree_coop.hip", "hare_amd/csrc/octree_group.hip", "hare_amd/csrc/kdtree_dense.hip", "hare_amd/csrc/order_kernels.hip", "hare_amd/csrc/hare_math.h",
                   "hare_amd/csrc/hare_trace.h", "hare_amd/csrc/hare_device.h")
 
 

@@ -103,6 +103,9 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_group_tail", &m->octree_group_tail},
         {"hare_octree_dense", &m->octree_dense},
         {"hare_kdtree_shoot", &m->kdtree},
+        {"hare_cost_order", &m->cost_order},
+        {"hare_kdtree_dense", &m->kdtree_dense},
+        {"hare_kdtree_dense_own", &m->kdtree_dense_own},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
         {"hare_occlusion", &m->occlusion},
@@ -569,8 +572,10 @@ void read_env_options(SceneOptions& o)
     if (const char* k = getenv("HARE_VOXEL_KERNEL")) o.voxel_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : 0);
     if (const char* k = getenv("HARE_OCTREE_KERNEL")) o.octree_kernel = strcmp(k, "persist") == 0 ? 1 : (strcmp(k, "pool") == 0 ? 2 : (strcmp(k, "group") == 0 ? 3 : (strcmp(k, "dense") == 0 ? 4 : 0)));
     if (const char* t = getenv("HARE_OCTREE_TAIL")) o.octree_tail = atoi(t);
+    if (const char* k = getenv("HARE_KDTREE_KERNEL")) o.kdtree_kernel = strcmp(k, "simple") == 0 ? 1 : (strcmp(k, "dense") == 0 ? 2 : 0);
     if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_TIGHT")) o.voxel_tight = atoi(t) != 0;
+    if (const char* t = getenv("HARE_VOXEL_ORDER")) o.voxel_order = std::max(0, std::min(2, atoi(t)));
     if (const char* t = getenv("HARE_VOXEL_TIGHT_MAX_MB")) o.voxel_tight_max_mb = std::max(0, atoi(t));
     if (const char* t = getenv("HARE_FAIL_CELLBOX_ALLOC")) o.dev_fail_cellbox_alloc = atoi(t) != 0;
     if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
@@ -633,7 +638,7 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 //    occupancy bit per voxel, three on a coarser bitmap (round 2, before the cooperative tails: three fills everywhere).
 // Both thresholds scale with the CU count of the device the scene lives on.
 enum class Kern { VoxelSimple, VoxelCount, VoxelAudit, VoxelProf, VoxelPool, VoxelPersist, VoxelOccl, OctSimple, OctCount, OctPool, OctPersist, OctDense, OctGroup, OctOccl,
-                  KdSimple, KdCount, None };
+                  KdSimple, KdCount, KdDense, None };
 struct KernChoice {
     Kern k = Kern::None;
     const char* name = "";
@@ -772,9 +777,20 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         return c;
     }
     if (kind == HARE_KIND_KDTREE) {
-        if (count) pick(Kern::KdCount, "hare_kdtree_shoot_count", &DeviceModule::kdtree_count);
-        else if (own) return c;                      // (no counting build of the one-ray-per-lane kd kernel)
-        else pick(Kern::KdSimple, "hare_kdtree_shoot", &DeviceModule::kdtree);
+        if (count) { pick(Kern::KdCount, "hare_kdtree_shoot_count", &DeviceModule::kdtree_count); return c; }
+        // K3d (hare_kdtree_dense, kdtree_dense.hip): persistent waves, one-line node records with both children's tight boxes, leaves pre-culled
+        // densely, exact tests deferred -- the production kernel of KDTree.Shoot since round 5 wherever its node records exist for the
+        // topology and its stack fits LDS (any depth hare_kdtree_build allows does); the one-ray-per-lane kernel (kdtree_kernel = 1) is the
+        // A/B baseline, the fall-back, and what the flags-only occlusion predicate runs
+        const bool dense_ok = !simple && !huge && !flags_only && s.opt.kdtree_kernel != 1 && top < s.d_kd_dev.size() && s.d_kd_dev[top] != nullptr &&
+                              kd_dense_lds(s.kd.depth_reached) <= kLdsMax && have(&DeviceModule::kdtree_dense);
+        if (dense_ok) {
+            pick(Kern::KdDense, "hare_kdtree_dense", &DeviceModule::kdtree_dense);
+            if (own) pick(Kern::KdDense, "hare_kdtree_dense_own", &DeviceModule::kdtree_dense_own);
+            return c;
+        }
+        if (own) return c;                           // (no counting build of the one-ray-per-lane kd kernel)
+        pick(Kern::KdSimple, "hare_kdtree_shoot", &DeviceModule::kdtree);
     }
     return c;
 }
@@ -1092,6 +1108,32 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (s.opt.k1p_static_rays > 0) io.static_rays = std::max(8, std::min(1024, s.opt.k1p_static_rays / 8 * 8));   // developer sweeps (tools/k1q_ticket_sweep.py)
             io.ticket_rays = ticket_rays_for(s, n, true);
             if (s.opt.dev && s.opt.dev_order_ptr) io.order = (const uint32_t*)(uintptr_t)s.opt.dev_order_ptr;
+            // The order in which K1q takes the rays (order_kernels.hip): inside every window of 4 096 consecutive rays, by an estimate of
+            // the walk length -- a pool of rays of similar cost wastes fewer lane-steps (C4 shard -6.8 %, C2 -5.3 % of the kernel's time with
+            // the order given; window_sort_*.log), the batch's own locality stays.  Rule ("voxel_order" 1, the default): batches of PRIMARY
+            // rays -- no exclusion arrays, not a cast of the bounce loop: reflected rays gain nothing and pay for the indirection
+            // (+5 ... +8 %, window_sort_cathedral_bounce5.log) -- from 262 144 rays, where the pass (~10 us per million rays) is a few per
+            // cent of the cast.  The scratch is stream-ordered (hipMallocAsync / hipFreeAsync): no host synchronisation, nothing kept.
+            const bool order_rule = s.opt.voxel_order == 2 || (s.opt.voxel_order == 1 && !d_e1 && !d_e2 && !(flags & SHOOT_RETIRED_RAYS) && n >= 262144);
+            if (!io.order && order_rule && M.cost_order && H->MallocAsync && H->FreeAsync && n <= 0x7FFFFF00ll && (flags & 0xF000u) == 0) {
+                void* d_order = nullptr;
+                if (H->MallocAsync(&d_order, (size_t)n * sizeof(uint32_t), st) == hipSuccess && d_order) {
+                    const void* rp = d_rays;
+                    long long nn = n;
+                    float o0[3], o1[3], iv[3];
+                    for (int a = 0; a < 3; ++a) { o0[a] = (float)s.vox.omin[a]; o1[a] = (float)s.vox.omax[a]; iv[a] = (float)(1.0 / s.vox.vd[a]); }
+                    float bpv = (float)kOrderBins / (3.0f * (float)std::max(1, s.vox.ct));
+                    void* oargs[] = {&rp, &nn, &o0[0], &o0[1], &o0[2], &o1[0], &o1[1], &o1[2], &iv[0], &iv[1], &iv[2], &bpv, &d_order};
+                    int rc = launch(H, M.cost_order, (unsigned)((n + kOrderWindow - 1) / kOrderWindow), (unsigned)kOrderThreads, 0, st, oargs);
+                    if (rc == HARE_OK) {
+                        io.order = (const uint32_t*)d_order;
+                        rc = launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
+                    }
+                    (void)H->FreeAsync(d_order, st);          // stream-ordered: released when the cast has run
+                    return rc;
+                }
+                (void)H->GetLastError();                       // no scratch: the cast runs in the caller's order
+            }
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }
         // persistent kernel K1p: a grid that just fills the chip; waves draw ray chunks from a ticket
@@ -1293,11 +1335,28 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             for (int a = 0; a < 3; ++a) g.tight_mid[a] = s.kd_tight_mid[a];
             g.tight_rad = s.kd_tight_rad;
         }
-        hipFunction_t f = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only).f;
+        const KernChoice kkc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
+        hipFunction_t f = kkc.f;
         if (!f && (flags & HARE_SHOOT_COUNT_OWN)) return no_own_build();
         if (!f) {
             set_error("hare_shoot: kd-tree kernel missing from code object");
             return HARE_E_STATE;
+        }
+        if (kkc.k == Kern::KdDense) {
+            // K3d: a grid that just fills the chip (what its LDS -- (depth + 2) stack entries of 8 bytes per lane -- allows per CU, at most
+            // HARE_K3D_WAVES_PER_EU workgroups); static first chunk and tickets as K2d
+            g.dnodes = (const KdDevNode*)s.d_kd_dev[(size_t)top];
+            const unsigned klds = kd_dense_lds(g.max_depth);
+            unsigned per_cu = std::min((unsigned)HARE_K3D_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / klds)));
+            unsigned pgrid = cus * per_cu;
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((n + 63) / 64 + 3) / 4);
+            if (pgrid == 0) pgrid = 1;
+            io.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : 16;
+            io.static_rays = static_chunk_rays(n, pgrid, true, true);
+            if (s.opt.k2p_static_rays > 0) io.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
+            if ((flags & 0x2000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline
+            void* kargs[] = {&g, &io};
+            return launch_on_slot(s, H, f, pgrid, 256, klds, st, io, kargs);
         }
         // node stack in LDS: at most depth + 2 entries per lane
         const unsigned slots = (unsigned)g.max_depth + 2;
@@ -1454,6 +1513,7 @@ void hare_scene_destroy(hare_scene* s)
             dev_free(H, *p);
         for (void*& p : s->d_oct_tight) dev_free(H, p);
         for (void*& p : s->d_kd_tight) dev_free(H, p);
+        for (void*& p : s->d_kd_dev) dev_free(H, p);
         free_bounce_buffers(H, *s);
         for (Scene::BatchCtx& c : s->ctx) {
             for (hipStream_t& x : c.st)
@@ -1601,6 +1661,65 @@ static int upload_tight_boxes(hare_scene* s, const HipApi* H, const Tree& tree, 
     rad = 1024.0 * ext;
     return HARE_OK;
 }
+
+// hare_kdtree_dense's node records (KdDevNode, hare_device.h), per topology a query may name: the host tree's node with the tight boxes
+// of BOTH its children's subtrees inlined (the same boxes upload_tight_boxes sends: same margin, same outward rounding) and the mark of a
+// child whose subtree lists no polygon.  A topology for which the boxes cannot be made (a tree not laid out parent-before-children)
+// gets no records and is served by the one-ray-per-lane kernel.
+static int upload_kd_dev_nodes(hare_scene* s, const HipApi* H)
+{
+    for (void*& p : s->d_kd_dev) dev_free(H, p);
+    s->d_kd_dev.assign(s->topos.size(), nullptr);
+    if (s->topos.empty() || s->kd.nodes.empty() || !(s->kd_tight_rad > 0)) return HARE_OK;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = s->topos[0].mn[a]; hi[a] = s->topos[0].mx[a]; }
+    for (const Topo& T : s->topos)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], T.mn[a]); hi[a] = std::max(hi[a], T.mx[a]); }
+    double ext = 0, mag = 0;
+    for (int a = 0; a < 3; ++a) {
+        ext = std::max(ext, hi[a] - lo[a]);
+        mag = std::max(mag, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+    }
+    const double delta = std::ldexp(std::max(ext, mag), -20);              // as upload_tight_boxes
+    const size_t n = s->kd.nodes.size();
+    // subtrees without a polygon (a fact of the tree: the same for every topology)
+    std::vector<unsigned char> has(n, 0);
+    for (size_t k = n; k-- > 0;) {
+        const KdNodeRec& nd = s->kd.nodes[k];
+        if (nd.left < 0 && nd.right < 0) has[k] = nd.item_count > 0;
+        else {
+            if (nd.left < 0 || nd.right < 0 || (size_t)nd.left <= k || (size_t)nd.right <= k || (size_t)nd.left >= n || (size_t)nd.right >= n) return HARE_OK;
+            has[k] = has[(size_t)nd.left] | has[(size_t)nd.right];
+        }
+    }
+    for (size_t m = 0; m < s->topos.size(); ++m) {
+        if (s->kd.id_count > s->topos[m].P || m >= s->d_kd_tight.size() || !s->d_kd_tight[m]) continue;
+        std::vector<float> tb;
+        make_tight_boxes(s->kd, s->topos[m], delta, tb);
+        if (tb.size() != n * 8) continue;
+        std::vector<KdDevNode> dev(n);
+        for (size_t k = 0; k < n; ++k) {
+            const KdNodeRec& nd = s->kd.nodes[k];
+            KdDevNode& o = dev[k];
+            memset(&o, 0, sizeof o);
+            const bool leaf = nd.left < 0 && nd.right < 0;
+            o.split = nd.split;
+            o.axis = leaf ? -1 : nd.axis;
+            o.left = nd.left;
+            o.right = nd.right;
+            o.item_start = nd.item_start;
+            o.item_count = nd.item_count;
+            if (!leaf) {
+                const int a = nd.axis, b = (a == 0) ? 1 : 0, c = (a == 2) ? 1 : 2;          // KDTree.cs:249-353: the two other axes, ascending
+                o.bb[0] = nd.bmin[b]; o.bb[1] = nd.bmax[b]; o.bb[2] = nd.bmin[c]; o.bb[3] = nd.bmax[c];
+                for (int j = 0; j < 6; ++j) { o.tl[j] = tb[(size_t)nd.left * 8 + j]; o.tr[j] = tb[(size_t)nd.right * 8 + j]; }
+                o.empty = (has[(size_t)nd.left] ? 0 : 1) | (has[(size_t)nd.right] ? 0 : 2);
+            }
+        }
+        if (int rc = upload(H, &s->d_kd_dev[m], dev.data(), dev.size() * sizeof(KdDevNode))) return rc;
+    }
+    return HARE_OK;
+}
 }  // extern "C++"
 
 // After a host build: push the partition to the device when one is available.  Builds succeed
@@ -1661,6 +1780,8 @@ static int sync_partition_to_device(hare_scene* s, int kind)
     rc = upload(H, &s->d_kd_nodes, s->kd.nodes.data(), s->kd.nodes.size() * sizeof(KdNodeRec));
     if (rc) return rc;
     rc = upload_tight_boxes(s, H, s->kd, s->kd.id_count, s->d_kd_tight, s->kd_tight_mid, s->kd_tight_rad);
+    if (rc) return rc;
+    rc = upload_kd_dev_nodes(s, H);
     if (rc) return rc;
     return upload(H, &s->d_kd_items, s->kd.items.data(), s->kd.items.size() * sizeof(int32_t));
 }
@@ -2329,8 +2450,10 @@ const OptionEntry kOptionTable[] = {
         {"voxel_kernel", &SceneOptions::voxel_kernel, 0, 2},
         {"octree_kernel", &SceneOptions::octree_kernel, 0, 4},
         {"octree_tail", &SceneOptions::octree_tail, 0, 2},
+        {"kdtree_kernel", &SceneOptions::kdtree_kernel, 0, 2},
         {"octree_tight", &SceneOptions::octree_tight, 0, 1},
         {"voxel_tight", &SceneOptions::voxel_tight, 0, 1},
+        {"voxel_order", &SceneOptions::voxel_order, 0, 2},
         {"voxel_tight_max_mb", &SceneOptions::voxel_tight_max_mb, 0, 1 << 30},
         {"dev_fail_cellbox_alloc", &SceneOptions::dev_fail_cellbox_alloc, 0, 1},
         {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},

@@ -195,6 +195,35 @@ struct KdNodeRec {             // 80 bytes
     int32_t pad;
 };
 
+// hare_cost_order (order_kernels.hip): window of consecutive rays that is ordered, bins of the counting sort, threads per window
+constexpr int kOrderWindow = 4096;
+constexpr int kOrderBins = 512;
+constexpr int kOrderThreads = 1024;
+
+// K3d (hare_kdtree_dense, kdtree_dense.hip): the device copy of a kd-tree node, ONE 128-byte cache line, per topology (api.cpp: make_kd_dev_nodes).
+// What a visit needs and nothing else: the split, the node's box on the two axes that are NOT the split axis (what KDTree.cs:249-353 compares
+// the crossing point with; ascending axis order), the children, a leaf's list -- and the tight boxes of BOTH children's subtrees
+// ({x0,y0,z0,x1,y1,z1}, as make_tight_boxes rounds them: outwards), so that the visit decides for both children whether to push them.
+struct KdDevNode {
+    double split;
+    double bb[4];              // {min_b, max_b, min_c, max_c}: axis 0 -> (y, z), 1 -> (x, z), 2 -> (x, y)
+    int32_t axis;              // 0, 1, 2; -1: a leaf
+    int32_t left, right;
+    int32_t item_start, item_count;
+    int32_t empty;             // bit 0 / 1: the left / right child's subtree lists no polygon at all (never pushed: popping it has no effect)
+    float tl[6], tr[6];        // tight boxes of the left / right child's subtree
+    int32_t pad[4];
+};
+static_assert(sizeof(KdDevNode) == 128, "kd device node: one cache line");
+#ifndef HARE_K3D_PEND
+#define HARE_K3D_PEND 4            // survivors a lane may hold before it waits for the exact phase
+#endif
+#ifndef HARE_K3D_WAVES_PER_EU
+#define HARE_K3D_WAVES_PER_EU 4
+#endif
+// dynamic LDS of a 256-lane workgroup of K3d: (depth + 2) stack entries of 8 bytes per lane, the pending survivors, a 64-word table per wave
+constexpr unsigned kd_dense_lds(int max_depth) { return (unsigned)(max_depth + 2) * 256u * 8u + 256u * 4u * (unsigned)HARE_K3D_PEND + 4u * 64u * 4u; }
+
 struct KdArgs {
     const PolyRec* polys;
     const QuadRec* quads;
@@ -207,6 +236,7 @@ struct KdArgs {
     const float* tight;        // as in OctreeArgs: per node the box of the polygons its subtree lists (device kernels; null on the host)
     double tight_mid[3];
     double tight_rad;
+    const KdDevNode* dnodes;   // hare_kdtree_dense: the one-line node records of this topology (null: the kernel is not used)
 };
 
 struct BuildArgs {             // Voxel_Grid construction kernels (build_kernels.hip)

@@ -1788,4 +1788,6 @@ __global__ __launch_bounds__(256) void hare_occlusion(const XEventRec* ev, const
 extern "C" __global__ __launch_bounds__(256, HARE_K2G_WAVES_PER_EU) void hare_octree_group(hare::OctreeArgs g, hare::ShootIO io) { octree_group_body<false>(g, io); }
 // K2g as the tail of K2p: the rays K2p's waves were still walking when the tickets ran dry, continued from their walk state
 extern "C" __global__ __launch_bounds__(256, HARE_K2G_WAVES_PER_EU) void hare_octree_group_tail(hare::OctreeArgs g, hare::ShootIO io) { octree_group_body<true>(g, io); }
+#include "kdtree_dense.hip"
+#include "order_kernels.hip"
 #include "build_kernels.hip"

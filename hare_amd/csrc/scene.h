@@ -41,9 +41,12 @@ struct SceneOptions {
     int bounce_fused = 0;      // 1: the bounce loop of a Voxel_Grid runs as ONE launch where the pool kernel serves (hare_voxel_bounce_*); 0 (default): a launch
                                // per cast -- measured: the hall +2.5 %, the cathedral -0 ... -10 % (a chip that works on all casts at once loses the L2 locality of one band)
     int voxel_tight = 1;       // 1: K1q sends a ray on past an occupied voxel whose polygons it cannot hit (the voxels' tight boxes, api.cpp: upload_cell_boxes); 0: every list the reference scans (A/B)
+    int voxel_order = 1;       // the pool kernel takes a batch's rays, window by window, in the order of their estimated walk length (order_kernels.hip):
+                               // 1 (default) batches of primary rays from 262 144 rays, 0 never, 2 every batch.  Results never depend on it
     int voxel_tight_max_mb = 0; // budget for those boxes (32 B per voxel and topology), MiB; 0 = none.  Over budget or out of memory: no boxes, same results
     int dev_fail_cellbox_alloc = 0;   // test hook: the boxes' allocation "fails" (tests/test_gpu_tight.py: a build must still succeed)
     int octree_tight = 1;      // 1: K2d / K2p skip a popped node whose subtree's polygons the ray cannot hit (the tight boxes of api.cpp); 0: every node the reference visits (A/B)
+    int kdtree_kernel = 0;     // 0 = the library's rule (K3d, hare_kdtree_dense, wherever its node records exist and its LDS fits), 1 = the one-ray-per-lane kernel, 2 = K3d
     int octree_tail = 2;       // what finishes the rays K2p gives up: 0 nothing (every lane finishes its own), 1 K2t (a wave per ray, a wave's last 16), 2 K2g-tail (eight lanes per ray, all of them)
     int k2p_tail_max = 0;      // developer sweeps: hand over once at most this many rays are alive in a wave (0 = the rule) ...
     int k2p_tail_patience = -1; // ... after this many rounds (-1 = the rule)
@@ -100,6 +103,8 @@ struct DeviceModule {
     // counting builds of the production kernels (HARE_SHOOT_COUNT_OWN)
     hipFunction_t voxel_pool_tri_own = nullptr, voxel_pool_quad_own = nullptr, voxel_pool_tri_g_own = nullptr, voxel_pool_quad_g_own = nullptr;
     hipFunction_t octree_dense_own = nullptr;
+    hipFunction_t cost_order = nullptr;                                    // order_kernels.hip
+    hipFunction_t kdtree_dense = nullptr, kdtree_dense_own = nullptr;      // K3d (kdtree_dense.hip) and its counting build
     hipFunction_t voxel_bounce_tri = nullptr, voxel_bounce_quad = nullptr, voxel_bounce_tri_g = nullptr, voxel_bounce_quad_g = nullptr, counters_sum = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr, octree_group = nullptr, octree_group_tail = nullptr, octree_dense = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
@@ -166,6 +171,7 @@ struct Scene {
     double oct_tight_mid[3] = {0, 0, 0}, oct_tight_rad = -1;      // ray origins the boxes may be used for: |o - mid|_inf <= rad
     void* d_kd_nodes = nullptr;
     std::vector<void*> d_kd_tight;    // as d_oct_tight, for the kd-tree's nodes
+    std::vector<void*> d_kd_dev;      // per topology: the one-line node records of hare_kdtree_dense (KdDevNode; api.cpp: upload_kd_dev_nodes); null = none
     double kd_tight_mid[3] = {0, 0, 0}, kd_tight_rad = -1;
     void* d_kd_items = nullptr;
     void* d_work = nullptr;                      // LaunchSlotMem[kLaunchSlots]: scratch of the persistent launches in flight

@@ -186,6 +186,8 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "octree_tail"     what finishes the rays K2p's waves still walk at the end of a launch: 2 (default) hare_octree_group_tail (eight lanes per
  *                     ray, every ray a wave holds 32 rounds after its tickets ran dry), 1 hare_octree_tail (a wave per ray, a wave's last 16), 0 nothing
  *   "k2p_tail_max", "k2p_tail_patience"   the hand-over rule (0 / -1: the library's)
+ *   "kdtree_kernel"   0 the library's rule (hare_kdtree_dense: persistent waves, one-line node records with both children's tight boxes,
+ *                     leaves pre-culled densely, exact tests deferred), 1 hare_kdtree_shoot (one ray per lane: A/B baseline), 2 hare_kdtree_dense
  *   "ticket_rays", "k1p_static_rays" (both voxel kernels), "k2p_static_rays", "batch_chunks"   0: the library's rule, else the value
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
  *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per
@@ -196,6 +198,9 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "voxel_tight"     the same per voxel: a ray without a hit walks on past an occupied voxel whose polygons it cannot hit; 1 (default) / 0.
  *                     The boxes cost 32 B per voxel and topology and exist only while this is on and the pool kernel serves the grid (up to
  *                     512 voxels a side); switching it on later builds them then
+ *   "voxel_order"     1 (default): the pool kernel takes the rays of a batch of primary rays (no exclusion arrays, from 262 144 rays), window by
+ *                     window of 4 096, in the order of their estimated walk length -- a wave's rays then cost about the same; 0 never, 2 every
+ *                     batch.  Rays and events stay where the caller has them; results never depend on it
  *   "voxel_tight_max_mb"  budget for those boxes in MiB (0, the default: none).  Over budget -- or out of device memory -- the grid is
  *                     built and traced without them: never an error, never a different result
  *   "dev"             1: developer flag bits of hare_shoot_* (timeline, phase profile, cull audit) pass

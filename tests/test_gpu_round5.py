@@ -1,0 +1,173 @@
+"""Round 5 on the GPU: K3d `hare_kdtree_dense` (kdtree_dense.hip) -- KDTree.Shoot (KDTree.cs:198-361) as a production kernel: persistent
+waves, one-line node records with both children's tight boxes, leaves pre-culled densely, exact tests deferred and made in the reference's
+visiting order.  Every case compares all eight X_Event fields with the oracle, with K3d and with the one-ray-per-lane kernel it replaces
+(`kdtree_kernel` 2 / 1): ties (where the visiting ORDER decides the polygon), trees from a single leaf to 26 levels, one polygon per leaf,
+exclusions, degenerate and far rays, two topologies, batches of 1 ray ... 300k, the bounce loop cast by cast, and the counting build."""
+import numpy as np
+import pytest
+import torch
+
+import hare_amd as H
+from hare_amd import capi
+from oracle import pyoracle as po
+from tests.helpers import assert_events_equal, oracle_bounce_loop, soup, soup_rays
+from tests.test_gpu_ties import tie_rays, tie_scene
+
+pytestmark = pytest.mark.gpu
+KERNELS = ((2, "hare_kdtree_dense"), (1, "hare_kdtree_shoot"))
+
+
+def both(kd, ko, rays, what, top=0, **kw):
+    okw = {("excl1" if k == "poly_origin1" else "excl2"): v for k, v in kw.items()}
+    ref, rc = ko.shoot(rays, top_index=top, **okw)
+    for kern, name in KERNELS:
+        kd.set_option("kdtree_kernel", kern)
+        assert kd.kernel_name(len(rays), top) == name
+        ev, c = kd.Shoot_batch(rays, top_index=top, **kw)
+        assert_events_equal(ev, ref, what=f"{what} {name}")
+        assert c["hits"] == rc["hits"] and c["rays"] == len(rays)
+    kd.set_option("kdtree_kernel", 0)
+    return ref
+
+
+def test_k3d_is_the_default_and_ties_go_to_the_polygon_the_reference_meets_first():
+    v, nv, size = tie_scene()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = tie_rays(v, nv, size, n=6000)
+    for depth, maxp in ((7, 6), (10, 1), (3, 40)):
+        kd, ko = H.KDTree([T], depth, maxp), po.KDTree([To], depth, maxp)
+        assert kd.kernel_name(len(rays)) == "hare_kdtree_dense"                 # the library's rule
+        ref = both(kd, ko, rays, f"ties {depth}/{maxp}")
+        both(kd, ko, rays, f"ties {depth}/{maxp} excl", poly_origin1=ref["poly_id"].astype(np.int32))
+        e2 = np.roll(ref["poly_id"], 1).astype(np.int32)
+        both(kd, ko, rays, f"ties {depth}/{maxp} excl x2", poly_origin1=ref["poly_id"].astype(np.int32), poly_origin2=e2)
+
+
+def test_k3d_tree_shapes_from_one_leaf_to_20_levels():
+    """maxDepth 0 (the root is the only leaf) ... 20 with one polygon per leaf (lists double where polygons straddle a split: 1.8M nodes at 20
+    levels; the stack is depth + 2 entries per lane in LDS, 49 KB per workgroup there)."""
+    v, nv, size = soup(n_tri=150, n_quad=50, seed=17)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = soup_rays(9000, size, seed=3)
+    rays[::7, 3] = 0.0; rays[1::7, 4] = -0.0; rays[2::7, 5] = 1e-17; rays[3::49, 3:] *= 1e-200; rays[4::49, 3:] *= 1e200; rays[5::49, 0] = np.nan
+    for depth, maxp in ((0, 4), (1, 1), (5, 8), (14, 2), (20, 1)):
+        try:
+            ko = po.KDTree([To], depth, maxp)
+        except MemoryError:
+            continue                                                            # the oracle's budget: lists that double per level
+        kd = H.KDTree([T], depth, maxp)
+        assert kd.info().n_nodes == ko.n_nodes
+        # the oracle visits EVERY leaf for every ray (F4): on a big tree it gets fewer rays
+        m = len(rays) if ko.n_nodes < 3000 else max(300, min(len(rays), 40_000_000 // ko.n_nodes))
+        both(kd, ko, rays[:m], f"shape {depth}/{maxp} ({ko.n_nodes} nodes, {m} rays)")
+
+
+def test_k3d_far_origins_two_topologies_and_boxes_off():
+    v, nv, size = soup(n_tri=700, n_quad=300, seed=21)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rng = np.random.default_rng(8)
+    n = 4000
+    tgt = rng.uniform(0.1, 0.9, (n, 3)) * np.asarray(size)
+    u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    far = np.concatenate([tgt - u * (6.0 * 10.0 ** rng.integers(1, 10, n).astype(np.float64))[:, None], u * 2.0 ** rng.integers(-30, 30, n)[:, None]], 1)
+    rays = np.ascontiguousarray(np.concatenate([soup_rays(6000, size, seed=12), far]))
+    kd, ko = H.KDTree([T], 9, 4), po.KDTree([To], 9, 4)
+    both(kd, ko, rays, "far origins")
+    kd.set_option("octree_tight", 0)                      # no box test at all: every node is visited, as the reference does
+    both(kd, ko, rays, "far origins, boxes off")
+    kd.set_option("octree_tight", 1)
+    v1, n1, _ = soup(n_tri=300, n_quad=80, seed=9, size=(5.0, 4.5, 3.5))
+    v0, n0, size0 = soup()
+    kd2, ko2 = H.KDTree([H.Topology(v0, n0), H.Topology(v1, n1)], 6, 8), po.KDTree([po.Topology(v0, n0), po.Topology(v1, n1)], 6, 8)
+    for top in (0, 1):
+        both(kd2, ko2, soup_rays(5000, size0), f"two topologies top {top}", top=top)
+
+
+def test_k3d_batches_of_every_size_and_many_launches_in_flight():
+    m = H.scenes.shoebox()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    kd, ko = H.KDTree([T], 12, 16), po.KDTree([To], 12, 16)
+    rays = H.scenes.random_rays(300_000, m.size)
+    ref, _ = ko.shoot(rays, nthreads=16)
+    for n in (1, 2, 63, 64, 65, 255, 4097, 65536, 196_609, 300_000):
+        ev, c = kd.Shoot_batch(rays[:n])
+        assert_events_equal(ev, ref[:n], what=f"n={n}")
+        assert c["rays"] == n
+    # 200 launches over four streams without a host synchronisation (the launch-slot ring comes round three times)
+    d_rays = torch.from_numpy(rays[:20_000].copy()).cuda()
+    outs = [torch.empty(20_000 * 56, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    for k in range(200):
+        kd.shoot_device(20_000, d_rays.data_ptr(), outs[k % 4].data_ptr(), stream=streams[k % 4].cuda_stream)
+    torch.cuda.synchronize()
+    for o in outs:
+        got = np.frombuffer(o.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE)
+        assert_events_equal(got, ref[:20_000], what="launches in flight")
+
+
+def test_k3d_in_the_bounce_loop_and_its_counting_build():
+    """hare_bounce_batch over a KDTree runs a launch per cast with the retired rays skipped (flag HARE_SHOOT_RETIRED_RAYS): every cast against
+    the oracle's loop, in an open soup where rays die.  Then HARE_SHOOT_COUNT_OWN: the counting build returns the same events and counters
+    that make sense (every ray fetches at least the root, pre-culls >= exact tests)."""
+    v, nv, size = soup(n_tri=500, n_quad=150, seed=33)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    kd, ko = H.KDTree([T], 8, 6), po.KDTree([To], 8, 6)
+    rays = soup_rays(30_000, size, seed=2)
+    ref_all, _ = oracle_bounce_loop(po, To, ko, rays, 5)
+    for kern, name in KERNELS:
+        kd.set_option("kdtree_kernel", kern)
+        ev_all, ctr = kd.Bounce_batch(rays, 5, all_casts=True)
+        for b in range(5):
+            assert_events_equal(ev_all[b], ref_all[b], what=f"bounce cast {b} {name}")
+    kd.set_option("kdtree_kernel", 0)
+    n = len(rays)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+    assert kd.kernel_name(n, flags=capi.SHOOT_COUNT_OWN) == "hare_kdtree_dense_own"
+    kd.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(), flags=capi.SHOOT_COUNT_OWN)
+    torch.cuda.synchronize()
+    got = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=capi.XEVENT_DTYPE)
+    assert_events_equal(got, ref_all[0], what="counting build")
+    c = [int(x) for x in d_ctr.cpu()]
+    assert c[0] == n and c[1] == int(ref_all[0]["hit"].sum())
+    assert c[2] > 0 and c[3] == c[5] and c[5] >= c[4] > 0                # nodes fetched, entries == pre-culls >= exact tests
+    _, ref_ctr = ko.shoot(rays)
+    assert c[2] < ref_ctr["cells"] and c[4] < ref_ctr["tests"]           # ... and far fewer than the reference's visit of every leaf
+    kd.set_option("kdtree_kernel", 1)
+    with pytest.raises(H.HareError) as e:                                 # the one-ray-per-lane kernel has no counting build: the call says so
+        kd.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(), flags=capi.SHOOT_COUNT_OWN)
+    assert e.value.code == capi.HARE_E_UNSUPPORTED
+
+
+def test_the_cost_order_of_the_pool_kernel_changes_no_event():
+    """order_kernels.hip: K1q takes the rays of a batch, window by window of 4 096, in the order of their estimated walk length
+    (`voxel_order`: 1 = batches of primary rays from 262 144 rays, 0 never, 2 every batch).  Rays, events and exclusions stay in the
+    caller's order and every X_Event is the oracle's: batch sizes around the windows, origins outside the grid with the origin write-back,
+    exclusion arrays (forced: the rule leaves such batches alone), NaN / zero / huge direction components, a coarse bitmap."""
+    v, nv, size = soup(n_tri=900, n_quad=200, seed=41)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = soup_rays(300_000, size, seed=6)
+    rays[::11, 3] = 0.0; rays[1::11, 4] = -0.0; rays[2::13, 5] = 1e-300; rays[3::97, 3:] *= 1e200; rays[5::101, 0] = np.nan; rays[7::103, 3] = np.inf
+    for D in (24, 96):
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        ref, rc = o.shoot(rays, nthreads=16)
+        refm, _, moved = o.shoot(rays, nthreads=16, mutate=True)
+        for n in (1, 4095, 4096, 4097, 262_143, 262_144, 300_000):
+            for order in (2, 1, 0):
+                g.set_option("voxel_order", order)
+                ev, c = g.Shoot_batch(rays[:n])
+                assert_events_equal(ev, ref[:n], what=f"D={D} n={n} order={order}")
+                assert c["rays"] == n
+        e1 = ref["poly_id"].astype(np.int32)
+        e2 = np.roll(e1, 3)
+        ref2, _ = o.shoot(rays, excl1=e1, excl2=e2, nthreads=16)
+        for order in (2, 0):
+            g.set_option("voxel_order", order)
+            assert_events_equal(g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], ref2, what=f"D={D} excl order={order}")
+            r = rays.copy()
+            ev, _ = g.Shoot_batch(r, writeback_origin=True)
+            assert_events_equal(ev, refm, what=f"D={D} write-back order={order}")
+            assert np.array_equal(r.view(np.int64), moved.view(np.int64))
+        g.set_option("voxel_order", 1)

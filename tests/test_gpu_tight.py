@@ -141,12 +141,16 @@ def test_kdtree_with_and_without_the_boxes():
     def check(kd, ko, rays, what, top=0, **kw):
         okw = {("excl1" if k == "poly_origin1" else "excl2"): v for k, v in kw.items()}
         ref, rc = ko.shoot(rays, top_index=top, **okw)
-        for tight in (1, 0):
-            kd.set_option("octree_tight", tight)
-            ev, c = kd.Shoot_batch(rays, top_index=top, **kw)
-            assert_events_equal(ev, ref, what=f"kd {what} tight={tight}")
-            assert c["hits"] == rc["hits"]
+        for kern, kname in ((2, "hare_kdtree_dense"), (1, "hare_kdtree_shoot")):      # K3d (round 5) and the one-ray-per-lane kernel
+            kd.set_option("kdtree_kernel", kern)
+            assert kd.kernel_name(len(rays), top) == kname
+            for tight in (1, 0):
+                kd.set_option("octree_tight", tight)
+                ev, c = kd.Shoot_batch(rays, top_index=top, **kw)
+                assert_events_equal(ev, ref, what=f"kd {what} {kname} tight={tight}")
+                assert c["hits"] == rc["hits"]
         kd.set_option("octree_tight", 1)
+        kd.set_option("kdtree_kernel", 0)
         return ref
 
     v, nv, size = tie_scene()
@@ -182,9 +186,11 @@ def test_kdtree_with_and_without_the_boxes():
     rays = H.scenes.burst_rays(1 << 20, m.size)[::512]              # 2 048 rays: the oracle's query is 100k polygons per ray
     kd, ko = H.KDTree([H.Topology(m.verts, m.nverts)], 16, 8), po.KDTree([po.Topology(m.verts, m.nverts)], 16, 8)
     ref, rc = ko.shoot(rays, nthreads=32)
-    ev, c = kd.Shoot_batch(rays)
-    assert_events_equal(ev, ref, what="kd hall")
-    assert c["hits"] == rc["hits"] == len(rays)
+    for kern in (2, 1):
+        kd.set_option("kdtree_kernel", kern)
+        ev, c = kd.Shoot_batch(rays)
+        assert_events_equal(ev, ref, what=f"kd hall kernel {kern}")
+        assert c["hits"] == rc["hits"] == len(rays)
 
 
 # ---------------------------------------------------------------------------------------------------------------- Voxel_Grid
