@@ -238,9 +238,9 @@ void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<Qua
         r.emax = up(emax);
         r.ee = up(n1 * (double)r.emax);
         if (T.nverts[p] == 4) {
-            r.emax = INFINITY;                  // quadrilaterals are never pre-culled:
-            r.ee = INFINITY;
-            r.e1f[0] = NAN;                     // with a NaN edge every comparison of cull_fp32 fails
+            r.emax = INFINITY;                  // the record HEAD of a quadrilateral says "never cull" (tools, the 48-byte A/B layout):
+            r.ee = INFINITY;                    // the dense pre-cull records are built from the corners and cull both its triangles
+            r.e1f[0] = NAN;                     // (make_cull_records; round 5)
             for (int a = 0; a < 3; ++a) quads[p].v3[a] = V[9 + a];
         }
         if (T.has_quads) quads[p].nverts = T.nverts[p];
@@ -250,8 +250,9 @@ void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<Qua
 // The pre-cull's dense records of one topology (hare_device.h, HARE_CULL32) and the frame that decodes them.
 void make_cull_records(const Topo& T, const std::vector<PolyRec>& rec, std::vector<unsigned char>& dense, CullFrame& cf)
 {
-    dense.assign(rec.size() * (size_t)kCullStride, 0);
     memset(&cf, 0, sizeof cf);
+    cf.stride = (HARE_CULL32 && T.has_quads) ? 48 : kCullStride;
+    dense.assign(rec.size() * (size_t)cf.stride, 0);
 #if HARE_CULL32
     // the quantisation box: the polygons' own v0 range (inside Topology.Min / Max; taken from the records so that a caller's
     // stale bounds cannot put a corner outside)
@@ -285,10 +286,24 @@ void make_cull_records(const Topo& T, const std::vector<PolyRec>& rec, std::vect
             q[a] = (uint64_t)v;
         }
         const uint64_t packed = q[0] | (q[1] << 21) | (q[2] << 42);
-        unsigned char* d = &dense[(size_t)p * 32];
+        unsigned char* d = &dense[(size_t)p * (size_t)cf.stride];
         memcpy(d, &packed, 8);
-        memcpy(d + 8, r.e1f, 12);
-        memcpy(d + 20, r.e2f, 12);
+        float e1f[3], e2f[3];
+        const double* V = &T.verts[(size_t)p * 12];
+        for (int a = 0; a < 3; ++a) {            // from the corners themselves: the PolyRec of a quadrilateral carries NaN in e1f[0] (tools)
+            e1f[a] = (float)(V[3 + a] - V[a]);
+            e2f[a] = (float)(V[6 + a] - V[a]);
+        }
+        memcpy(d + 8, e1f, 12);
+        memcpy(d + 20, e2f, 12);
+        if (cf.stride == 48) {
+            float w2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (T.nverts[p] == 4) {
+                for (int a = 0; a < 3; ++a) w2[a] = (float)(V[9 + a] - V[a]);      // e3f: the second triangle is (v0, v2, v3)
+                w2[3] = 1.0f;
+            }
+            memcpy(d + 32, w2, 16);
+        }
     }
 #else
     static_assert(offsetof(PolyRec, ee) == 48, "the 48-byte pre-cull record is the head of the PolyRec");
@@ -609,7 +624,7 @@ size_t voxel_scene_bytes(const Scene& s, size_t top)
 {
     const size_t ncell = (size_t)s.vox.ct * s.vox.ct * s.vox.ct;
     const size_t items = top < s.vox.items.size() ? s.vox.items[top].size() : 0;
-    return (size_t)s.topos[top].P * (sizeof(PolyRec) + (size_t)kCullStride) + ncell * sizeof(CellRec) + items * sizeof(int32_t);
+    return (size_t)s.topos[top].P * (sizeof(PolyRec) + (size_t)(s.topos[top].has_quads ? 48 : kCullStride)) + ncell * sizeof(CellRec) + items * sizeof(int32_t);
 }
 int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 {
@@ -1066,7 +1081,6 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         tune_blocks_per_cu = s.opt.tune[3] > 0 ? (unsigned)s.opt.tune[3] : 0u;
         if (s.opt.tune[4] > 0 && s.opt.tune[4] <= 64) io.exact_min_parked = s.opt.tune[4];
     }
-    const bool quads = s.topos[top].has_quads;
     const DeviceModule& M = *s.module;
     auto no_own_build = [&]() {
         set_error("hare_shoot: HARE_SHOOT_COUNT_OWN -- the kernel this batch gets has no counting build (the pool kernel of Voxel_Grid, "
@@ -1086,8 +1100,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         fill_voxel_args(s, top, g);
         const KernChoice kc = choose_kernel(s, &M, kind, (size_t)top, n, flags, flags_only);
         if (!kc.f && (flags & HARE_SHOOT_COUNT_OWN)) return no_own_build();
-        if (!kc.f || (kc.k == Kern::VoxelAudit && quads)) {
-            set_error(kc.k == Kern::VoxelAudit ? "hare_shoot: cull audit needs an all-triangle topology and the audit kernel"
+        if (!kc.f) {
+            set_error(kc.k == Kern::VoxelAudit ? "hare_shoot: the cull audit kernel is missing from the code object"
                                                : "hare_shoot: kernel missing from code object");
             return HARE_E_STATE;
         }
@@ -1112,13 +1126,29 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // the walk length -- a pool of rays of similar cost wastes fewer lane-steps (C4 shard -6.8 %, C2 -5.3 % of the kernel's time with
             // the order given; window_sort_*.log), the batch's own locality stays.  Rule ("voxel_order" 1, the default): batches of PRIMARY
             // rays -- no exclusion arrays, not a cast of the bounce loop: reflected rays gain nothing and pay for the indirection
-            // (+5 ... +8 %, window_sort_cathedral_bounce5.log) -- from 262 144 rays, where the pass (~10 us per million rays) is a few per
-            // cent of the cast.  The scratch is stream-ordered (hipMallocAsync / hipFreeAsync): no host synchronisation, nothing kept.
-            const bool order_rule = s.opt.voxel_order == 2 || (s.opt.voxel_order == 1 && !d_e1 && !d_e2 && !(flags & SHOOT_RETIRED_RAYS) && n >= 262144);
-            if (!io.order && order_rule && M.cost_order && H->MallocAsync && H->FreeAsync && n <= 0x7FFFFF00ll && (flags & 0xF000u) == 0) {
-                void* d_order = nullptr;
-                if (H->MallocAsync(&d_order, (size_t)n * sizeof(uint32_t), st) == hipSuccess && d_order) {
+            // (+5 ... +8 %, window_sort_cathedral_bounce5.log) -- from kOrderMinRays: the pass reads every ray once more (12 us per million
+            // rays: half of HBM's rate), which at 1M rays is what the order gains.  The scratch is a block of the scene's order ring
+            // (stream-ordered allocation was tried first: hipMallocAsync / hipFreeAsync cost the stream more than the pass itself).
+            const bool order_rule = s.opt.voxel_order == 2 || (s.opt.voxel_order == 1 && !d_e1 && !d_e2 && !(flags & SHOOT_RETIRED_RAYS) && n >= kOrderMinRays);
+            if (!io.order && order_rule && M.cost_order && n <= 0x7FFFFF00ll && (flags & 0xF000u) == 0) {
+                // a block of the scene's order ring (scene.h); held under the ring's lock across wait + launches + record
+                std::lock_guard<std::mutex> olk(s.order_mu);
+                const int ob = (int)(s.order_seq++ % (unsigned)Scene::kOrderRing);
+                bool have_block = true;
+                if (!s.order_ev[ob] && H->EventCreateWithFlags(&s.order_ev[ob], hipEventDisableTiming) != hipSuccess) { (void)H->GetLastError(); have_block = false; }
+                if (have_block && s.order_cap[ob] < (size_t)n) {
+                    if (s.order_used[ob]) (void)H->EventSynchronize(s.order_ev[ob]);        // its previous user has finished before it is replaced
+                    dev_free(H, s.d_order[ob]);
+                    s.order_cap[ob] = 0;
+                    s.order_used[ob] = false;
+                    const size_t cap = ((size_t)n + 65535u) & ~(size_t)65535u;
+                    if (H->Malloc(&s.d_order[ob], cap * sizeof(uint32_t)) == hipSuccess) s.order_cap[ob] = cap;
+                    else { (void)H->GetLastError(); s.d_order[ob] = nullptr; have_block = false; }      // no scratch: the cast runs in the caller's order
+                }
+                if (have_block) {
+                    if (s.order_used[ob]) HIP_TRY(H->StreamWaitEvent(st, s.order_ev[ob], 0));
                     const void* rp = d_rays;
+                    void* d_order = s.d_order[ob];
                     long long nn = n;
                     float o0[3], o1[3], iv[3];
                     for (int a = 0; a < 3; ++a) { o0[a] = (float)s.vox.omin[a]; o1[a] = (float)s.vox.omax[a]; iv[a] = (float)(1.0 / s.vox.vd[a]); }
@@ -1129,10 +1159,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
                         io.order = (const uint32_t*)d_order;
                         rc = launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
                     }
-                    (void)H->FreeAsync(d_order, st);          // stream-ordered: released when the cast has run
+                    if (H->EventRecord(s.order_ev[ob], st) == hipSuccess) s.order_used[ob] = true;
+                    else (void)H->GetLastError();
                     return rc;
                 }
-                (void)H->GetLastError();                       // no scratch: the cast runs in the caller's order
             }
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }
@@ -1528,6 +1558,10 @@ void hare_scene_destroy(hare_scene* s)
             if (sl.ev) { (void)H->EventSynchronize(sl.ev); (void)H->EventDestroy(sl.ev); sl.ev = nullptr; }
         for (hipEvent_t& e : s->oct_tail_ev)
             if (e) { (void)H->EventSynchronize(e); (void)H->EventDestroy(e); e = nullptr; }
+        for (int k = 0; k < Scene::kOrderRing; ++k) {
+            if (s->order_ev[k]) { (void)H->EventSynchronize(s->order_ev[k]); (void)H->EventDestroy(s->order_ev[k]); s->order_ev[k] = nullptr; }
+            dev_free(H, s->d_order[k]);
+        }
         if (s->stream) (void)H->StreamDestroy(s->stream);
     }
     delete s;

@@ -47,7 +47,12 @@ struct OwnWork { unsigned cells = 0, entries = 0, culls = 0, tests = 0; };
 // casts/s in the bounce loop over gathering from the record heads).
 //   HARE_CULL32 = 1 (default): 32 bytes per polygon, one 32-byte sector, TWO 16-byte gathers:
 //       word 0-1   v0 quantised to 21 bits per axis on the topology's bounding box: q = round((v0 - org) / step), x | y << 21 | z << 42
-//       word 2-7   e1f, e2f (FP32 edges as before; a quadrilateral has NaN in e1f[0]: never culled)
+//       word 2-7   e1f, e2f (FP32 edges as before)
+//     A topology WITH quadrilaterals (round 5) has 48-byte records (CullFrame::stride), three gathers: + e3f = (float)(v3 - v0) and a
+//     flag word.  Quadrilateral.Intersect tries the triangles (0,1,2) and (2,3,0) (Hare_Geometry_Polygons.cs:784-823), so a quadrilateral
+//     is culled when cull_fp32 is certain to miss BOTH -- edges (e1, e2) and (e2, e3) from the same corner v0.  Until round 5 a
+//     quadrilateral was never pre-culled (NaN in e1f[0]) and every list entry that named one cost an exact FP64 test: 5.6 of them
+//     per ray on the hall with its lattices un-split, against 1.4 on the triangulated hall.
 //     The quantisation (<= step / 2 per axis: 21 um on a 90 m cathedral) and the FP32 arithmetic that rebuilds tv = o - v0 from it
 //     only widen the cull's margins (cull_fp32's tv_err, hare_math.h); the exact FP64 test that decides a hit still reads the
 //     128-byte record.  Audited like the cull itself (hare_cull_audit: 0 rejected hits over every ray x polygon pair).
@@ -60,6 +65,8 @@ struct CullFrame {             // how tv = o - v0 is rebuilt from a 32-byte reco
     double org[3];             // the box's min corner: o_rel = (float)(o - org)
     float step[3];             // quantisation step per axis (0 for a flat axis)
     float err0;                // step_max / 2 + 2^-22 * extent_max, rounded up: the ray-independent part of tv_err
+    int32_t stride;            // bytes per record: 32, or 48 for a topology with quadrilaterals (+ e3f and the quadrilateral flag)
+    int32_t pad;
 };
 
 struct VoxelArgs {
@@ -118,6 +125,7 @@ struct CullRaw {
 #if HARE_CULL32
     uint4 w0;                  // q.lo q.hi | e1f.x e1f.y
     float4 w1;                 // e1f.z e2f.x e2f.y e2f.z
+    float4 w2;                 // 48-byte records only: e3f.x e3f.y e3f.z | 1.0f for a quadrilateral, 0 for a triangle
 #else
     double2 c0;                // v0.x v0.y
     uint4 r1;                  // v0.z | e1f.x e1f.y
@@ -133,14 +141,23 @@ struct CullRay {
 #endif
     float dfx, dfy, dfz, dm;
 };
-template <class Args>
+// Q: 0 the topology has no quadrilaterals (32-byte records), 1 it has (48-byte records), -1 decided at run time from the frame
+// (the tree kernels, which are not compiled per topology kind)
+template <int Q = -1, class Args>
 __device__ __forceinline__ CullRaw cull_load(const Args& g, int i)
 {
+#if HARE_CULL32
+    const bool wide = Q == 1 || (Q < 0 && g.cf.stride == 48);
+    const unsigned char* rec = g.cull + (Q == 0 ? (size_t)(unsigned)i * 32u : (Q == 1 ? (size_t)(unsigned)i * 48u : (size_t)(unsigned)i * (size_t)(unsigned)g.cf.stride));
+#else
     const unsigned char* rec = g.cull + (size_t)(unsigned)i * (size_t)kCullStride;
+#endif
     CullRaw r;
 #if HARE_CULL32
     r.w0 = *reinterpret_cast<const uint4*>(rec);
     r.w1 = *reinterpret_cast<const float4*>(rec + 16);
+    r.w2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (wide) r.w2 = *reinterpret_cast<const float4*>(rec + 32);
 #else
     r.c0 = *reinterpret_cast<const double2*>(rec);
     r.r1 = *reinterpret_cast<const uint4*>(rec + 16);
@@ -165,7 +182,7 @@ __device__ __forceinline__ CullRay cull_ray(const Args& g, double ox, double oy,
     r.dm = fabsf(r.dfx) + fabsf(r.dfy) + fabsf(r.dfz);
     return r;
 }
-template <class Args>
+template <int Q = -1, class Args>
 __device__ __forceinline__ bool cull_test(const Args& g, const CullRay& r, const CullRaw& c)
 {
 #if HARE_CULL32
@@ -176,7 +193,15 @@ __device__ __forceinline__ bool cull_test(const Args& g, const CullRay& r, const
     const float tvy = __builtin_fmaf(-qy, g.cf.step[1], r.oy);
     const float tvz = __builtin_fmaf(-qz, g.cf.step[2], r.oz);
     const float e1[3] = {__uint_as_float(c.w0.z), __uint_as_float(c.w0.w), c.w1.x}, e2[3] = {c.w1.y, c.w1.z, c.w1.w};
-    return cull_fp32(tvx, tvy, tvz, r.dfx, r.dfy, r.dfz, r.dm, e1, e2, r.err);
+    bool miss = cull_fp32(tvx, tvy, tvz, r.dfx, r.dfy, r.dfz, r.dm, e1, e2, r.err);
+    if (Q != 0) {
+        // a quadrilateral: certain to miss only when the second triangle (v0, v2, v3) is certain to be missed too
+        if ((Q == 1 || g.cf.stride == 48) && c.w2.w != 0.0f) {
+            const float e3[3] = {c.w2.x, c.w2.y, c.w2.z};
+            miss = miss & cull_fp32(tvx, tvy, tvz, r.dfx, r.dfy, r.dfz, r.dm, e2, e3, r.err);
+        }
+    }
+    return miss;
 #else
     (void)g;
     const double v0z = __hiloint2double((int)c.r1.y, (int)c.r1.x);
@@ -199,6 +224,7 @@ struct KdNodeRec {             // 80 bytes
 constexpr int kOrderWindow = 4096;
 constexpr int kOrderBins = 512;
 constexpr int kOrderThreads = 1024;
+constexpr long long kOrderMinRays = 1572864;      // "voxel_order" 1: batches of primary rays from this size (api.cpp)
 
 // K3d (hare_kdtree_dense, kdtree_dense.hip): the device copy of a kd-tree node, ONE 128-byte cache line, per topology (api.cpp: make_kd_dev_nodes).
 // What a visit needs and nothing else: the split, the node's box on the two axes that are NOT the split axis (what KDTree.cs:249-353 compares

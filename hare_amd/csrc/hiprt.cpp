@@ -80,11 +80,6 @@ void do_bind()
         g_err = e + " (" + g_api.path + ")";
         return;
     }
-    {   // optional entry points: absent -> the features that want them stay off
-        std::string ignored;
-        if (!bind(h, "hipMallocAsync", g_api.MallocAsync, ignored)) g_api.MallocAsync = nullptr;
-        if (!bind(h, "hipFreeAsync", g_api.FreeAsync, ignored)) g_api.FreeAsync = nullptr;
-    }
     g_ok = true;
 }
 

@@ -43,9 +43,6 @@ struct HipApi {
     hipError_t (*EventElapsedTime)(float*, hipEvent_t, hipEvent_t);
     hipError_t (*HostMalloc)(void**, size_t, unsigned int);
     hipError_t (*HostFree)(void*);
-    // optional (null when the runtime lacks them): stream-ordered allocation, for per-launch scratch that must not synchronise the device
-    hipError_t (*MallocAsync)(void**, size_t, hipStream_t);
-    hipError_t (*FreeAsync)(void*, hipStream_t);
     std::string path;   // which runtime was bound
 };
 

@@ -574,8 +574,8 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                 next_candidate();
             } else {
                 // the candidate's pre-cull record (hare_device.h: two or three 16-byte gathers)
-                const CullRaw cr = cull_load(g, idx);
-                if (cull_test(g, cray, cr)) {
+                const CullRaw cr = cull_load<QUADS ? 1 : 0>(g, idx);
+                if (cull_test<QUADS ? 1 : 0>(g, cray, cr)) {
                     done2 = done1;       // a certain miss counts as tested
                     done1 = idx;
                     next_candidate();
@@ -693,7 +693,8 @@ __device__ __forceinline__ void audit_body(const VoxelArgs& g, const ShootIO& io
             const PolyRec& p = g.polys[k];
             const bool c = cull_test(g, cray, cull_load(g, k));
             double t;
-            const bool hit = poly_fast(p, nullptr, o, d, t);
+            const double* v3 = (g.quads && g.quads[k].nverts == 4) ? g.quads[k].v3 : nullptr;
+            const bool hit = poly_fast(p, v3, o, d, t);
             cands++;
             if (c) {
                 culled++;

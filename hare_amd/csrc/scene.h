@@ -42,7 +42,7 @@ struct SceneOptions {
                                // per cast -- measured: the hall +2.5 %, the cathedral -0 ... -10 % (a chip that works on all casts at once loses the L2 locality of one band)
     int voxel_tight = 1;       // 1: K1q sends a ray on past an occupied voxel whose polygons it cannot hit (the voxels' tight boxes, api.cpp: upload_cell_boxes); 0: every list the reference scans (A/B)
     int voxel_order = 1;       // the pool kernel takes a batch's rays, window by window, in the order of their estimated walk length (order_kernels.hip):
-                               // 1 (default) batches of primary rays from 262 144 rays, 0 never, 2 every batch.  Results never depend on it
+                               // 1 (default) batches of primary rays from 1 572 864 rays, 0 never, 2 every batch.  Results never depend on it
     int voxel_tight_max_mb = 0; // budget for those boxes (32 B per voxel and topology), MiB; 0 = none.  Over budget or out of memory: no boxes, same results
     int dev_fail_cellbox_alloc = 0;   // test hook: the boxes' allocation "fails" (tests/test_gpu_tight.py: a build must still succeed)
     int octree_tight = 1;      // 1: K2d / K2p skip a popped node whose subtree's polygons the ray cannot hit (the tight boxes of api.cpp); 0: every node the reference visits (A/B)
@@ -195,6 +195,16 @@ struct Scene {
     hipEvent_t oct_tail_ev[kOctTailRing] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool oct_tail_used[kOctTailRing] = {false, false, false, false, false, false, false, false};
     std::mutex oct_tail_mu;
+    // the ray orders of the pool kernel (order_kernels.hip): a ring of blocks of n uint32, one per launch in flight; a block comes round
+    // after kOrderRing launches and waits for the event its previous user recorded (as the octree scratch ring).  Grown on demand -- the
+    // first ordered launch of a new largest batch size synchronises the block's previous user, like every first-use allocation here
+    static constexpr int kOrderRing = 4;
+    void* d_order[kOrderRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t order_cap[kOrderRing] = {0, 0, 0, 0};
+    hipEvent_t order_ev[kOrderRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool order_used[kOrderRing] = {false, false, false, false};
+    unsigned order_seq = 0;
+    std::mutex order_mu;
 
     // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
     // over), so that host threads calling on one scene run side by side instead of queueing on one mutex; `mu` guards

@@ -61,7 +61,7 @@ __device__ __forceinline__ bool coop_trace(const VoxelArgs& g, const ShootIO& io
                 if (valid) i = k == 0 ? c.i0 : (k == 1 ? c.i1 : g.items[c.start + k]);
                 bool test = valid && i != e1 && i != e2;
                 if (own) { own->entries += valid ? 1u : 0u; own->culls += test ? 1u : 0u; }
-                if (test) test = !cull_test(g, cray, cull_load(g, i));
+                if (test) test = !cull_test<QUADS ? 1 : 0>(g, cray, cull_load<QUADS ? 1 : 0>(g, i));
                 double t = kDblMax;
                 if (own) own->tests += test ? 1u : 0u;
                 if (test) {

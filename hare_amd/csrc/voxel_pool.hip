@@ -186,6 +186,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     if (cn > n32) cn = n32;
     if (ce > n32) ce = n32;
     bool drained = false;
+    unsigned dead_run = 0;           // SHOOT_RETIRED_RAYS: tickets in a row whose rays were all retired (the next ticket is 2^dead_run x as large)
+    bool chunk_live = true;          // ... a live ray seen since the last draw (the static first chunk counts as live: it is not a ticket)
     unsigned nhits = 0, nrays = 0;
     const bool writeback = (io.flags & SHOOT_WRITEBACK_ORIGIN) != 0;
     // the cooperative tail (voxel_coop.hip); with origin write-back the ray record holds the MOVED origin, which coop_trace would move again
@@ -317,7 +319,17 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP + nR == 0)) {
             if (cn >= ce) {
                 unsigned base = 0;
-                const unsigned dyn = (unsigned)io.ticket_rays;
+                unsigned dyn = (unsigned)io.ticket_rays;
+                if (io.flags & SHOOT_RETIRED_RAYS) {
+                    // a cast of the bounce loop over rays most of which the loop has retired (an open scene): a ticket whose rays were ALL
+                    // retired costs this wave nothing but the draw, and the draws -- ~11 ns each on one address, chip-wide -- are then the
+                    // whole launch (measured: 192 us per million retired rays, three quarters of a cast of live rays;
+                    // profiles/r05_experiments/bounce_open_scene.log).  Every such ticket in a row doubles the next one, up to 64 x;
+                    // the first live ray puts the size back.  A closed room never sees a dead ticket.
+                    dead_run = chunk_live ? 0u : (dead_run < 6u ? dead_run + 1u : 6u);
+                    chunk_live = false;
+                    dyn <<= dead_run;
+                }
                 if (lane == 0) base = atomicAdd(io.work, dyn);
                 base = __shfl(base, 0, 64);
                 cn = base + n_static;
@@ -335,7 +347,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 nF -= m;
                 const unsigned ray = (io.order != nullptr && act) ? io.order[cn + lane] : cn + lane;
                 cn += m;
-                bool to_walk = false, to_cull = false, freed = false;
+                bool to_walk = false, to_cull = false, freed = false, retired_lane = false;
                 if (act) {
                     const RayRec r = io.rays[ray];
                     const V3 o = {r.x, r.y, r.z};
@@ -343,6 +355,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if ((io.flags & SHOOT_RETIRED_RAYS) && io.excl1 && io.excl1[ray] == -2) {   // retired by the bounce loop: miss, not counted
                         store_miss(ray);
                         freed = true;
+                        retired_lane = true;
                     } else {
                         nrays++;
                         if (BOUNCE) { L_cast[slot] = 0; atomicAdd(&C_rays[0], 1u); }
@@ -350,6 +363,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     }
                 }
                 if (OWN && (to_walk || to_cull)) own.cells++;            // the voxel the ray starts in
+                if (io.flags & SHOOT_RETIRED_RAYS) chunk_live = chunk_live || __ballot(act && !retired_lane) != 0ull;
                 push(Q_walk, hW, nW, to_walk, slot);
                 push(Q_cull, hC, nC, to_cull, slot);
                 push(Q_free, hF, nF, freed, slot);
@@ -534,9 +548,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         const int it0 = n0, it1 = n1, it2 = n2, it3 = n3;
                         if (OWN) { const unsigned m4 = cnt - base < 4u ? cnt - base : 4u; own.entries += m4; own.culls += m4; }
                         if (base + 4u < cnt) entries(base + 4u);
-                        const CullRaw r0 = cull_load(g, it0), r1 = cull_load(g, it1), r2 = cull_load(g, it2), r3 = cull_load(g, it3);
+                        const CullRaw r0 = cull_load<QUADS ? 1 : 0>(g, it0), r1 = cull_load<QUADS ? 1 : 0>(g, it1), r2 = cull_load<QUADS ? 1 : 0>(g, it2), r3 = cull_load<QUADS ? 1 : 0>(g, it3);
                         auto keep = [&](unsigned k, int it, const CullRaw& rr) {
-                            return k < cnt && it != e1 && it != e2 && !(HARE_K1Q_MAILBOX && it == done1) && !cull_test(g, cray, rr);
+                            return k < cnt && it != e1 && it != e2 && !(HARE_K1Q_MAILBOX && it == done1) && !cull_test<QUADS ? 1 : 0>(g, cray, rr);
                         };
                         const bool k0 = keep(base, it0, r0), k1 = keep(base + 1u, it1, r1), k2 = keep(base + 2u, it2, r2), k3 = keep(base + 3u, it3, r3);
                         if (k0 | k1 | k2 | k3) {
@@ -692,9 +706,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 it1 = g.items[k0 + 1u < last ? k0 + 1u : last];
                 it2 = g.items[k0 + 2u < last ? k0 + 2u : last];
                 it3 = g.items[k0 + 3u < last ? k0 + 3u : last];
-                const CullRaw r0 = cull_load(g, it0), r1 = cull_load(g, it1), r2 = cull_load(g, it2), r3 = cull_load(g, it3);
+                const CullRaw r0 = cull_load<QUADS ? 1 : 0>(g, it0), r1 = cull_load<QUADS ? 1 : 0>(g, it1), r2 = cull_load<QUADS ? 1 : 0>(g, it2), r3 = cull_load<QUADS ? 1 : 0>(g, it3);
                 auto keep = [&](unsigned k, int it, const CullRaw& rr) {
-                    return k < qe && it != e1 && it != e2 && !(HARE_K1Q_MAILBOX && it == done1) && !cull_test(g, cray, rr);
+                    return k < qe && it != e1 && it != e2 && !(HARE_K1Q_MAILBOX && it == done1) && !cull_test<QUADS ? 1 : 0>(g, cray, rr);
                 };
                 s0 = keep(k0, it0, r0);
                 s1 = keep(k0 + 1u, it1, r1);
@@ -785,9 +799,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 for (int b0 = 0; b0 < NC; b0 += NB) {
                     CullRaw R[NB];
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) R[k] = cull_load(g, E[b0 + k]);
+                    for (int k = 0; k < NB; ++k) R[k] = cull_load<QUADS ? 1 : 0>(g, E[b0 + k]);
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) T[b0 + k] = cull_test(g, cray, R[k]);
+                    for (int k = 0; k < NB; ++k) T[b0 + k] = cull_test<QUADS ? 1 : 0>(g, cray, R[k]);
                     if (NB < NC) __builtin_amdgcn_sched_barrier(0);          // keep the next batch's requests behind this batch's tests (registers)
                 }
                 unsigned consumed = 0;
@@ -833,9 +847,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         i2 = g.items[qa]; i3 = i2;                           // q + 3 >= qe: i3 is never a candidate
                     }
                     const int ia = idx >= 0 ? idx : 0, ib = (has1 && nexti >= 0) ? nexti : ia;   // a finished lane may hold -1: stay inside the array
-                    const CullRaw ra = cull_load(g, ia), rb = cull_load(g, ib);
-                    const bool ca = cull_test(g, cray, ra);
-                    const bool cb = cull_test(g, cray, rb);
+                    const CullRaw ra = cull_load<QUADS ? 1 : 0>(g, ia), rb = cull_load<QUADS ? 1 : 0>(g, ib);
+                    const bool ca = cull_test<QUADS ? 1 : 0>(g, cray, ra);
+                    const bool cb = cull_test<QUADS ? 1 : 0>(g, cray, rb);
                     // Re-testing a polygon can never change the result (strict `t < tmin`), so skipping the one this ray
                     // tested last is exact (Voxel_Grid.cs:477 + K1p's register mailbox)
                     const bool sk0 = idx == e1 || idx == e2 || (HARE_K1Q_MAILBOX && idx == done1);

@@ -198,7 +198,7 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "voxel_tight"     the same per voxel: a ray without a hit walks on past an occupied voxel whose polygons it cannot hit; 1 (default) / 0.
  *                     The boxes cost 32 B per voxel and topology and exist only while this is on and the pool kernel serves the grid (up to
  *                     512 voxels a side); switching it on later builds them then
- *   "voxel_order"     1 (default): the pool kernel takes the rays of a batch of primary rays (no exclusion arrays, from 262 144 rays), window by
+ *   "voxel_order"     1 (default): the pool kernel takes the rays of a batch of primary rays (no exclusion arrays, from 1 572 864 rays), window by
  *                     window of 4 096, in the order of their estimated walk length -- a wave's rays then cost about the same; 0 never, 2 every
  *                     batch.  Rays and events stay where the caller has them; results never depend on it
  *   "voxel_tight_max_mb"  budget for those boxes in MiB (0, the default: none).  Over budget -- or out of device memory -- the grid is

@@ -143,7 +143,7 @@ def test_k3d_in_the_bounce_loop_and_its_counting_build():
 
 def test_the_cost_order_of_the_pool_kernel_changes_no_event():
     """order_kernels.hip: K1q takes the rays of a batch, window by window of 4 096, in the order of their estimated walk length
-    (`voxel_order`: 1 = batches of primary rays from 262 144 rays, 0 never, 2 every batch).  Rays, events and exclusions stay in the
+    (`voxel_order`: 1 = batches of primary rays from 1 572 864 rays, 0 never, 2 every batch).  Rays, events and exclusions stay in the
     caller's order and every X_Event is the oracle's: batch sizes around the windows, origins outside the grid with the origin write-back,
     exclusion arrays (forced: the rule leaves such batches alone), NaN / zero / huge direction components, a coarse bitmap."""
     v, nv, size = soup(n_tri=900, n_quad=200, seed=41)
@@ -169,5 +169,50 @@ def test_the_cost_order_of_the_pool_kernel_changes_no_event():
             r = rays.copy()
             ev, _ = g.Shoot_batch(r, writeback_origin=True)
             assert_events_equal(ev, refm, what=f"D={D} write-back order={order}")
-            assert np.array_equal(r.view(np.int64), moved.view(np.int64))
+            nan = np.isnan(moved)                                   # a NaN / infinite ray may come back with a NaN origin: the payload bits are the FPU's
+            assert np.array_equal(np.isnan(r), nan) and np.array_equal(r.view(np.int64)[~nan], moved.view(np.int64)[~nan])
         g.set_option("voxel_order", 1)
+
+
+def test_the_quadrilateral_pre_cull_never_rejects_a_hit(monkeypatch):
+    """Round 5: a quadrilateral is pre-culled when cull_fp32 is certain to miss BOTH triangles Quadrilateral.Intersect tries
+    (Hare_Geometry_Polygons.cs:784-823: (0,1,2) then (2,3,0)); until now it went to the exact test unfiltered.  The audit kernel runs every
+    ray against every polygon through the production load / decode / test and counts (culled AND the exact test accepts): must be zero --
+    on general convex quads (not only parallelograms), slightly non-planar ones, slivers, scales from 1e-3 to 300 with offsets to 1e5,
+    mixed with triangles; rays aimed at corners, edge points, the shared diagonal, and the interior."""
+    import ctypes as C
+    monkeypatch.setenv("HARE_DEV", "1")
+    rng = np.random.default_rng(11)
+    cases = []
+    hq = H.scenes.hall_quads(edge=1.0)
+    cases.append((hq.verts, hq.nverts, H.scenes.burst_rays(1500, hq.size)))
+    for scale, shift in ((1.0, 0.0), (1e-3, 0.0), (1.0, 5000.0), (300.0, -1e5)):
+        P = 500
+        c = rng.uniform(0, 10, (P, 1, 3))
+        a = rng.normal(size=(P, 3)); b = rng.normal(size=(P, 3))
+        uv = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]])[None] + rng.uniform(-0.3, 0.3, (P, 4, 2))     # convex-ish corners
+        quad = c + uv[..., :1] * a[:, None, :] + uv[..., 1:] * b[:, None, :]
+        quad[::5] += rng.normal(size=(P, 4, 3))[::5] * 0.02                       # a fifth slightly non-planar
+        quad[3::9, 3] = quad[3::9, 0] + (quad[3::9, 2] - quad[3::9, 0]) * 1.00001   # slivers: second triangle nearly degenerate
+        verts = quad * scale + shift
+        nverts = np.full(P, 4, np.int32)
+        nverts[::4] = 3                                                           # a quarter are triangles (corner 3 ignored)
+        o = rng.uniform(0, 10, (3000, 3)) * scale + shift
+        pick = rng.integers(0, P, 3000)
+        w = rng.dirichlet([0.3, 0.3, 0.3, 0.3], 3000)
+        w[::5] = np.eye(4)[rng.integers(0, 4, 600)]                               # exactly at a corner
+        w[1::5, 1] = 0; w[1::5, 3] = 0; w[1::5] /= w[1::5].sum(1, keepdims=True)  # on the diagonal v0 - v2 both triangles share
+        aim = np.einsum("nk,nkc->nc", w, verts[pick])
+        d = aim - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        cases.append((np.ascontiguousarray(verts), nverts, np.concatenate([o, d], 1)))
+    for verts, nverts, rays in cases:
+        g = H.Voxel_Grid([H.Topology(verts, nverts)], 2)
+        rays = np.ascontiguousarray(rays)
+        out = np.zeros(len(rays), capi.XEVENT_DTYPE)
+        ctr = (C.c_uint64 * 8)()
+        capi.check(capi.lib.hare_shoot_batch(g._h, 0, 0, len(rays), rays.ctypes.data, None, None, 0x8000, out.ctypes.data, C.addressof(ctr)))
+        viol, culled, cands = ctr[5], ctr[6], ctr[7]
+        assert cands == len(rays) * g.Model[0].Polygon_Count
+        assert viol == 0, f"the pre-cull rejected {viol} true hits on quadrilaterals"
+        assert culled > 0.5 * cands                                               # ... and quadrilaterals ARE culled now
