@@ -105,7 +105,7 @@ int bounce_on_scene(Scene& s, const HipApi* H, Scene::BatchCtx& c, int32_t kind,
 
     if (!events_all) {
         // ---- only the last cast's events are wanted: the whole loop is enqueued ONCE, with no host round trip between casts
-        // (bounce_device_impl, api.cpp: a launch per cast with the retired rays skipped -- or, under the scene option `bounce_fused`,
+        // (bounce_device_impl, launch.cpp: a launch per cast with the retired rays skipped -- or, under the scene option `bounce_fused`,
         // one launch for a Voxel_Grid where the pool kernel serves), and the call synchronises once, at its end.  No packing: a
         // retired ray costs its launch a record read and a miss record.  b.ev[1] serves as the loop's work array (2 n int32).
         HIP_TRY(H->MemcpyAsync(b.rays[0], rays, (size_t)n * sizeof(hare_ray), hipMemcpyHostToDevice, st));

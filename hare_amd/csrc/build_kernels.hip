@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void hare_ob_fill(BuildArgs b, const OctTask* 
     octree_task<true>(b, tasks, pitems, nullptr, oitems);
 }
 
-// The voxels' TIGHT boxes (api.cpp: upload_cell_boxes; used by K1q, voxel_pool.hip): per voxel the bounding box of ALL polygons its list
+// The voxels' TIGHT boxes (device_scene.cpp: upload_cell_boxes; used by K1q, voxel_pool.hip): per voxel the bounding box of ALL polygons its list
 // holds -- whole polygons, not clipped to the voxel: Voxel_Grid.Shoot records a hit wherever it lies on the polygon (Voxel_Grid.cs:691-699)
 // -- grown by `delta` and rounded outwards to floats.  8 floats per voxel: lo xyz, hi xyz, two spare; an empty voxel gets an empty box.
 __global__ __launch_bounds__(256) void hare_cell_boxes(const CellRec* cells, const int32_t* items, const PolyRec* polys, const QuadRec* quads,

@@ -99,7 +99,7 @@ struct OctNode {               // 64 bytes
     int32_t item_start;
     int32_t item_count;
     int32_t pad;               // device copy: a leaf's items[start] (above); an interior node's mask of children that are empty leaves, by octant
-                               // (an interior node's item_start / item_count there: the same mask in cursor order per direction mask, api.cpp)
+                               // (an interior node's item_start / item_count there: the same mask in cursor order per direction mask, device_scene.cpp)
 };
 static_assert(sizeof(OctNode) == 64, "octree node size");
 
@@ -113,7 +113,7 @@ struct OctreeArgs {
     const unsigned char* cull; // as in VoxelArgs
     CullFrame cf;
     const float* tight;        // nullable: per node {lo xyz, hi xyz, 0, 0}: the box of ALL polygons the node's subtree lists, grown by a margin and
-                               // rounded outwards (api.cpp: make_tight_boxes).  A tame ray (K2p / K2d) that misses it cannot hit any of them.
+                               // rounded outwards (device_scene.cpp: make_tight_boxes).  A tame ray (K2p / K2d) that misses it cannot hit any of them.
     double tight_mid[3];       // ... for origins with |o - tight_mid|_inf <= tight_rad only (the margin is sized for those)
     double tight_rad;
 };
@@ -224,9 +224,9 @@ struct KdNodeRec {             // 80 bytes
 constexpr int kOrderWindow = 4096;
 constexpr int kOrderBins = 512;
 constexpr int kOrderThreads = 1024;
-constexpr long long kOrderMinRays = 1572864;      // "voxel_order" 1: batches of primary rays from this size (api.cpp)
+constexpr long long kOrderMinRays = 1572864;      // "voxel_order" 1: batches of primary rays from this size (launch.cpp)
 
-// K3d (hare_kdtree_dense, kdtree_dense.hip): the device copy of a kd-tree node, ONE 128-byte cache line, per topology (api.cpp: make_kd_dev_nodes).
+// K3d (hare_kdtree_dense, kdtree_dense.hip): the device copy of a kd-tree node, ONE 128-byte cache line, per topology (device_scene.cpp: make_kd_dev_nodes).
 // What a visit needs and nothing else: the split, the node's box on the two axes that are NOT the split axis (what KDTree.cs:249-353 compares
 // the crossing point with; ascending axis order), the children, a leaf's list -- and the tight boxes of BOTH children's subtrees
 // ({x0,y0,z0,x1,y1,z1}, as make_tight_boxes rounds them: outwards), so that the visit decides for both children whether to push them.
@@ -242,7 +242,10 @@ struct KdDevNode {
 };
 static_assert(sizeof(KdDevNode) == 128, "kd device node: one cache line");
 #ifndef HARE_K3D_PEND
-#define HARE_K3D_PEND 4            // survivors a lane may hold before it waits for the exact phase
+#define HARE_K3D_PEND 1            // survivors a lane may hold before it waits for the exact phase.  Swept on the hall at 1M rays: 1 / 2 / 3 / 4 / 6:
+                                   // 667 / 650 / 647 / 586 / 564 Mrays/s (shoebox 1 320 / 1 297 / 1 292; 262k rays 367 / 345 / 347) -- a kd leaf holds few
+                                   // polygons and the walk behind a survivor is mostly pruned by its hit: testing it at once beats walking on without
+                                   // (profiles/r05_experiments/k3d_variants*.log)
 #endif
 #ifndef HARE_K3D_WAVES_PER_EU
 #define HARE_K3D_WAVES_PER_EU 4
@@ -363,7 +366,7 @@ struct LaunchSlotMem {
     unsigned long long acc[128];
 };
 static_assert(sizeof(LaunchSlotMem) == 64 + 1024, "launch slot layout (kernels index it by word)");
-constexpr unsigned kLaunchSlots = 64;     // launches of one scene that may be in flight; a 65th waits for the first (api.cpp)
+constexpr unsigned kLaunchSlots = 64;     // launches of one scene that may be in flight; a 65th waits for the first (launch.cpp)
 
 // One ray a K2p wave handed to the cooperative tail kernel K2t (octree_coop.hip): the state of its depth-first walk.  A record is
 // 64 bytes of scalars followed by (levels) frames of 20 bytes, padded to 16: kOctTailHead + 20 * levels rounded up.

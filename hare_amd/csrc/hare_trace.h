@@ -300,7 +300,7 @@ HARE_HD void trace_kdtree(const KdArgs& g, int* stack, int tid, int nt, const V3
     const double oo[3] = {o.x, o.y, o.z};
     const double dd[3] = {d.x, d.y, d.z};
 #if defined(__HIPCC__)
-    // The subtrees' tight boxes (api.cpp: make_tight_boxes; as in the octree kernels): KDTree.Shoot visits EVERY leaf and lets RayXtri
+    // The subtrees' tight boxes (device_scene.cpp: make_tight_boxes; as in the octree kernels): KDTree.Shoot visits EVERY leaf and lets RayXtri
     // say no to all but a few polygons.  A ray that misses the box of all polygons below a node -- or, holding a hit, reaches that box
     // behind it -- cannot make RayXtri accept (t > 1e-10 && t < closestT, :233) any of them: the node is dropped, the event unchanged.
     // Only for finite rays with the origin within the range the boxes' margin is sized for; 1/d may be infinite (a zero component):

@@ -4,7 +4,7 @@
 // is decided by where the ray crosses the split plane (:249-353) -- and tests every polygon of every leaf with the full RayXtri, keeping
 // the smallest t (strict `<`, t > 1e-10; :233).  Nothing about that walk depends on the hits found so far except the accept itself, so
 // its RESULT is: the smallest t over all polygons, ties to the polygon met first in the reference's visiting order.  Round 4 made the
-// one-ray-per-lane kernel a real tree walk by dropping subtrees whose polygons the ray cannot hit (the subtree TIGHT BOXES, api.cpp:
+// one-ray-per-lane kernel a real tree walk by dropping subtrees whose polygons the ray cannot hit (the subtree TIGHT BOXES, device_scene.cpp:
 // make_tight_boxes); this kernel gives that walk the shape the other two partitions' production kernels have (K2d, kernels.hip):
 //   * persistent waves, a static first chunk of rays per wave and tickets behind it; a lane owns a ray and is refilled when it finishes;
 //   * the node records are a device copy of ONE cache line each (KdDevNode, 128 B: split, the four box bounds the crossing test reads,
@@ -27,7 +27,7 @@
 #define HARE_K3D_STEPS 3          // node visits per round at most
 #endif
 #ifndef HARE_K3D_POP_MIN
-#define HARE_K3D_POP_MIN 12       // a second / third visit step only while this many lanes take it
+#define HARE_K3D_POP_MIN 1        // a second / third visit step only while this many lanes take it (1 / 12 / 24: 598 / 586 / 583 Mrays/s on the hall)
 #endif
 #ifndef HARE_K3D_REFILL
 #define HARE_K3D_REFILL 16        // refill when this many lanes are idle
@@ -78,6 +78,8 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
     if (cn > n32) cn = n32;
     if (ce > n32) ce = n32;
     bool drained = false;
+    unsigned int dead_run = 0;          // SHOOT_RETIRED_RAYS: tickets in a row whose rays were all retired
+    bool chunk_live = true;
 
     bool alive = false, hit = false, tight_ok = false;
     unsigned int ray = 0;
@@ -134,7 +136,14 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                 if (wm == 0) break;
                 if (cn >= ce) {
                     unsigned int base = 0;
-                    const unsigned int dyn = (unsigned int)io.ticket_rays;
+                    unsigned int dyn = (unsigned int)io.ticket_rays;
+                    if (io.flags & SHOOT_RETIRED_RAYS) {
+                        // a cast of the bounce loop: a ticket whose rays the loop had all retired cost nothing but its draw -- every such
+                        // ticket in a row doubles the next one (up to 64 x), the first live ray puts the size back (as K1q, voxel_pool.hip)
+                        dead_run = chunk_live ? 0u : (dead_run < 6u ? dead_run + 1u : 6u);
+                        chunk_live = false;
+                        dyn <<= dead_run;
+                    }
                     if (lane == 0) base = atomicAdd(io.work, dyn);
                     base = __shfl(base, 0, 64);
                     cn = base + n_static;
@@ -144,6 +153,7 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                 const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
                 const bool got = want && mine < ce;
                 cn += (unsigned int)__popcll(__ballot(got));
+                bool live_lane = false;
                 if (got) {
                     want = false;
                     ray = mine;
@@ -159,6 +169,7 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                         finish();                                           // retired by the bounce loop: miss record, not counted
                     } else {
                         nrays++;
+                        live_lane = true;
                         cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
                         tight_ok = g.tight != nullptr && fabs(o.x - g.tight_mid[0]) <= g.tight_rad && fabs(o.y - g.tight_mid[1]) <= g.tight_rad &&
                                    fabs(o.z - g.tight_mid[2]) <= g.tight_rad && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
@@ -173,6 +184,10 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                             if ((uf < un) | (uf < 0)) finish();             // the ray misses every polygon of the tree
                         }
                     }
+                }
+                if (io.flags & SHOOT_RETIRED_RAYS) {
+                    chunk_live = chunk_live || __ballot(live_lane) != 0ull;
+                    want = want || (got && !alive);          // a lane that drew a retired ray draws again: its record is written, it holds nothing
                 }
             }
         }
@@ -209,7 +224,7 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                         q = nd.item_start; qe = nd.item_start + nd.item_count;
                         cur = -1;
                     } else {
-                        // :249-353 -- the three SplitAxis branches are one pattern; the two other axes in ascending order (bb, api.cpp)
+                        // :249-353 -- the three SplitAxis branches are one pattern; the two other axes in ascending order (bb, device_scene.cpp)
                         const int a = nd.axis;
                         const double oa = a == 0 ? o.x : (a == 1 ? o.y : o.z);
                         const double da = a == 0 ? d.x : (a == 1 ? d.y : d.z);

@@ -79,7 +79,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long s)
 //   3. that wave fetches-and-zeroes the shards (atomic exchanges: memory side again, so it sees every add of step 1, each of
 //      which returned before its wave's done-count was issued), adds the sums to the caller's counters, and zeroes the done
 //      counters and the ticket word: the slot is all zero again for the launch that uses it next (the host orders launches
-//      on one slot, api.cpp).  No fence is needed anywhere: every word of the slot is only ever touched by atomics.
+//      on one slot, launch.cpp).  No fence is needed anywhere: every word of the slot is only ever touched by atomics.
 // Cost: three dependent atomics per wave, off the ray path; ~4,000 done-counts spread over 8 + 1 addresses.
 __device__ __forceinline__ void launch_epilogue(const ShootIO& io, unsigned int nrays, unsigned int nhits, unsigned int waves_per_block)
 {
@@ -822,7 +822,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     OwnWork ownw;
     int tail_rounds = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int nt = 256;          // the launch's block size (api.cpp: launch_persist): frame indices are shifts, not 32-bit multiplies (quarter rate)
+    constexpr int nt = 256;          // the launch's block size (launch.cpp: launch_persist): frame indices are shifts, not 32-bit multiplies (quarter rate)
     const int tid = threadIdx.x;
     const int levels = g.max_depth > 0 ? g.max_depth : 1;
     double* const fa = reinterpret_cast<double*>(lds);              // [levels][nt] interval start of the frame's node
@@ -864,6 +864,8 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     if (cn > n32) cn = n32;
     if (ce > n32) ce = n32;
     bool drained = false;
+    unsigned int dead_run = 0;          // SHOOT_RETIRED_RAYS: tickets in a row whose rays were all retired
+    bool chunk_live = true;
 
     bool alive = false, parked = false, hit = false, tame = true;
     bool tight_ok = false;              // this ray may be tested against the subtrees' tight boxes (g.tight: a tame ray with its origin near the scene)
@@ -937,7 +939,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             // arise, so Math.Max / Math.Min are v_max_f64 / v_min_f64 and the four conditions of :268 fold.  The slabs are formed in
             // CURSOR order (cursor index a along an axis is the octant slab a ^ (d < 0)), so the eight tests yield the frame's mask as it
             // is stored -- no octant -> cursor permutation -- and the children that are empty leaves come as a cursor-ordered byte of
-            // the device copy (one per direction mask, api.cpp).  Same expressions on the same operands as below: same bits.
+            // the device copy (one per direction mask, device_scene.cpp).  Same expressions on the same operands as below: same bits.
             double ncx[2], fcx[2], ncy[2], fcy[2], ncz[2], fcz[2];
             {
                 const double c = (nd.bmax[0] + nd.bmin[0]) / 2;
@@ -1025,7 +1027,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 p = p && !(hit && closestT <= mx(tmn, ca));
                 pushed |= p ? (1u << oct) : 0u;
             }
-            pushed &= ~((unsigned)nd.pad & 255u);                   // children that are empty leaves (the device copy's mask, api.cpp): popping one
+            pushed &= ~((unsigned)nd.pad & 255u);                   // children that are empty leaves (the device copy's mask, device_scene.cpp): popping one
                                                                    // has no effect ("Octree - alt.cs":213: the list loop does not run), a third of K2p's pops
             unsigned byc = 0;                                      // octant bit -> cursor bit: cursor k examines octant k ^ mask
 #pragma unroll
@@ -1049,7 +1051,14 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 if (wm == 0) break;
                 if (cn >= ce) {
                     unsigned int base = 0;
-                    const unsigned int dyn = (unsigned int)io.ticket_rays;
+                    unsigned int dyn = (unsigned int)io.ticket_rays;
+                    if (io.flags & SHOOT_RETIRED_RAYS) {
+                        // a cast of the bounce loop: a ticket whose rays the loop had all retired cost nothing but its draw -- every such
+                        // ticket in a row doubles the next one (up to 64 x), the first live ray puts the size back (as K1q, voxel_pool.hip)
+                        dead_run = chunk_live ? 0u : (dead_run < 6u ? dead_run + 1u : 6u);
+                        chunk_live = false;
+                        dyn <<= dead_run;
+                    }
                     if (lane == 0) base = atomicAdd(io.work, dyn);
                     base = __shfl(base, 0, 64);
                     cn = base + n_static;
@@ -1059,6 +1068,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
                 const bool got = want && mine < ce;
                 cn += (unsigned int)__popcll(__ballot(got));
+                bool live_lane = false;
                 if (got) {
                     want = false;
                     ray = mine;
@@ -1083,6 +1093,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         finish();
                     } else {
                         nrays++;
+                        live_lane = true;
                         invDx = fabs(d.x) > 1e-16 ? 1.0 / d.x : 1e16;      // "Octree - alt.cs":165-167
                         invDy = fabs(d.y) > 1e-16 ? 1.0 / d.y : 1e16;
                         invDz = fabs(d.z) > 1e-16 ? 1.0 / d.z : 1e16;
@@ -1103,6 +1114,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         //  root's visit out of this set-up path, where the compiler spills ~20 registers around it, and was measured:
                         //  bit-exact, 2.88 -> 3.32 ms at 1M rays.  The spills sit here and in the kernel's prologue only, once per ray.)
                     }
+                }
+                if (io.flags & SHOOT_RETIRED_RAYS) {
+                    chunk_live = chunk_live || __ballot(live_lane) != 0ull;
+                    want = want || (got && !alive);          // a lane that drew a retired ray draws again: its record is written, it holds nothing
                 }
             }
         }
@@ -1166,7 +1181,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                         // index, list words -- in the branches that use them, a second and a third wait per pop
                         OctNode nd = g.nodes[c];
                         if (OWN) ownw.cells++;
-                        // ... and, in the same batch, the box of the polygons its subtree lists (api.cpp: make_tight_boxes)
+                        // ... and, in the same batch, the box of the polygons its subtree lists (device_scene.cpp: make_tight_boxes)
                         float4 tb0 = make_float4(0, 0, 0, 0), tb1 = tb0;
                         if (FAST && g.tight != nullptr) {
                             const float4* tp = reinterpret_cast<const float4*>(g.tight) + 2 * (size_t)c;

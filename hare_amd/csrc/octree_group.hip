@@ -30,7 +30,7 @@
 // Results are bit-identical to the sequential walk (tests: every octree test of the suite runs against this kernel).
 //
 // LDS per group: the stack's top kGStack entries (24 B each) + 16 pending survivors (16 B each); entries below the top kGStack
-// spill to a per-launch block in device memory (the scene's octree scratch ring, api.cpp), so a stack of any depth the tree
+// spill to a per-launch block in device memory (the scene's octree scratch ring, launch.cpp), so a stack of any depth the tree
 // allows (7 x levels + 8) works, at LDS speed for all but pathological rays.
 namespace {
 
@@ -107,7 +107,7 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
 
     // ---- per-ray state, uniform over the group's eight lanes
     bool alive = false, hit = false, tame = true;
-    bool tight_ok = false;              // the subtrees' tight boxes may be used for this ray (g.tight, api.cpp: make_tight_boxes): tame, origin near the scene
+    bool tight_ok = false;              // the subtrees' tight boxes may be used for this ray (g.tight, device_scene.cpp: make_tight_boxes): tame, origin near the scene
     unsigned int ray = 0;
     V3 o = {0, 0, 0}, d = {0, 0, 0};
     double invDx = 0, invDy = 0, invDz = 0;

@@ -40,12 +40,12 @@ struct SceneOptions {
     int k2p_static_rays = 0;
     int bounce_fused = 0;      // 1: the bounce loop of a Voxel_Grid runs as ONE launch where the pool kernel serves (hare_voxel_bounce_*); 0 (default): a launch
                                // per cast -- measured: the hall +2.5 %, the cathedral -0 ... -10 % (a chip that works on all casts at once loses the L2 locality of one band)
-    int voxel_tight = 1;       // 1: K1q sends a ray on past an occupied voxel whose polygons it cannot hit (the voxels' tight boxes, api.cpp: upload_cell_boxes); 0: every list the reference scans (A/B)
+    int voxel_tight = 1;       // 1: K1q sends a ray on past an occupied voxel whose polygons it cannot hit (the voxels' tight boxes, device_scene.cpp: upload_cell_boxes); 0: every list the reference scans (A/B)
     int voxel_order = 1;       // the pool kernel takes a batch's rays, window by window, in the order of their estimated walk length (order_kernels.hip):
                                // 1 (default) batches of primary rays from 1 572 864 rays, 0 never, 2 every batch.  Results never depend on it
     int voxel_tight_max_mb = 0; // budget for those boxes (32 B per voxel and topology), MiB; 0 = none.  Over budget or out of memory: no boxes, same results
     int dev_fail_cellbox_alloc = 0;   // test hook: the boxes' allocation "fails" (tests/test_gpu_tight.py: a build must still succeed)
-    int octree_tight = 1;      // 1: K2d / K2p skip a popped node whose subtree's polygons the ray cannot hit (the tight boxes of api.cpp); 0: every node the reference visits (A/B)
+    int octree_tight = 1;      // 1: K2d / K2p skip a popped node whose subtree's polygons the ray cannot hit (the tight boxes of device_scene.cpp); 0: every node the reference visits (A/B)
     int kdtree_kernel = 0;     // 0 = the library's rule (K3d, hare_kdtree_dense, wherever its node records exist and its LDS fits), 1 = the one-ray-per-lane kernel, 2 = K3d
     int octree_tail = 2;       // what finishes the rays K2p gives up: 0 nothing (every lane finishes its own), 1 K2t (a wave per ray, a wave's last 16), 2 K2g-tail (eight lanes per ray, all of them)
     int k2p_tail_max = 0;      // developer sweeps: hand over once at most this many rays are alive in a wave (0 = the rule) ...
@@ -161,17 +161,17 @@ struct Scene {
     std::vector<CullFrame> cull_frames;          // per topo: how those records decode
     std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
-    std::vector<void*> d_cellbox;                // per topo: the voxels' tight boxes, 8 floats per voxel (api.cpp: upload_cell_boxes); null = none
+    std::vector<void*> d_cellbox;                // per topo: the voxels' tight boxes, 8 floats per voxel (device_scene.cpp: upload_cell_boxes); null = none
     double cellbox_mid[3] = {0, 0, 0}, cellbox_rad = -1;   // ray origins they may be used for: |o - mid|_inf <= rad
     int32_t occ_words = 0;                       // words of the occupancy bitmap the persistent kernel stages in LDS
     int32_t occ_shift = 0, occ_cd = 0;           // bitmap resolution: one bit per (2^occ_shift)^3 voxels, occ_cd blocks per axis
     void* d_oct_nodes = nullptr;
     void* d_oct_items = nullptr;
-    std::vector<void*> d_oct_tight;   // per topology: the box of the polygons every node's subtree lists, 8 floats per node (api.cpp: make_tight_boxes); null = none
+    std::vector<void*> d_oct_tight;   // per topology: the box of the polygons every node's subtree lists, 8 floats per node (device_scene.cpp: make_tight_boxes); null = none
     double oct_tight_mid[3] = {0, 0, 0}, oct_tight_rad = -1;      // ray origins the boxes may be used for: |o - mid|_inf <= rad
     void* d_kd_nodes = nullptr;
     std::vector<void*> d_kd_tight;    // as d_oct_tight, for the kd-tree's nodes
-    std::vector<void*> d_kd_dev;      // per topology: the one-line node records of hare_kdtree_dense (KdDevNode; api.cpp: upload_kd_dev_nodes); null = none
+    std::vector<void*> d_kd_dev;      // per topology: the one-line node records of hare_kdtree_dense (KdDevNode; device_scene.cpp: upload_kd_dev_nodes); null = none
     double kd_tight_mid[3] = {0, 0, 0}, kd_tight_rad = -1;
     void* d_kd_items = nullptr;
     void* d_work = nullptr;                      // LaunchSlotMem[kLaunchSlots]: scratch of the persistent launches in flight
@@ -261,14 +261,14 @@ struct Scene {
     int32_t oct_levels = 0;                      // interior levels the octree actually has (frames the kernels need)
 };
 void free_host_mirror(Scene& s);             // host_trace.cpp
-void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<QuadRec>& quads);   // api.cpp
-void make_cull_records(const Topo& T, const std::vector<PolyRec>& rec, std::vector<unsigned char>& dense, CullFrame& cf);   // api.cpp
+void make_poly_records(const Topo& T, std::vector<PolyRec>& rec, std::vector<QuadRec>& quads);   // device_scene.cpp
+void make_cull_records(const Topo& T, const std::vector<PolyRec>& rec, std::vector<unsigned char>& dense, CullFrame& cf);   // device_scene.cpp
 
 // error plumbing (thread-local message)
 void set_error(const std::string& msg);
 const char* last_error();
 
-// the launcher behind every shoot entry point (api.cpp)
+// the launcher behind every shoot entry point (launch.cpp)
 // d_occ != null: also (d_out != null) or only (d_out == null) the occlusion flags against d_tmax (nullable: any hit)
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays, const void* d_e1, const void* d_e2,
                       uint32_t flags, void* d_out, void* d_ctr, hipStream_t st, const void* d_tmax = nullptr, void* d_occ = nullptr);
@@ -278,7 +278,7 @@ uint32_t sanitize_flags(const Scene& s, uint32_t flags);
 int dev_free(const HipApi* H, void*& p);
 void free_bounce_buffers(const HipApi* H, Scene& s);          // bounce.cpp
 
-// device plumbing shared by api.cpp and build_gpu.cpp
+// device plumbing (device_scene.cpp) shared with api.cpp, launch.cpp and build_gpu.cpp
 const HipApi* api_or_err();
 int ensure_device(Scene& s, const HipApi*& H);
 int upload(const HipApi* H, void** dst, const void* src, size_t bytes);
@@ -312,7 +312,7 @@ int octree_check_args(const Scene& s, int32_t max_depth, int32_t max_polys);
 void octree_root_box(const Topo& T, double bmin[3], double bmax[3]);                      // "Octree - alt.cs":63-88
 void octree_child_box(const double nmin[3], const double nmax[3], int i, double cmin[3], double cmax[3]);   // :96-114
 int build_kdtree(Scene& s, int32_t max_depth, int32_t max_polys);
-int32_t octree_levels(const OctreeHost& o);   // api.cpp
+int32_t octree_levels(const OctreeHost& o);   // device_scene.cpp
 
 // host helpers
 void polygon_normals(const double* verts, const int32_t* nverts, int32_t P, double* out);

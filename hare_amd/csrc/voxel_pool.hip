@@ -37,7 +37,7 @@
 // loads that follow are ordinary global_loads, and the s_waitcnt vmcnt the compiler puts in front of their first use is the only
 // wait involved; the earlier store needs none of its own, because the later load of the same wave queues behind it in the same L1.
 // The invariant holds only while no OTHER wave touches those bytes (another CU's L1 is never refreshed by this one's stores: that
-// would need the agent-scope forms): the host refuses calls whose rays / events / exclusion buffers overlap (api.cpp), and a ray
+// would need the agent-scope forms): the host refuses calls whose rays / events / exclusion buffers overlap (launch.cpp), and a ray
 // belongs to exactly one wave from its set-up to its final event.
 #ifndef HARE_K1Q_WALK_STEPS
 #define HARE_K1Q_WALK_STEPS 16    // DDA steps per walk task at most
@@ -205,7 +205,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                                     : (uint32_t)cell;
         return (locc[bit >> 5] >> (bit & 31)) & 1u;
     };
-    // The voxel's tight box (hare_cell_boxes; api.cpp: upload_cell_boxes): does the ray (origin as the walk uses it, i.e. moved) miss the box
+    // The voxel's tight box (hare_cell_boxes; device_scene.cpp: upload_cell_boxes): does the ray (origin as the walk uses it, i.e. moved) miss the box
     // of ALL polygons of the voxel's list?  Then the exact test cannot accept any of them and scanning the list would leave the ray as
     // it is.  FP64 slab test on reciprocals refined once (2^-47); the box is grown by 2^-20 of the scene's extent, a million times the
     // rounding of either test; rays that are not finite or start beyond 1 024 extents of the scene are never said to miss.  fmax / fmin
@@ -794,7 +794,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #ifndef HARE_K1Q_CULL_BATCH
 #define HARE_K1Q_CULL_BATCH (NC % 4 == 0 ? 4 : 2)    // records requested together (8 VGPRs each): 4 measured better than 8 (registers) and 2
 #endif
-                constexpr int NB = HARE_K1Q_CULL_BATCH;
+#ifndef HARE_K1Q_CULL_BATCH_QUADS
+#define HARE_K1Q_CULL_BATCH_QUADS HARE_K1Q_CULL_BATCH   // the 48-byte records of a topology with quadrilaterals: 12 VGPRs each
+#endif
+                constexpr int NB = QUADS ? HARE_K1Q_CULL_BATCH_QUADS : HARE_K1Q_CULL_BATCH;
 #pragma unroll
                 for (int b0 = 0; b0 < NC; b0 += NB) {
                     CullRaw R[NB];

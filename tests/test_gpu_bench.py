@@ -124,7 +124,7 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
 
 
 @pytest.mark.parametrize("extra,kernel", [
-    ((), "hare_voxel_pool_tri"),                          # the pool kernel serves every batch size (api.cpp: choose_kernel)
+    ((), "hare_voxel_pool_tri"),                          # the pool kernel serves every batch size (launch.cpp: choose_kernel)
     (("--kind", "octree"), OCTREE_KERNEL),
     (("--bounces", "3"), "hare_voxel_pool_tri"),
     (("--rays", "1048576"), "hare_voxel_pool_tri"),

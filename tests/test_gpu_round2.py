@@ -442,7 +442,7 @@ def test_concurrent_batch_callers_on_one_scene(hall, what):
 
 
 def test_the_picker_follows_its_rule(hall):
-    """api.cpp choose_kernel: K1q for every batch size since round 3 (a batch below one pool fill of the chip is spread over all
+    """launch.cpp choose_kernel: K1q for every batch size since round 3 (a batch below one pool fill of the chip is spread over all
     waves, which the wide drain modes then serve with several lanes per ray); K1p for grids the pool kernel cannot take (more than
     512 voxels a side); the per-scene option is for A/B runs."""
     _, T, _ = hall

@@ -1,4 +1,4 @@
-"""The subtree TIGHT BOXES of the octree kernels K2d / K2p / K2g (api.cpp: make_tight_boxes; scene option `octree_tight`): a popped node whose
+"""The subtree TIGHT BOXES of the octree kernels K2d / K2p / K2g (device_scene.cpp: make_tight_boxes; scene option `octree_tight`): a popped node whose
 subtree's polygons the ray cannot hit is dropped without being visited.  Not in the reference -- "Octree - alt.cs":207-237 visits every
 node its loose boxes let through and lets RayXtri say no -- so the only acceptable effect is none: the same eight X_Event fields, bit for
 bit, with the boxes on, off, and from the oracle.  The cases are chosen where a box test has the least room: rays aimed exactly at

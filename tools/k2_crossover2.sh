@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p "${GRAFT_REPO_ROOT:-.}/gpurun_out"   # the failing command's stderr is kept there (ERRLOG)
-# Developer: K2d against K2g over batch sizes (the rule of api.cpp: K2d from N rays), hall octree 8/16.  GPU box.
+# Developer: K2d against K2g over batch sizes (the rule of launch.cpp: K2d from N rays), hall octree 8/16.  GPU box.
 cd "$(dirname "$0")/.."
 one() { local label=$1 n=$2; shift 2
   env HARE_DEV=1 "$@" timeout -k 10 120 python bench.py --kind octree --rays $n --steps 8 --warmup 2 --no-e2e --no-cpu-baseline 2>>"${ERRLOG:=${GRAFT_REPO_ROOT:-.}/gpurun_out/tools_stderr.log}" |
