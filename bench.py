@@ -402,9 +402,9 @@ def measure(w, env):
     #   for, and what rocprofv3's average for the kernel agrees with (profiles/);
     #   anything else (a reduce per step, a bounce loop): the event pair around every call.
     if B == 1 and dist is None:
-        kern_ms, kern_src = dev_ms / steps, "HIP events around the timed region / steps"
+        kern_ms, kern_src = dev_ms / steps, "timed region / steps (HIP events)"
     else:
-        kern_ms, kern_src = kern_ms_pairs, "HIP event pair around every call"
+        kern_ms, kern_src = kern_ms_pairs, "event pair per call (HIP events)"
     per_cast_ms = [kern_ms] * B
     events_dev = out_sets[state["set"]].cpu().numpy().tobytes() if B == 1 else None   # the bench buffers themselves, for the parity check
 
@@ -431,7 +431,7 @@ def measure(w, env):
             torch.cuda.synchronize()
         t2 = t0e.elapsed_time(t1e)
         two_streams = {"value": round(n * k2 / t2 / 1e3, 2), "unit": "Mrays/s", "ms_per_step": round(t2 / k2, 4), "steps": k2,
-                       "note": "the same launches alternating over two HIP streams (a streaming caller); not the contract's `value`"}
+                       "note": "same launches alternating over two HIP streams; not the contract's value"}
 
     # measured device-copy bandwidth (what "HBM peak" means in practice on this box) and the host-buffer (PCIe-inclusive) rate
     copy_gbs = None
@@ -602,8 +602,7 @@ def measure(w, env):
                    "value_1thread": round(c1ctr["rays"] / dt1 / 1e6, 6 if c1ctr["rays"] / dt1 < 1e4 else 3),
                    "sample": (f"{n} rays of this workload" if samp is None else f"every {n // len(samp)}th ray of this workload ({len(samp)} rays)")
                              + (f" x {B} casts ({casts} live)" if B > 1 else "")
-                             + f", best of {reps} passes, {cores} threads; 1 thread on {n1} rays. C restatement of Hare {ref_name} "
-                             f"(oracle/): an upper bound on the C# reference, which cannot be run here"}
+                             + f", best of {reps} passes; 1 thread on {n1} rays. C restatement of {ref_name} (oracle/): an upper bound on the C# reference"}
         # parity check of the bench buffers themselves (not timed): every ray of this rank's shard, all eight fields, bit for bit --
         # BEFORE anything else is cast into them
         got = device_events(n)
@@ -647,7 +646,7 @@ def measure(w, env):
                        "bytes_per_launch": own_bytes // B, "bytes_per_cast": round(own_bytes / max(casts, 1), 1),
                        "per_cast": {"C": round(oc[2] / max(casts, 1), 2), "L": round(oc[3] / max(casts, 1), 2),
                                     "K": round(oc[5] / max(casts, 1), 2), "T": round(oc[4] / max(casts, 1), 2)},
-                       "formula": f"104 + {cw} C' + 4 L' + 32 K' + 128 T' (+28 per bounce); counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}
+                       "formula": f"104+{cw}C'+4L'+32K'+128T' (+28/bounce), counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}
         except Exception as e:       # a batch whose kernel has no counting build (HARE_E_UNSUPPORTED): the line says so
             own = {"frac": None, "why": str(e)[:120]}
         # ---- roofline.issue: the bound the counters name (VALU issue), as a fraction: PMC wave-instruction counts by class x the measured
@@ -679,8 +678,7 @@ def measure(w, env):
                     "hbm_busy_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1)}
         if roofline["frac"] > 1.0:
-            roofline["warning"] = ("frac > 1: the numerator is the reference algorithm's bytes (SURVEY 8(d)); the kernel skips part of that "
-                                   "work (tight boxes, pre-cull) -- not a fraction of a hardware bound; read own.frac / issue.frac")
+            roofline["warning"] = "frac > 1: reference-priced numerator (SURVEY 8(d)), not a hardware fraction; read own.frac / issue.frac"
         if B > 1:
             roofline["bounce_loop_ms"] = round(loop_ms, 4)
             roofline["bounce_loop"] = "hare_bounce_device: " + (part.bounce_kernel_name(n, B) or "a launch per cast")
@@ -713,6 +711,7 @@ def measure(w, env):
                                 f"{n} spherical-Fibonacci burst rays per GPU") + f" -> {mesh.name} "
                                f"({mesh.P} triangles), {kdesc}, closest hit (X_Event)"
                                + (f", x{B} specular bounces device-resident (value = casts/s)" if B > 1 else ""),
+                   "workload_short": f"{n_total} burst rays -> {mesh.name}, {kdesc}" + (f", x{B} specular bounces" if B > 1 else ""),
                    "rays_per_gpu": n, "rays_total": n_total, "triangles": mesh.P, "partition": kdesc,
                    "sharding": f"rays x{world}, scene replicated",
                    "buffer_sets": n_sets,
@@ -772,10 +771,11 @@ def compact_sub(sub: dict) -> dict:
     own, issue, cpu = rf.get("own") or {}, rf.get("issue") or {}, sub.get("cpu_baseline")
     out = {k: sub[k] for k in ("value", "unit", "n_gpus", "scaling", "steps", "warmup", "ms_per_step", "kernel_only_mrays_s", "hits", "rays",
                                "x_event_parity_vs_oracle", "parity_per_rank", "ranks_seen_in_reduce") if k in sub}
-    out["config"] = {k: sub["config"][k] for k in ("workload", "rays_per_gpu", "rays_total", "backend")}
+    out["config"] = {k: sub["config"][k] for k in ("rays_per_gpu", "rays_total", "backend")}
+    out["config"]["workload"] = sub["config"]["workload_short"]
     r = {k: rf.get(k) for k in ("frac", "achieved", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "bytes_per_cast", "per_cast")}
     if rf.get("warning"):
-        r["warning"] = "frac > 1: reference-priced numerator, not a hardware fraction; see own / issue"
+        r["warning"] = "frac > 1: reference-priced; see own / issue"
     r["own"] = {k: own.get(k) for k in ("frac", "bytes_per_cast", "per_cast", "why") if own.get(k) is not None} if own else None
     r["issue"] = {k: issue.get(k) for k in ("frac", "lane_util")} if issue else None
     for k in ("live_casts_per_pass", "bounce_loop_ms"):
@@ -794,8 +794,9 @@ def fit_line(line: dict) -> str:
     """The one JSON line, within LINE_BUDGET: what is dropped first is prose, never a number."""
     dumps = lambda o: json.dumps(o, separators=(",", ":"))
     txt = dumps(line)
-    drops = [("roofline", "own", "formula"), ("cpu_baseline", "sample"), ("roofline", "kernel_ms_source"), ("roofline", "warning"),
-             ("parity_sample",), ("config", "sharding"), ("config", "partition")]
+    line.get("config", {}).pop("workload_short", None)
+    drops = [("cpu_baseline", "sample"), ("roofline", "measured_bound"), ("parity_sample",), ("config", "sharding"), ("config", "partition"),
+             ("roofline", "own", "formula"), ("roofline", "warning"), ("two_streams", "note")]
     for path in drops:
         if len(txt) <= LINE_BUDGET:
             break

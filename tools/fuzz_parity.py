@@ -92,11 +92,27 @@ def main():
             occ = g.Occluded_batch(rays, t_max=tmax)[0]
             want_occ = (ref["hit"] == 1) & (ref["t"] < tmax); checks += 1
             if not np.array_equal(np.asarray(occ, bool), want_occ): print("MISMATCH seed %d occlusion D=%d n=%d" % (seed, D, n)); return 1
-        if seed % 4 == 0:
-            kd, ko = H.KDTree([T], depth + 2, maxp), po.KDTree([To], depth + 2, maxp)
+        if seed % 2 == 0:
+            # KDTree: K3d (hare_kdtree_dense, round 5) and the one-ray-per-lane kernel, plain and with exclusions, boxes on and off
+            kdepth = int(rng.integers(0, 14))
+            kd, ko = H.KDTree([T], kdepth, maxp), po.KDTree([To], kdepth, maxp)
             m = min(n, 800)
-            bad = same(kd.Shoot_batch(rays[:m])[0], ko.shoot(rays[:m])[0]); checks += 1
-            if bad: print("MISMATCH seed %d kd %d/%d" % (seed, depth + 2, maxp), bad); return 1
+            kref, krefx = ko.shoot(rays[:m])[0], ko.shoot(rays[:m], excl1=e1[:m], excl2=e2[:m])[0]
+            for kern in (2, 1):
+                kd.set_option("kdtree_kernel", kern)
+                for tight in ((1, 0) if seed % 4 == 0 else (1,)):
+                    kd.set_option("octree_tight", tight)
+                    for what, got, want in (("plain", kd.Shoot_batch(rays[:m])[0], kref),
+                                            ("excl", kd.Shoot_batch(rays[:m], poly_origin1=e1[:m], poly_origin2=e2[:m])[0], krefx)):
+                        bad = same(got, want); checks += 1
+                        if bad: print("MISMATCH seed %d kd %d/%d kernel %d tight %d %s" % (seed, kdepth, maxp, kern, tight, what), bad); return 1
+        if seed % 3 == 0:
+            # the pool kernel through the cost order (voxel_order forced on: the rule only takes batches of 1.5M primary rays)
+            g.set_option("voxel_order", 2)
+            for what, got, want in (("plain", g.Shoot_batch(rays)[0], ref), ("excl", g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], refx)):
+                bad = same(got, want); checks += 1
+                if bad: print("MISMATCH seed %d voxel D=%d n=%d cost order %s" % (seed, D, n, what), bad); return 1
+            g.set_option("voxel_order", 1)
         print("seed %d clean (D=%d n=%d octree %d/%d), %d comparisons so far, %.0f s" % (seed, D, n, depth, maxp, checks, time.time() - t0), flush=True)
     print("CLEAN: seeds %d..%d, %d comparisons of full X_Event arrays, %.0f s" % (lo, hi - 1, checks, time.time() - t0))
     return 0

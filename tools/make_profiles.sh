@@ -36,5 +36,7 @@ prof c3 --kind octree --steps 5 --warmup 1
 prof c3_262k --kind octree --rays 262144 --steps 8 --warmup 2
 prof c4shard --scene cathedral --domain 128 --rays 2097152 --steps 8 --warmup 2
 prof c5 --scene cathedral --domain 128 --bounces 8 --steps 3 --warmup 1
-KT_ONLY=1 prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
+prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
+prof kd_hall --kind kdtree --scene hall --rays 1048576 --steps 5 --warmup 1
+prof c2_quads --scene hall_quads --steps 10 --warmup 2
 ROUND=r05 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
