@@ -323,7 +323,9 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 // K2d (hare_octree_dense: K2p's DENSE build, kernels.hip): per workgroup of 256 lanes, behind the frames: HARE_K2D_PEND pending survivors per
 // lane (12 bytes each) and a 64-word table per wave
 #ifndef HARE_K2D_PEND
-#define HARE_K2D_PEND 2
+#define HARE_K2D_PEND 1            // round 5, re-swept after K3d's sweep said the same: 1 / 2 / 3 survivors per lane: 768 / 747 / 740 Mrays/s at 1M rays, 1 015 / 981 / 956
+                                   // at 4M, 314 / 313 / 305 at 262k (profiles/r05_experiments/k2d_pend.log): with one, a lane that holds a survivor is "blocked"
+                                   // and the exact phase runs in the same round -- the hit it finds prunes the walk behind it at once
 #define HARE_K2D_CAP 128
 #define HARE_K2D_EXACT_MIN 24
 #endif

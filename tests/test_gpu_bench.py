@@ -138,6 +138,8 @@ def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     assert rf["algorithmic_bytes_per_launch"] > 104 * j["config"]["rays_per_gpu"] * 0.5
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
     assert "timed region" in rf["kernel_ms_source"] or "event pair" in rf["kernel_ms_source"]     # ONE estimator, named
+    if "--bounces" not in extra:          # what a caller that alternates two streams gets: beside the contract's value, never instead of it
+        assert j["two_streams"]["value"] > 0.5 * j["value"] and j["two_streams"]["steps"] >= 2
     if "octree" not in extra:
         own = rf["own"]          # counted by the counting build of the kernel that was timed, on the same rays
         assert 0 < own["frac"] <= 1.0 and own["bytes_per_launch"] >= 104 * j["config"]["rays_per_gpu"]

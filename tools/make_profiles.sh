@@ -30,13 +30,15 @@ prof() {  # tag, bench args...
   # the bench line of the same command, un-profiled, with the oracle (roofline, cpu_baseline, parity)
   python3 $R/bench.py "$@" --no-extra-configs > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 }
-prof c2 --steps 20 --warmup 3
-prof c2_4M --rays 4194304 --steps 8 --warmup 2
-prof c3 --kind octree --steps 5 --warmup 1
-prof c3_262k --kind octree --rays 262144 --steps 8 --warmup 2
-prof c4shard --scene cathedral --domain 128 --rays 2097152 --steps 8 --warmup 2
-prof c5 --scene cathedral --domain 128 --bounces 8 --steps 3 --warmup 1
-prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
-prof kd_hall --kind kdtree --scene hall --rays 1048576 --steps 5 --warmup 1
-prof c2_quads --scene hall_quads --steps 10 --warmup 2
-ROUND=r05 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
+want() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }      # ONLY="c2 c3": a subset (one gpurun call holds ~3 configurations)
+want c2 && prof c2 --steps 20 --warmup 3
+want c2_4M && prof c2_4M --rays 4194304 --steps 8 --warmup 2
+want c3 && prof c3 --kind octree --steps 5 --warmup 1
+want c3_262k && prof c3_262k --kind octree --rays 262144 --steps 8 --warmup 2
+want c4shard && prof c4shard --scene cathedral --domain 128 --rays 2097152 --steps 8 --warmup 2
+want c5 && prof c5 --scene cathedral --domain 128 --bounces 8 --steps 3 --warmup 1
+want kd && prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
+want kd_hall && prof kd_hall --kind kdtree --scene hall --rays 1048576 --steps 5 --warmup 1
+want c2_quads && prof c2_quads --scene hall_quads --steps 10 --warmup 2
+echo "done: $ONLY" >> $O/progress.log
+[ -n "$NO_CONDENSE" ] || ROUND=r05 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
