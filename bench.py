@@ -412,7 +412,8 @@ def measure(w, env):
     # streams batches over TWO HIP streams gets -- one launch's drain runs under the next one's ramp (DESIGN.md 6 "Two streams").  Same
     # launches, same buffers in rotation, same events; reported as `two_streams`, never as `value`.
     two_streams = None
-    if B == 1 and dist is None and w.get("two_streams", False) and n_sets >= 2:
+    if B == 1 and dist is None and w.get("two_streams", False) and n_sets >= 2 and w["cpu_baseline"]:      # (not in the profiling runs, --no-cpu-baseline:
+        # launches that overlap would enter rocprofv3's per-kernel average, which is to agree with kernel_ms)
         ss = [torch.cuda.Stream(), torch.cuda.Stream()]
         k2 = max(4, steps)
         ne = n_sets - (n_sets % 2)                 # an even rotation: a buffer set always meets the same stream
@@ -677,6 +678,12 @@ def measure(w, env):
                     "own": own, "issue": issue, "measured_bound": "valu issue + dependent-load latency (not HBM)",
                     "hbm_busy_frac": None if traffic is None else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1)}
+        try:
+            if kind == "voxel" and B == 1 and n >= 1572864 and part.get_option("voxel_order") == 1:
+                # a large batch of primary rays: a step is the order pass + the pool kernel; kernel_ms is the step's
+                roofline["step_kernels"] = "hare_cost_order (~12 us per million rays) + " + kernel_name
+        except Exception:
+            pass
         if roofline["frac"] > 1.0:
             roofline["warning"] = "frac > 1: reference-priced numerator (SURVEY 8(d)), not a hardware fraction; read own.frac / issue.frac"
         if B > 1:
@@ -778,7 +785,7 @@ def compact_sub(sub: dict) -> dict:
         r["warning"] = "frac > 1: reference-priced; see own / issue"
     r["own"] = {k: own.get(k) for k in ("frac", "bytes_per_cast", "per_cast", "why") if own.get(k) is not None} if own else None
     r["issue"] = {k: issue.get(k) for k in ("frac", "lane_util")} if issue else None
-    for k in ("live_casts_per_pass", "bounce_loop_ms"):
+    for k in ("live_casts_per_pass", "bounce_loop_ms", "step_kernels"):
         if k in rf:
             r[k] = rf[k]
     out["roofline"] = r

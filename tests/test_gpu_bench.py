@@ -128,6 +128,8 @@ def test_bench_appends_configs_3_4_5_to_the_one_line():
     (("--kind", "octree"), OCTREE_KERNEL),
     (("--bounces", "3"), "hare_voxel_pool_tri"),
     (("--rays", "1048576"), "hare_voxel_pool_tri"),
+    (("--kind", "kdtree", "--scene", "shoebox"), "hare_kdtree_dense"),      # K3d: the kd-tree's production kernel, with its counting build
+    (("--scene", "hall_quads"), "hare_voxel_pool_quad"),                     # the quadrilateral build of the pool kernel
 ])
 def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     j = _bench(*(("--rays", "32768") if "--rays" not in extra else ()), "--steps", "2", "--warmup", "1", *extra)
@@ -140,7 +142,7 @@ def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
     assert "timed region" in rf["kernel_ms_source"] or "event pair" in rf["kernel_ms_source"]     # ONE estimator, named
     if "--bounces" not in extra:          # what a caller that alternates two streams gets: beside the contract's value, never instead of it
         assert j["two_streams"]["value"] > 0.5 * j["value"] and j["two_streams"]["steps"] >= 2
-    if "octree" not in extra:
+    if "octree" not in extra:             # (32 768 octree rays go to hare_octree_group, which has no counting build)
         own = rf["own"]          # counted by the counting build of the kernel that was timed, on the same rays
         assert 0 < own["frac"] <= 1.0 and own["bytes_per_launch"] >= 104 * j["config"]["rays_per_gpu"]
         assert own["per_cast"]["L"] >= own["per_cast"]["K"] >= own["per_cast"]["T"] > 0

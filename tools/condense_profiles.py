@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_sha)
 
 SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_octree_pool", "hare_octree_dense", "hare_octree_group", "hare_octree_tail", "hare_kdtree",
+         "hare_cost_order",        # the order pass in front of the pool kernel on large batches of primary rays: part of the cast
          "hare_reflect")
 NSHOOT = len(SHOOT) - 1          # the kernels a shoot consists of (hare_reflect is listed in the summary, not priced)
 ROUND = os.environ.get("ROUND", "r05")
