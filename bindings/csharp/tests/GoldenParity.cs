@@ -1,6 +1,6 @@
 // GoldenParity.cs -- pins this repo's oracle (and, when libhare_hip.so + a GPU are present, the HIP kernels) to the
 // REFERENCE implementation: runs PachydermAcoustic/Hare's own Voxel_Grid / Octree / KDTree .Shoot on the committed
-// config-1 inputs (and on case 2: exact ties, trees over two topologies) and compares every X_Event with the committed
+// config-1 inputs (and on case 2: exact ties, trees over two topologies; case 3: quadrilaterals) and compares every X_Event with the committed
 // expected records, bit for bit.
 //
 // It cannot run where this repo is built (no .NET toolchain there; DESIGN.md section 1) -- it is the recipe for
@@ -147,6 +147,42 @@ public static class GoldenParity
         return bad;
     }
 
+    // Case 3 (tests/golden/c3_quads.npz, written to <dir>/c3 by export_raw.py): QUADRILATERALS -- a room of rectangles, general convex
+    // and tilted quadrilaterals, coincident twins, mixed with triangles; rays aimed at corners, edge points, the diagonal both triangles of
+    // Quadrilateral.Intersect share (Hare_Geometry_Polygons.cs:731-823), and interiors.  Topology(Point[][]) makes a Quadrilateral of a
+    // four-corner polygon (Hare_Geometry_Topology.cs:288-291).
+    static int Case3(string dir)
+    {
+        if (!File.Exists(Path.Combine(dir, "params.txt"))) { Console.WriteLine("case 3 not exported (" + dir + "): skipped"); return 0; }
+        string[] p = File.ReadAllText(Path.Combine(dir, "params.txt")).Split(new[] { ' ', '\n', '\r' }, StringSplitOptions.RemoveEmptyEntries);
+        int D = int.Parse(p[0]), OD = int.Parse(p[1]), OP = int.Parse(p[2]), KDD = int.Parse(p[3]), KDP = int.Parse(p[4]), P = int.Parse(p[5]), N = int.Parse(p[6]);
+        double[] v = ReadF64(Path.Combine(dir, "polys.f64"));
+        int[] nv = ReadI32(Path.Combine(dir, "nverts.i32"));
+        double[] rays = ReadF64(Path.Combine(dir, "rays.f64"));
+        int[] excl1 = ReadI32(Path.Combine(dir, "excl1.i32"));
+        if (v.Length != P * 12 || nv.Length != P || rays.Length != N * 6 || excl1.Length != N) throw new InvalidDataException("case 3: sizes disagree with params.txt");
+        var polys = new Point[P][];
+        for (int k = 0; k < P; k++)
+        {
+            polys[k] = new Point[nv[k]];
+            for (int c = 0; c < nv[k]; c++) polys[k][c] = new Point(v[12 * k + 3 * c], v[12 * k + 3 * c + 1], v[12 * k + 3 * c + 2]);
+        }
+        var T = new Topology(polys);
+        T.Finish_Topology();
+        if (T.Polygon_Count != P) throw new InvalidDataException("case 3: Topology kept " + T.Polygon_Count + " of " + P + " polygons");
+        var model = new Topology[] { T };
+        Func<string, Rec[]> ev = name => ReadEvents(Path.Combine(dir, name + ".xev"), N);
+        int bad = 0;
+        var vox = new Voxel_Grid(model, D);
+        bad += Run("c3 voxel", vox, rays, null, ev("voxel"), 31);
+        bad += Run("c3 voxel_excl", vox, rays, excl1, ev("voxel_excl"), 32);
+        var oct = new Octree(model, OD, OP);
+        bad += Run("c3 octree", oct, rays, null, ev("octree"), 33);
+        bad += Run("c3 octree_excl", oct, rays, excl1, ev("octree_excl"), 34);
+        bad += Run("c3 kdtree", new KDTree(model, KDD, KDP), rays, null, ev("kdtree"), 35);
+        return bad;
+    }
+
     public static int Main(string[] args)
     {
         if (args.Length < 1) { Console.Error.WriteLine("usage: GoldenParity <dir written by tests/golden/export_raw.py> [--gpu]"); return 2; }
@@ -202,6 +238,7 @@ public static class GoldenParity
         if (gpu) Console.WriteLine("--gpu: rebuild with -p:DefineConstants=HARE_GPU and the shim sources (HareHip.cs, Gpu_Spatial_Partition.cs)");
 #endif
         bad += Case2(Path.Combine(dir, "c2"));
+        bad += Case3(Path.Combine(dir, "c3"));
         Console.WriteLine(bad == 0 ? "PINNED: the reference reproduces every committed X_Event bit for bit" : "MISMATCH: " + bad + " records differ");
         return bad == 0 ? 0 : 1;
     }

@@ -44,7 +44,28 @@ def main(out_dir=None):
         f.write(" ".join(str(int(x)) for x in G["params"]) + f" {tris.shape[0]} {n}\n")
     print(f"wrote {out_dir}: {tris.shape[0]} triangles, {n} rays, 5 event files")
     export_c2(os.path.join(out_dir, "c2"))
+    export_c3(os.path.join(out_dir, "c3"))
     return out_dir
+
+
+def export_c3(out_dir):
+    """Case 3 (tests/golden/c3_quads.npz): quadrilaterals.  polys.f64 is P x 4 x 3 (corner 3 unused for a triangle), nverts.i32 the corner
+    counts (3 or 4); rays.f64, excl1.i32 and the events voxel / voxel_excl / octree / octree_excl / kdtree as in case 1.
+    params.txt: D OD OP KDD KDP P N."""
+    os.makedirs(out_dir, exist_ok=True)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "c3_quads.npz"))
+    n = G["rays"].shape[0]
+    np.ascontiguousarray(G["verts"], "<f8").tofile(os.path.join(out_dir, "polys.f64"))
+    np.ascontiguousarray(G["nverts"], "<i4").tofile(os.path.join(out_dir, "nverts.i32"))
+    np.ascontiguousarray(G["rays"], "<f8").tofile(os.path.join(out_dir, "rays.f64"))
+    np.ascontiguousarray(G["excl1"], "<i4").tofile(os.path.join(out_dir, "excl1.i32"))
+    for name in ("voxel", "voxel_excl", "octree", "octree_excl", "kdtree"):
+        ev = np.ascontiguousarray(G[name])
+        assert ev.dtype.itemsize == 56 and len(ev) == n
+        ev.tofile(os.path.join(out_dir, name + ".xev"))
+    with open(os.path.join(out_dir, "params.txt"), "w") as f:
+        f.write(" ".join(str(int(x)) for x in G["params"]) + f" {len(G['nverts'])} {n}\n")
+    print(f"wrote {out_dir}: {len(G['nverts'])} polygons ({int((G['nverts'] == 4).sum())} quadrilaterals), {n} rays, 5 event files")
 
 
 def export_c2(out_dir):
