@@ -76,6 +76,18 @@ int main()
         check(hare_octree_get_nodes(oct.native(), boxes.data(), fc.data(), is.data(), ic.data(), it.data()));
         std::printf("selftest: %d polys, grid ct=%d/%d, %u list entries, octree %d nodes\n", topo.Polygon_Count(), fixed.info().ct,
                     adaptive.info().ct, start.back(), ti.n_nodes);
+        {   // options: set / read back / range check / unknown name; the memory figures are 0 on a scene that never saw a device
+            kd.SetOption("kdtree_kernel", 2);
+            fixed.SetOption("voxel_order", 0);
+            if (kd.GetOption("kdtree_kernel") != 2 || fixed.GetOption("voxel_order") != 0 || fixed.GetOption("voxel_tight") != 1) ++failures;
+            int64_t v = -1;
+            if (hare_scene_get_option(fixed.native(), "no_such_option", &v) != HARE_E_INVALID) ++failures;
+            if (hare_scene_get_option(fixed.native(), "voxel_tight", nullptr) != HARE_E_INVALID) ++failures;
+            if (hare_scene_set_option(fixed.native(), "voxel_order", 3) != HARE_E_INVALID) ++failures;
+            if (fixed.GetOption("voxel_tight_bytes") < 0 || oct.GetOption("octree_scratch_bytes") < 0) ++failures;
+            fixed.SetOption("voxel_order", 1);
+            kd.SetOption("kdtree_kernel", 0);
+        }
         std::vector<hare_ray> rays(1000);
         for (size_t i = 0; i < rays.size(); ++i) rays[i] = {2.5, 2.0, 1.5, std::cos(0.01 * i), std::sin(0.01 * i), 0.3};
         std::vector<hare_xevent> ev;
