@@ -91,6 +91,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_cost_order", &m->cost_order},
         {"hare_kdtree_dense", &m->kdtree_dense},
         {"hare_kdtree_dense_own", &m->kdtree_dense_own},
+        {"hare_kdtree_occl", &m->kdtree_occl},
         {"hare_kdtree_shoot_count", &m->kdtree_count},
         {"hare_reflect", &m->reflect},
         {"hare_occlusion", &m->occlusion},
@@ -99,6 +100,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_voxel_occl_tri_g", &m->voxel_occl_tri_g},
         {"hare_voxel_occl_quad_g", &m->voxel_occl_quad_g},
         {"hare_octree_occl", &m->octree_occl},
+        {"hare_octree_occl_any", &m->octree_occl_any},
         {"hare_events_pack_slim", &m->events_pack_slim},
         {"hare_live_count", &m->live_count},
         {"hare_scan_tiles", &m->scan_tiles},

@@ -23,6 +23,11 @@
 // as in K2d); other rays -- and every ray when the option octree_tight is off -- visit every node, as the reference does.
 //
 // OWN (hare_kdtree_dense_own; HARE_SHOOT_COUNT_OWN): the same kernel counting its own node fetches, list entries pre-culled and exact tests.
+// OCC (hare_kdtree_occl): the occlusion predicate without events (harness-defined, SURVEY.md 8(a) A9: occluded = the closest hit exists and
+// its t is below t_max).  KDTree.Shoot returns the smallest accepted t over ALL polygons, so the flag is "some polygon is accepted with
+// t < t_max": the walk ends at the first such hit, and a subtree whose tight box the ray enters at or beyond t_max cannot hold one (every
+// accepted t in there is >= the entry) -- the same prune as behind a hit, with t_max as the hit.  (The octree's flag kernel may NOT prune
+// by t_max: its reference walk is not a closest-hit query, F15; the kd-tree's is.)
 #ifndef HARE_K3D_STEPS
 #define HARE_K3D_STEPS 3          // node visits per round at most
 #endif
@@ -53,7 +58,7 @@ __device__ __forceinline__ float float_below(double x)
     return f;
 }
 
-template <bool OWN>
+template <bool OWN, bool OCC = false>
 __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO& io)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -92,6 +97,7 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
     int q = 0, qe = 0;              // the leaf in hand: items[q .. qe) still to pre-cull
     int np = 0;                     // survivors noted
     double closestT = kDblMax, bu = 0, bv = 0;
+    double tlim = kDblMax;          // OCC: t_max of this ray (the bound a subtree's entry is held against while no hit is held)
     int pid = -1;
     unsigned int nhits = 0, nrays = 0;
 
@@ -103,6 +109,13 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
     timeline(0);
 
     auto finish = [&]() {
+        if (OCC) {
+            const bool occ = hit && (io.tmax == nullptr || closestT < io.tmax[ray]);
+            io.occluded[ray] = occ ? 1 : 0;
+            if (occ) nhits++;                               // flags only: the batch counter `hits` counts occluded rays
+            alive = false;
+            return;
+        }
         XEventRec ev;
         if (hit) {
             ev.t = closestT; ev.u = bu; ev.v = bv;
@@ -170,6 +183,10 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                     } else {
                         nrays++;
                         live_lane = true;
+                        if (OCC) {
+                            tlim = io.tmax ? io.tmax[ray] : kDblMax;
+                            if (!(tlim == tlim)) tlim = kDblMax;            // a NaN t_max compares false with every t: never occluded, nothing to prune by
+                        }
                         cray = cull_ray(g, o.x, o.y, o.z, d.x, d.y, d.z);
                         tight_ok = g.tight != nullptr && fabs(o.x - g.tight_mid[0]) <= g.tight_rad && fabs(o.y - g.tight_mid[1]) <= g.tight_rad &&
                                    fabs(o.z - g.tight_mid[2]) <= g.tight_rad && fabs(d.x) < 1e300 && fabs(d.y) < 1e300 && fabs(d.z) < 1e300;
@@ -215,7 +232,7 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                     const int node = st_node[sp * nt + tid];
                     const float un = st_un[sp * nt + tid];
                     // holding a hit in front of the node's box: nothing in there can be accepted (t < closestT) -- dropped unfetched
-                    cur = (hit && closestT <= (double)un) ? -1 : node;
+                    cur = ((hit && closestT <= (double)un) || (OCC && tlim <= (double)un)) ? -1 : node;
                 }
                 if (cur >= 0) {
                     const KdDevNode nd = g.dnodes[cur];                     // one 128-byte line
@@ -245,8 +262,8 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                             double unL, ufL, unR, ufR;
                             box_entry(nd.tl, unL, ufL);
                             box_entry(nd.tr, unR, ufR);
-                            const bool okL = !((ufL < unL) | (ufL < 0) | (hit & (closestT <= unL)));
-                            const bool okR = !((ufR < unR) | (ufR < 0) | (hit & (closestT <= unR)));
+                            const bool okL = !((ufL < unL) | (ufL < 0) | (hit & (closestT <= unL)) | (OCC & (tlim <= unL)));
+                            const bool okR = !((ufR < unR) | (ufR < 0) | (hit & (closestT <= unR)) | (OCC & (tlim <= unR)));
                             ok1 = first_right ? okR : okL;
                             ok2 = first_right ? okL : okR;
                             un2 = first_right ? unL : unR;
@@ -336,9 +353,10 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
             const unsigned long long holding = __ballot(alive && np > 0);
             const unsigned long long blocked = __ballot(alive && np > 0 && (np >= P || over));
             if (holding != 0 && (blocked != 0 || __popcll(holding) >= HARE_K3D_EXACT_MIN)) {
+                bool decided = false;
 #pragma unroll 1
                 for (int k = 0; k < P; ++k) {
-                    const bool act = alive && k < np;
+                    const bool act = alive && k < np && !decided;
                     if (__ballot(act) == 0) break;
                     if (act) {
                         const int i = pend_w[k * nt + tid];
@@ -351,10 +369,12 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                                 closestT = t; bu = u; bv = v; pid = i;
                                 hit = true;
                             }
+                            if (OCC && (io.tmax == nullptr || closestT < io.tmax[ray])) decided = true;      // some polygon lies in front of t_max: the flag is 1
                         }
                     }
                 }
                 np = alive ? 0 : np;
+                if (OCC && decided) finish();
             }
             if (alive && q == qe && cur < 0 && sp == 0 && np == 0) finish();
         }
@@ -369,4 +389,6 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
 extern "C" {
 __global__ __launch_bounds__(256, HARE_K3D_WAVES_PER_EU) void hare_kdtree_dense(hare::KdArgs g, hare::ShootIO io) { kdtree_dense_body<false>(g, io); }
 __global__ __launch_bounds__(256, HARE_K3D_WAVES_PER_EU) void hare_kdtree_dense_own(hare::KdArgs g, hare::ShootIO io) { kdtree_dense_body<true>(g, io); }
+// the occlusion predicate, flags only (hare_occluded_* with events == NULL)
+__global__ __launch_bounds__(256, HARE_K3D_WAVES_PER_EU) void hare_kdtree_occl(hare::KdArgs g, hare::ShootIO io) { kdtree_dense_body<false, true>(g, io); }
 }

@@ -850,7 +850,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
 #define HARE_K2P_REFILL 8
 #define HARE_K2P_EXACT 1
 #endif
-    const int STEPS = DENSE ? HARE_K2D_STEPS : HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS, REFILL_MIN_IDLE = DENSE ? HARE_K2D_REFILL : HARE_K2P_REFILL,
+    // (DENSE: the refill threshold comes from the host -- launch.cpp: 16 idle lanes on long batches, 32 on short ones, where a wave's few
+    //  refills are better made of whole tickets)
+    const int STEPS = DENSE ? HARE_K2D_STEPS : HARE_K2P_STEPS, CULLS = HARE_K2P_CULLS,
+              REFILL_MIN_IDLE = DENSE ? ((io.refill_min_idle > 0 && io.refill_min_idle <= 64) ? io.refill_min_idle : HARE_K2D_REFILL) : HARE_K2P_REFILL,
               EXACT_MIN_PARKED = HARE_K2P_EXACT;
     const int RAY_CHUNK = io.static_rays > 0 ? io.static_rays : 128;      // the host sizes it by the batch (ShootIO::static_rays)
     const unsigned int n32 = (unsigned int)io.n;
@@ -1330,6 +1333,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                             closestT = t; bu = u; bv = v; pid = i;
                             hit = true;
                             if (closestT <= lk) ended = true;                                           // :233
+                            else if (OCC && (io.tmax == nullptr || closestT < io.tmax[ray])) ended = true;   // any hit below t_max decides the flag
                         }
                     }
                 }
@@ -1604,7 +1608,12 @@ __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_persis
 // K2t: the cooperative tail behind K2p (octree_coop.hip)
 __global__ __launch_bounds__(256) void hare_octree_tail(OctreeArgs g, ShootIO io) { octree_tail_body(g, io); }
 // the occlusion predicate on the same walk (flags only, any-hit early out); same launch geometry
-__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true>(g, io); }
+// (round 5: K2d's OCC build -- the dense walk with the any-hit early out; K2p's, which this was until then, had fallen behind the closest-hit
+//  kernel it was meant to beat: 457 against 784 Mrays/s at t_max = half the mean free path)
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true, true>(g, io); }
+// ... and K2p's stays for queries WITHOUT a t_max (any hit at all decides): there the first accepted test ends the ray, and testing a leaf's
+// entries at once beats deferring them -- 2356 against the dense build's 1627 Mrays/s
+__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl_any(OctreeArgs g, ShootIO io) { octree_persist_body<true>(g, io); }
 // K2d: K2p with its leaf entries spread densely over the wave and its exact tests deferred (octree_persist_body<.., DENSE>);
 // dynamic LDS = K2p's frames + kOctDenseExtra bytes per workgroup
 __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense(OctreeArgs g, ShootIO io) { octree_persist_body<false, true>(g, io); }

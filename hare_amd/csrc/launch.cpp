@@ -135,6 +135,7 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
 // never reach a kernel.
 // HARE_SHOOT_BOUNCE_LOOP is NOT among them: it is a question to hare_shoot_kernel_name (which reads it from the raw flags), never a mode
 // of a cast, and must not travel into ShootIO::flags where a device-side bit 32 would one day collide with it (ADVICE, round 4).
+constexpr uint32_t kFlagAnyHit = 0x40000u;         // internal (set below, never by a caller): a flags-only occlusion query without t_max
 constexpr uint32_t kPublicFlags = HARE_SHOOT_WRITEBACK_ORIGIN | HARE_SHOOT_COUNT_WORK | HARE_SHOOT_SIMPLE_KERNEL | HARE_SHOOT_RETIRED_RAYS | HARE_SHOOT_SLIM_EVENTS |
                                  HARE_SHOOT_COUNT_OWN;
 static_assert((kPublicFlags & HARE_SHOOT_BOUNCE_LOOP) == 0, "the kernel-name query bit never reaches a kernel");
@@ -220,6 +221,7 @@ int ticket_rays_for(const Scene& s, int64_t n, bool pool)
 //    occupancy bit per voxel, three on a coarser bitmap (round 2, before the cooperative tails: three fills everywhere).
 // Both thresholds scale with the CU count of the device the scene lives on.
 constexpr bool kOctreePoolDefault = false;
+constexpr int64_t kK2dShortBatchPerCu = 1280;      // K2d: below this many rays per CU (327 680 on 256 CUs) a wave is refilled at 32 idle lanes instead of 16
 
 // flags_only: an occlusion query without events (hare_occluded_* with events == NULL): the hare_*_occl kernels, which write the
 // flag and cut the traversal short; the simple kernels (counting, forced, kd-tree) write the flag after the full trace.
@@ -304,7 +306,11 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         const int levels = std::max(1, s.oct_levels);
         const bool small_tree = (int64_t)s.oct.nodes.size() < (1 << 23);
         if (!simple && !huge && small_tree && flags_only) {
-            if ((unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_occl)) {
+            if ((flags & kFlagAnyHit) && (unsigned)levels * 256u * 20u <= kLdsMax && have(&DeviceModule::octree_occl_any)) {
+                pick(Kern::OctOccl, "hare_octree_occl_any", &DeviceModule::octree_occl_any);      // no t_max: K2p's OCC build (tests a leaf at once)
+                return c;
+            }
+            if ((unsigned)levels * 256u * 20u + kOctDenseExtra <= kLdsMax && have(&DeviceModule::octree_occl)) {
                 pick(Kern::OctOccl, "hare_octree_occl", &DeviceModule::octree_occl);
                 return c;
             }
@@ -353,8 +359,13 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
         // densely, exact tests deferred -- the production kernel of KDTree.Shoot since round 5 wherever its node records exist for the
         // topology and its stack fits LDS (any depth hare_kdtree_build allows does); the one-ray-per-lane kernel (kdtree_kernel = 1) is the
         // A/B baseline, the fall-back, and what the flags-only occlusion predicate runs
-        const bool dense_ok = !simple && !huge && !flags_only && s.opt.kdtree_kernel != 1 && top < s.d_kd_dev.size() && s.d_kd_dev[top] != nullptr &&
-                              kd_dense_lds(s.kd.depth_reached) <= kLdsMax && have(&DeviceModule::kdtree_dense);
+        const bool dense_fits = !simple && !huge && s.opt.kdtree_kernel != 1 && top < s.d_kd_dev.size() && s.d_kd_dev[top] != nullptr &&
+                                kd_dense_lds(s.kd.depth_reached) <= kLdsMax;
+        if (dense_fits && flags_only && have(&DeviceModule::kdtree_occl)) {      // the flag without events: K3d's occlusion build (stops at the first hit below t_max)
+            pick(Kern::KdDense, "hare_kdtree_occl", &DeviceModule::kdtree_occl);
+            return c;
+        }
+        const bool dense_ok = dense_fits && !flags_only && have(&DeviceModule::kdtree_dense);
         if (dense_ok) {
             pick(Kern::KdDense, "hare_kdtree_dense", &DeviceModule::kdtree_dense);
             if (own) pick(Kern::KdDense, "hare_kdtree_dense_own", &DeviceModule::kdtree_dense_own);
@@ -540,6 +551,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         return HARE_E_INVALID;
     }
     if (flags_only) flags &= ~(uint32_t)SHOOT_WRITEBACK_ORIGIN & ~0xE000u;     // a predicate: rays are input only, no developer modes
+    if (flags_only && d_tmax == nullptr) flags |= kFlagAnyHit;
     // A live ray's own X_Event slot is its scratch in the pool kernels, and rays[] is re-read while events are written: the
     // buffers of one call must not alias (each other, the exclusion arrays, or the counters)
     {
@@ -800,7 +812,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // the kernel is compiled for HARE_K2P_WAVES_PER_EU waves per SIMD (= workgroups of 4 waves per CU); a persistent
             // grid must not exceed what is resident, or the extra workgroups start when the others have finished
             // 20 bytes x levels x 256 lanes per workgroup (interval + child word); the dense build: + its pending survivors and tables
-            const bool dense_k = f != nullptr && (f == M.octree_dense || f == M.octree_dense_own);
+            const bool dense_k = f != nullptr && (f == M.octree_dense || f == M.octree_dense_own || f == M.octree_occl);   // (the flags-only kernel is K2d's OCC build)
             const unsigned plds = (unsigned)g.max_depth * 256u * 20u + (dense_k ? kOctDenseExtra : 0u);
             unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = cus * per_cu;
@@ -809,6 +821,10 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // an octree ray costs ~10x a voxel ray: ticket atomics never bind.  K2p: 32 rays; K2d finishes rays sooner and likes 16
             // (8 / 16 / 24 / 32 rays per ticket: 1M rays 478 / 502 / 466 / 489 Mrays/s, 1.5M 553 / 570 / 569 / 563, 524k 353 / 354 / 348 / 346)
             sub.ticket_rays = s.opt.ticket_rays > 0 ? std::max(8, std::min(4096, s.opt.ticket_rays)) : (dense_k ? 16 : 32);
+            // K2d refills a wave when this many of its lanes are idle: 16 on long batches; on short ones (a wave draws only a few tickets) 32 --
+            // swept (k2d_refill_by_size.log), 16 / 24 / 32 / 48 idle lanes: 196 608 rays 247 / 249 / 251 / 251 Mrays/s, 262 144 317 / 336 / 341 / 340,
+            // 393 216 489 / 495 / 471 / 395, 524 288 559 / 556 / 558 / 530, 655 360 662 / 649 / 624 / 587, 1M 775 / 775 / 757 / 676
+            if (dense_k && !(s.opt.tune[0] > 0 && s.opt.tune[1] > 0)) sub.refill_min_idle = m < (int64_t)cus * kK2dShortBatchPerCu ? 32 : 16;
             sub.static_rays = static_chunk_rays(m, pgrid, true, dense_k);    // K2p: 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336; K2d: half
                                                                              // the share (393k rays 338 -> 418 Mrays/s, 524k 421 -> 474, 655k 393 -> 515)
             if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps

@@ -104,12 +104,12 @@ struct DeviceModule {
     hipFunction_t voxel_pool_tri_own = nullptr, voxel_pool_quad_own = nullptr, voxel_pool_tri_g_own = nullptr, voxel_pool_quad_g_own = nullptr;
     hipFunction_t octree_dense_own = nullptr;
     hipFunction_t cost_order = nullptr;                                    // order_kernels.hip
-    hipFunction_t kdtree_dense = nullptr, kdtree_dense_own = nullptr;      // K3d (kdtree_dense.hip) and its counting build
+    hipFunction_t kdtree_dense = nullptr, kdtree_dense_own = nullptr, kdtree_occl = nullptr;      // K3d (kdtree_dense.hip) and its counting build
     hipFunction_t voxel_bounce_tri = nullptr, voxel_bounce_quad = nullptr, voxel_bounce_tri_g = nullptr, voxel_bounce_quad_g = nullptr, counters_sum = nullptr;
     hipFunction_t octree = nullptr, octree_count = nullptr, octree_persist = nullptr, octree_pool = nullptr, octree_tail = nullptr, octree_group = nullptr, octree_group_tail = nullptr, octree_dense = nullptr;
     hipFunction_t kdtree = nullptr, kdtree_count = nullptr;
     hipFunction_t reflect = nullptr, occlusion = nullptr;
-    hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr;
+    hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr, octree_occl_any = nullptr;
     hipFunction_t events_pack_slim = nullptr;
     hipFunction_t live_count = nullptr, scan_tiles = nullptr, reflect_compact = nullptr, events_fill_miss = nullptr, events_expand = nullptr;
     hipFunction_t cull_audit = nullptr;

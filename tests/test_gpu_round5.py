@@ -216,3 +216,43 @@ def test_the_quadrilateral_pre_cull_never_rejects_a_hit(monkeypatch):
         assert cands == len(rays) * g.Model[0].Polygon_Count
         assert viol == 0, f"the pre-cull rejected {viol} true hits on quadrilaterals"
         assert culled > 0.5 * cands                                               # ... and quadrilaterals ARE culled now
+
+
+def test_kdtree_occlusion_flags_from_k3d_stop_early_and_agree_with_the_closest_hit():
+    """hare_kdtree_occl (K3d's OCC build): occluded = KDTree.Shoot hits and that closest hit has t < t_max.  The flags-only kernel ends a
+    ray at the first polygon accepted below t_max and skips subtrees the ray enters at or beyond t_max; the flag must equal the one
+    derived from the oracle's closest hit for t_max at 0.3 ... 3 x every ray's own hit distance, EXACTLY at it and one ulp either side,
+    infinite, NaN, negative, zero -- with exclusions, on the hall (every 512th burst ray) and an open soup, from both kernels."""
+    cases = []
+    m = H.scenes.hall()
+    cases.append((m.verts, m.nverts, H.scenes.burst_rays(1 << 20, m.size)[::512], (16, 8)))
+    v, nv, size = soup(n_tri=900, n_quad=300, seed=19)
+    cases.append((v, nv, soup_rays(20_000, size, seed=7), (9, 4)))
+    rng = np.random.default_rng(12)
+    for verts, nverts, rays, (depth, maxp) in cases:
+        kd, ko = H.KDTree([H.Topology(verts, nverts)], depth, maxp), po.KDTree([po.Topology(verts, nverts)], depth, maxp)
+        n = len(rays)
+        e1 = rng.integers(-1, len(nverts), n).astype(np.int32)
+        for excl in (None, e1):
+            ref, _ = ko.shoot(rays, excl1=excl, nthreads=16)
+            t = ref["t"].copy()
+            tmax = t * rng.choice([0.3, 0.999999, 1.0, 1.000001, 3.0], n)
+            tmax[1::7] = t[1::7]                                         # exactly the hit distance: not occluded (strict <)
+            tmax[2::7] = np.nextafter(t[2::7], np.inf)                   # one ulp beyond: occluded
+            tmax[3::11] = np.inf; tmax[4::11] = np.nan; tmax[5::11] = -1.0; tmax[6::11] = 0.0
+            miss = ref["hit"] == 0
+            tmax[miss] = rng.uniform(0.1, 30.0, int(miss.sum()))
+            want = ((ref["hit"] != 0) & (ref["t"] < tmax)).astype(np.int32)
+            kw = {} if excl is None else {"poly_origin1": excl}
+            for kern, name in ((0, "hare_kdtree_occl"), (1, "hare_kdtree_shoot")):
+                kd.set_option("kdtree_kernel", kern)
+                occ, c = kd.Occluded_batch(rays, tmax, events=False, **kw)
+                bad = np.nonzero(occ != want)[0]
+                assert bad.size == 0, (name, bad[:5], tmax[bad[:5]], ref[bad[:5]])
+                assert c["hits"] == int(want.sum())
+                occ_any, _ = kd.Occluded_batch(rays, None, events=False, **kw)
+                assert np.array_equal(occ_any, (ref["hit"] != 0).astype(np.int32)), name
+            kd.set_option("kdtree_kernel", 0)
+            ev_occ, ev = kd.Occluded_batch(rays, tmax, events=True, **kw)      # with events: the closest-hit cast + one compare
+            assert np.array_equal(ev_occ, want)
+            assert_events_equal(ev, ref, what="kd occlusion with events")

@@ -62,6 +62,25 @@ def main():
                 bad = same(got, want); checks += 1
                 if bad: print("MISMATCH", cfg, what, bad); return 1
         oc.set_option("octree_kernel", 0)
+
+        def occl_check(part, name, want_ev, r, ex1, ex2):
+            """The flags-only kernels (hare_*_occl*: a ray ends as soon as its flag is decided) against the closest-hit predicate."""
+            nonlocal checks
+            hits = want_ev["t"][want_ev["hit"] == 1]
+            scale = float(np.median(hits)) if hits.size else 1.0
+            for tm in (None, np.abs(rng.normal(0, 1, r.shape[0])) * scale):
+                occ = part.Occluded_batch(r, t_max=tm, poly_origin1=ex1, poly_origin2=ex2, events=False)[0]
+                want = (want_ev["hit"] == 1) if tm is None else ((want_ev["hit"] == 1) & (want_ev["t"] < tm))
+                checks += 1
+                if not np.array_equal(np.asarray(occ, bool), want):
+                    print("MISMATCH seed %d %s flags-only occlusion, t_max %s, %d flags differ" % (seed, name, "none" if tm is None else "drawn", int((np.asarray(occ, bool) != want).sum())))
+                    return False
+            return True
+        if seed % 2 == 1:
+            if not occl_check(oc, "octree %d/%d n=%d" % (depth, maxp, n), oref, rays, None, None): return 1
+            if not occl_check(oc, "octree %d/%d n=%d excl" % (depth, maxp, n), orefx, rays, e1, e2): return 1
+            if not occl_check(g, "voxel D=%d n=%d" % (D, n), ref, rays, None, None): return 1
+            if not occl_check(g, "voxel D=%d n=%d excl" % (D, n), refx, rays, e1, e2): return 1
         if seed % 5 == 0 and n >= 1000:
             # the device-resident bounce loop on this scene (open soups: many rays leave and are retired), both voxel kernels,
             # and the occlusion predicate on the first cast
@@ -106,6 +125,9 @@ def main():
                                             ("excl", kd.Shoot_batch(rays[:m], poly_origin1=e1[:m], poly_origin2=e2[:m])[0], krefx)):
                         bad = same(got, want); checks += 1
                         if bad: print("MISMATCH seed %d kd %d/%d kernel %d tight %d %s" % (seed, kdepth, maxp, kern, tight, what), bad); return 1
+            kd.set_option("kdtree_kernel", 0); kd.set_option("octree_tight", 1)
+            if not occl_check(kd, "kd %d/%d" % (kdepth, maxp), kref, rays[:m], None, None): return 1
+            if not occl_check(kd, "kd %d/%d excl" % (kdepth, maxp), krefx, rays[:m], e1[:m], e2[:m]): return 1
         if seed % 3 == 0:
             # the pool kernel through the cost order (voxel_order forced on: the rule only takes batches of 1.5M primary rays)
             g.set_option("voxel_order", 2)

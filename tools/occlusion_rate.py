@@ -27,7 +27,7 @@ def timed(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
-for kind, g in (("voxel D=%d" % D, H.Voxel_Grid([T], D)), ("octree 8/16", H.Octree([T], 8, 16))):
+for kind, g in (("voxel D=%d" % D, H.Voxel_Grid([T], D)), ("octree 8/16", H.Octree([T], 8, 16)), ("kdtree 16/8", H.KDTree([T], 16, 8))):
     ev, _ = g.Shoot_batch(rays)
     mfp = float(ev["t"][ev["hit"] != 0].mean())
     ms_shoot = timed(lambda: g.shoot_device(n, d_rays.data_ptr(), d_ev.data_ptr(), stream=st))
@@ -41,6 +41,10 @@ for kind, g in (("voxel D=%d" % D, H.Voxel_Grid([T], D)), ("octree 8/16", H.Octr
         d_occ.zero_()
         ms_flag = timed(lambda: g.occluded_device(n, d_rays.data_ptr(), 0, d_occ.data_ptr(), d_tmax=d_tmax.data_ptr(), stream=st))
         ok_flag = np.array_equal(d_occ.cpu().numpy(), want)
+        if f == float("inf"):      # ... and the same question asked WITHOUT a t_max array (the octree then gets hare_octree_occl_any)
+            d_occ.zero_()
+            ms_none = timed(lambda: g.occluded_device(n, d_rays.data_ptr(), 0, d_occ.data_ptr(), stream=st))
+            print("  t_max = NULL      : flags only %.3f ms (%5.0f Mrays/s), flags equal: %s" % (ms_none, n / ms_none / 1e3, np.array_equal(d_occ.cpu().numpy(), want)), flush=True)
         import ctypes as C
         occ = np.zeros(n, np.int32); evh = np.zeros(n, capi.XEVENT_DTYPE); ctr = capi.Counters()
 
