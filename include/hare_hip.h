@@ -328,7 +328,10 @@ HARE_API int hare_shoot_one(hare_scene *s, int32_t kind, int32_t top_index, hare
  *                    passed t_max without a hit below it pending (the pending-hit confirmation of Voxel_Grid.cs:705-709 is
  *                    kept: a hit counts when the reference would return it); the octree walk ends at the first hit below
  *                    t_max (no node is skipped for lying beyond t_max: with the reference's far-to-near order and early
- *                    return that would change which hit is "the" hit).  The flags are identical either way; the host call
+ *                    return that would change which hit is "the" hit); the kd-tree walk ends at the first accepted hit below
+ *                    t_max and never enters a subtree whose tight box the ray reaches at or beyond t_max (KDTree.Shoot returns
+ *                    the smallest accepted t over ALL polygons, so "some polygon is accepted below t_max" is its flag).  The
+ *                    flags are identical either way; the host call
  *                    then brings back 4 bytes per ray instead of 56.  counters: rays, and hits = number of occluded rays.
  * rays[] is never written. */
 HARE_API int hare_occluded_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
