@@ -365,7 +365,7 @@ HARE_API int hare_reflect_device(hare_scene *s, int32_t top_index, int64_t n, vo
  * wherever the pool kernel serves a batch, and bounces <= 16: ONE persistent launch (hare_voxel_bounce_*) in which every ray runs
  * through its casts on its own -- rays are independent across casts too, so no cast waits for the slowest ray of the one before.
  * Results are identical either way; measured on MI355X the single launch gains 2.5 % in the 100k-triangle hall and loses up to
- * 10 % in the 1M-triangle cathedral, hence the default.
+ * 10 % in the 1M-triangle cathedral (profiles/r04_experiments/EXPERIMENTS.md), hence the default.
  *   d_rays               n rays: READ AND OVERWRITTEN (work array; every ray's last reflection remains)
  *   d_excl1 / d_excl2    nullable, read only: poly_origin1 / poly_origin2 of cast 0 (a negative index excludes nothing)
  *   d_work               scratch, 2 n int32
