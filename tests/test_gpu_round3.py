@@ -268,6 +268,16 @@ def test_bounded_octree_occlusion_on_the_hall(hall):
     occ, c = oc.Occluded_batch(rays, tmax, events=False)
     want = _want(refo, tmax)
     assert np.array_equal(occ, want) and c["hits"] == int(want.sum())
+    # no t_max at all: any hit decides (round 5: hare_octree_occl_any, K2p's OCC build; with a t_max array the dense build, hare_octree_occl)
+    occ_any, c_any = oc.Occluded_batch(rays, None, events=False)
+    assert np.array_equal(occ_any, (refo["hit"] == 1).astype(np.int32)) and c_any["hits"] == int((refo["hit"] == 1).sum())
+    # ... and the same flags with exclusions, both builds
+    e1 = refo["poly_id"].astype(np.int32).copy(); e1[::3] = -1
+    refx, _ = po.Octree([To], 8, 16).shoot(rays[:50_000], excl1=e1[:50_000], nthreads=16)
+    occ_x, _ = oc.Occluded_batch(rays[:50_000], tmax[:50_000], poly_origin1=e1[:50_000], events=False)
+    assert np.array_equal(occ_x, _want(refx, tmax[:50_000]))
+    occ_xa, _ = oc.Occluded_batch(rays[:50_000], None, poly_origin1=e1[:50_000], events=False)
+    assert np.array_equal(occ_xa, (refx["hit"] == 1).astype(np.int32))
 
 
 # ---------------------------------------------------------------------------------------------------------------
