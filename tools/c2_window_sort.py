@@ -20,7 +20,9 @@ import hare_amd as H
 def main():
     D = int(os.environ.get("DOMAIN", 64)); KB = int(os.environ.get("BOUNCE", 0))
     mesh = H.scenes.SCENES[os.environ.get("SCENE", "hall")]()
-    g = H.Voxel_Grid([H.Topology(mesh.verts, mesh.nverts)], D)
+    KIND = os.environ.get("KIND", "voxel")          # octree / kdtree: the same estimate (a virtual grid of D voxels a side), physical permutations only
+    T0 = H.Topology(mesh.verts, mesh.nverts)
+    g = H.Voxel_Grid([T0], D) if KIND == "voxel" else (H.Octree([T0], 8, 16) if KIND == "octree" else H.KDTree([T0], 16, 8))
     st = torch.cuda.current_stream().cuda_stream
     V = np.asarray(mesh.verts).reshape(-1, 4, 3)[:, :3, :].reshape(-1, 3)
     lo, hi = V.min(0), V.max(0)
@@ -60,7 +62,7 @@ def main():
         def run_physical(perm):
             dr = torch.from_numpy(np.ascontiguousarray(rays[perm])).cuda(); out = torch.empty(N * 56, dtype=torch.uint8, device="cuda")
             de = None if excl is None else torch.from_numpy(np.ascontiguousarray(excl[perm])).cuda()
-            g.set_option("dev_order_ptr", 0)
+            if KIND == "voxel": g.set_option("dev_order_ptr", 0)
             t = timed(dr, out, de)
             ev = out.cpu().numpy().reshape(N, 56); back = np.empty_like(ev); back[perm] = ev
             return t, zlib.crc32(back.tobytes())
@@ -89,6 +91,9 @@ def main():
 
         def report(label, perm):
             tp, cp = run_physical(perm)
+            if KIND != "voxel":
+                print("   %-44s physical %.4f ms (%+.1f %%)%s" % (label, tp, 100 * (tp / t_base - 1), "" if cp == c0 else " EVENTS DIFFER"), flush=True)
+                return
             ti, ci = run_indirect(perm)
             print("   %-44s physical %.4f ms (%+.1f %%)%s | through order[] %.4f ms (%+.1f %%)%s"
                   % (label, tp, 100 * (tp / t_base - 1), "" if cp == c0 else " EVENTS DIFFER", ti, 100 * (ti / t_base - 1), "" if ci == c0 else " EVENTS DIFFER"), flush=True)
