@@ -28,6 +28,7 @@
 #include <type_traits>
 #include "hare_device.h"
 #include "hare_trace.h"
+#include "voxel_walk.h"
 
 using namespace hare;
 

@@ -77,11 +77,20 @@
 #ifndef HARE_K1Q_WIDE_WALK
 #define HARE_K1Q_WIDE_WALK 1      // ... and the walk looks several occupied voxels ahead, one per lane of the ray's group
 #endif
+#ifndef HARE_K1Q_HAND_WALK
+#define HARE_K1Q_HAND_WALK 1      // the DDA step loop of the walk phases as written by hand (voxel_walk.h); 0: the compiler's (A/B)
+#endif
 #ifndef HARE_K1Q_REFILL_MIN
 #define HARE_K1Q_REFILL_MIN 64    // set up new rays when this many slots are free (a full wave of set-ups)
 #endif
 
 namespace {
+
+#ifdef HARE_K1Q_STATS
+constexpr bool kK1qStats = true;
+#else
+constexpr bool kK1qStats = false;
+#endif
 
 // BOUNCE (hare_voxel_bounce_*, round 4): the whole specular bounce loop of a ray inside ONE launch.  Rays are independent, also across
 // casts: ray i's cast c + 1 needs nothing but ray i's cast c.  The launch-per-cast loop puts a chip-wide barrier between casts and
@@ -103,6 +112,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr unsigned S = kPoolSlots, R = kPoolRing, SM = kPoolRing - 1;   // slots; queue (ring) capacity and its mask
     uint32_t* const locc = reinterpret_cast<uint32_t*>(lds_raw);
+    // the bitmap's byte address in LDS, for the hand-written step loop (voxel_walk.h)
+    const unsigned lds_bitmap = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)lds_raw;
     const int nw4 = (g.occ_words + 3) >> 2;
     {
         const uint4* src = reinterpret_cast<const uint4*>(g.occ);
@@ -152,7 +163,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     unsigned hW = 0, nW = 0, hC = 0, nC = 0, hE = 0, nE = 0, hP = 0, nP = 0, hF = 0, nF = S;
     unsigned hR = 0, nR = 0;            // BOUNCE: slots whose hit stands and whose ray goes on to its next cast
 #ifdef HARE_K1Q_STATS                   // developer build (tools/k1q_stats.py): executions and active lanes of every phase; lane 0 counts
-    unsigned long long kq_n[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kq_l[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kq_steps = 0;
+    unsigned long long kq_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, kq_l[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, kq_steps = 0;   // [8]: steps inside pend-walk tasks
 #define K1Q_STAT(i, act) { kq_n[i]++; kq_l[i] += (unsigned long long)__popcll(__ballot(act)); }
 #else
 #define K1Q_STAT(i, act)
@@ -609,6 +620,18 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             const int n0 = __popcll(__ballot(walking));
             const int walk_min = tail ? 1 : (n0 / 3 < HARE_K1Q_WALK_MIN ? n0 / 3 : HARE_K1Q_WALK_MIN);
             const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : HARE_K1Q_WALK_STEPS;   // end of the launch: fewer, longer tasks
+#if HARE_K1Q_HAND_WALK
+            {
+                // the step loop written by hand (voxel_walk.h): the same steps, the per-axis updates under the axis' own EXEC mask
+                unsigned taken = 0, iters = 0;
+                hare_walk::walk_steps<COARSE, OWN || kK1qStats>(tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, X, Y, Z, dx1, dy1, dz1, walking, (unsigned)ct,
+                                                             (unsigned)walk_steps, (unsigned)walk_min, lds_bitmap, (unsigned)g.occ_shift, (unsigned)g.occ_cd, taken, iters);
+                if (OWN) own.cells += taken;
+#ifdef HARE_K1Q_STATS
+                kq_n[7] += iters; kq_l[7] += wave_sum_u32(taken);      // executions of the step; voxels walked into (lane 0 holds the sum)
+#endif
+            }
+#else
 #pragma unroll 1
             for (int k = 0; k < walk_steps; ++k) {
                 const unsigned long long wm = __ballot(walking);
@@ -625,6 +648,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if (OWN && !out) own.cells++;
                 }
             }
+#endif
             const bool exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
             bool to_cull = act && !walking && !exited;
             if (exited) store_miss(L_ray[slot]);                            // leaving the grid: miss
@@ -996,6 +1020,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #pragma unroll 1
             for (int k = 0; k < pend_steps; ++k) {
                 if (__ballot(walking) == 0) break;
+#ifdef HARE_K1Q_STATS
+                kq_n[8]++; kq_l[8] += (unsigned long long)__popcll(__ballot(walking));
+#endif
                 if (walking) {
                     // Voxel_Grid.cs:705: hit point inside the CURRENT padded voxel?
                     const double lox = voxel_lo(X, g.vd[0], g.omin[0]), hix = voxel_hi(X, g.vd[0], g.omin[0]);
@@ -1118,6 +1145,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     if (lane == 0 && io.prof) {
         for (int k = 0; k < 8; ++k) { atomicAdd(&io.prof[2 * k], kq_n[k]); atomicAdd(&io.prof[2 * k + 1], kq_l[k]); }
         atomicAdd(&io.prof[16], (unsigned long long)rounds_done);
+        atomicAdd(&io.prof[18], kq_n[8]); atomicAdd(&io.prof[19], kq_l[8]);
     }
     (void)kq_steps;
 #endif

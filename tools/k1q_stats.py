@@ -27,3 +27,6 @@ for k, nm in enumerate(names):
     ex, ln = c[8 + 2 * k], c[8 + 2 * k + 1]
     if ex:
         print("%-32s executions per ray %.4f   lanes per execution %.1f   lane-tasks per ray %.2f" % (nm, ex / r, ln / ex, ln / r))
+ex, ln = c[8 + 18], c[8 + 19]
+if ex:
+    print("%-32s executions per ray %.4f   lanes per execution %.1f   lane-tasks per ray %.2f" % ("pend step (inside pend walks)", ex / r, ln / ex, ln / r))
