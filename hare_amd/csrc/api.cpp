@@ -889,6 +889,7 @@ const OptionEntry kOptionTable[] = {
         {"batch_chunks", &SceneOptions::batch_chunks, 0, 16},
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},
         {"wide_drain", &SceneOptions::wide_drain, 0, 1},
+        {"voxel_walk", &SceneOptions::voxel_walk, 0, 1},
 };
 }  // namespace
 

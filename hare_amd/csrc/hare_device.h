@@ -442,6 +442,7 @@ struct ShootIO {
     unsigned long long* ctr_casts;   // nullable: bounce_casts counter blocks (rays = rays that started the cast, hits), accumulated
     const uint32_t* order;     // K1q, nullable: the ORDER in which the launch takes the batch's rays -- position k of the static chunks / tickets is ray
                                // order[k] (a permutation of 0 .. n-1; rays, events and exclusions stay where the caller has them)
+    int32_t hand_walk;         // K1q: 1 = the DDA step loop written by hand (voxel_walk.h), 0 = the compiler's (scene option "voxel_walk")
     unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
     int32_t oct_spill_cap;
 };

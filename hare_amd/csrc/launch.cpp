@@ -50,6 +50,7 @@ int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, un
     io.work = reinterpret_cast<unsigned int*>(static_cast<LaunchSlotMem*>(s.d_work) + idx);
     io.coop_tail = (coop_tail && s.opt.coop_tail) ? 1 : 0;
     io.wide_drain = s.opt.wide_drain ? 1 : 0;
+    io.hand_walk = s.opt.voxel_walk ? 1 : 0;
     io.oct_tail = nullptr;
     io.oct_spill = nullptr;
     io.oct_spill_cap = 0;

@@ -52,6 +52,7 @@ struct SceneOptions {
     int k2p_tail_patience = -1; // ... after this many rounds (-1 = the rule)
     int batch_chunks = 0;      // chunks hare_shoot_batch pipelines a batch over (0 = the host's rule)
     int coop_tail = 1;         // 1: a drained wave traces its last rays with all 64 lanes (voxel_coop.hip); 0: as lanes of the pool to the end (A/B)
+    int voxel_walk = 1;        // 1: K1q's DDA step loop as written by hand for gfx950 (voxel_walk.h: per-axis updates under EXEC masks); 0: the compiler's loop (A/B)
     int wide_drain = 1;        // 1: K1q's wide cull / wide walk in the drain of a launch (voxel_pool.hip); 0: the pool's ordinary phases to the end (A/B)
     long long dev_order_ptr = 0;   // developer experiments (a `dev` scene only): a device array of n uint32, the order K1q takes the rays in (ShootIO::order)
     int tune[5] = {0, 0, 0, 0, 0};   // HARE_TUNE: steps,refill,chunk,blocks_per_cu,exact (profiling build; blocks_per_cu: K1p)

@@ -205,6 +205,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     const bool coop = io.coop_tail != 0 && !writeback;
     unsigned tail_rounds = 0;        // rounds since the tickets ran dry
     const bool wide_on = io.wide_drain != 0;
+    const bool hand_walk = io.hand_walk != 0;     // scene option "voxel_walk": the hand-written step loop (voxel_walk.h) / the compiler's
 
     auto store_miss = [&](unsigned ray) {
         XEventRec ev;
@@ -498,6 +499,19 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 dx1 = (xf & F_NX) ? -1 : 1; dy1 = (xf & F_NY) ? -1 : 1; dz1 = (xf & F_NZ) ? -1 : 1;
             }
             bool walking = act, mine = false, exited = false;
+            unsigned lead_sub = 0u;                  // the lane of a group that holds the state the walk ENDED in
+            if (HARE_K1Q_HAND_WALK && hand_walk) {
+                // by hand (voxel_walk.h): lane `sub` passes `sub` occupied voxels and stops AT the next one -- its own -- or outside the grid;
+                // the lanes of a group run the same walk, so the group's last lane ends where the walk of all G voxels ends
+                unsigned taken = 0, iters = 0;
+                hare_walk::walk_steps<COARSE, OWN, true>(tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, X, Y, Z, dx1, dy1, dz1, walking, (unsigned)ct,
+                                                         (unsigned)HARE_K1Q_TAIL_STEPS, 1u, lds_bitmap, (unsigned)g.occ_shift, (unsigned)g.occ_cd, taken, iters, sub);
+                lead_sub = G - 1u;
+                exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
+                mine = act && !walking && !exited;
+                sX = tMaxX; sY = tMaxY; sZ = tMaxZ; vX = X; vY = Y; vZ = Z;
+                if (OWN && sub == lead_sub) own.cells += taken;              // the group's lanes run the same walk: counted once
+            } else {
             unsigned seen = 0;
 #pragma unroll 1
             for (int k = 0; k < HARE_K1Q_TAIL_STEPS; ++k) {
@@ -515,6 +529,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         walking = seen < G;
                     }
                 }
+            }
             }
             // the G voxels of a ray, one per lane: cell record, then its list in chunks of four (entries, then their records)
             bool surv = false;
@@ -581,7 +596,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             const bool has_stop = ms != 0u;
             const unsigned stop_sub = has_stop ? (unsigned)__builtin_ctz(ms) : 0u;
             const bool writer = act && has_stop && sub == stop_sub;          // the lane that holds the voxel the ray stops in
-            const bool lead = act && !has_stop && sub == 0u;                 // no stop: the ray walks on from where the walk ended, or has left the grid
+            const bool lead = act && !has_stop && sub == lead_sub;           // no stop: the ray walks on from where the walk ended, or has left the grid
             if (writer) {
                 L_tmx[slot] = sX; L_tmy[slot] = sY; L_tmz[slot] = sZ;
                 L_xyzf[slot] = (xf & 0xF8000000u) | (uint32_t)vX | ((uint32_t)vY << 9) | ((uint32_t)vZ << 18);
@@ -620,8 +635,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             const int n0 = __popcll(__ballot(walking));
             const int walk_min = tail ? 1 : (n0 / 3 < HARE_K1Q_WALK_MIN ? n0 / 3 : HARE_K1Q_WALK_MIN);
             const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : HARE_K1Q_WALK_STEPS;   // end of the launch: fewer, longer tasks
-#if HARE_K1Q_HAND_WALK
-            {
+            if (HARE_K1Q_HAND_WALK && hand_walk) {
                 // the step loop written by hand (voxel_walk.h): the same steps, the per-axis updates under the axis' own EXEC mask
                 unsigned taken = 0, iters = 0;
                 hare_walk::walk_steps<COARSE, OWN || kK1qStats>(tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, X, Y, Z, dx1, dy1, dz1, walking, (unsigned)ct,
@@ -630,8 +644,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #ifdef HARE_K1Q_STATS
                 kq_n[7] += iters; kq_l[7] += wave_sum_u32(taken);      // executions of the step; voxels walked into (lane 0 holds the sum)
 #endif
-            }
-#else
+            } else {
 #pragma unroll 1
             for (int k = 0; k < walk_steps; ++k) {
                 const unsigned long long wm = __ballot(walking);
@@ -648,7 +661,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if (OWN && !out) own.cells++;
                 }
             }
-#endif
+            }
             const bool exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
             bool to_cull = act && !walking && !exited;
             if (exited) store_miss(L_ray[slot]);                            // leaving the grid: miss

@@ -22,12 +22,13 @@ namespace hare_walk {
 // loop also ends once fewer than `min_lanes` lanes still walk (never before the first step).  On return `walking` is true for
 // lanes that have not stopped (the task's step budget ran out).  `lds_bitmap` = LDS byte address of the occupancy bitmap
 // (scene.h: occ_layout; COARSE: one bit per block of (2^occ_shift)^3 voxels, occ_cd blocks per axis).  COUNT: `taken` += voxels
-// walked into (inside the grid) by this lane; `iters` += executions of the step (wave-uniform).  Must be called in wave-uniform control flow.
-template <bool COARSE, bool COUNT>
+// walked into (inside the grid) by this lane; `iters` += executions of the step (wave-uniform).  SKIP (the wide walk of the drain): a lane
+// passes `skip` occupied voxels and stops at the next one.  Must be called in wave-uniform control flow.
+template <bool COARSE, bool COUNT, bool SKIP = false>
 __device__ __forceinline__ void walk_steps(double& tMaxX, double& tMaxY, double& tMaxZ, const double tDeltaX, const double tDeltaY,
                                            const double tDeltaZ, int& X, int& Y, int& Z, const int dx1, const int dy1, const int dz1,
                                            bool& walking, const unsigned ct, const unsigned max_steps, const unsigned min_lanes,
-                                           const unsigned lds_bitmap, const unsigned occ_shift, const unsigned occ_cd, unsigned& taken, unsigned& iters)
+                                           const unsigned lds_bitmap, const unsigned occ_shift, const unsigned occ_cd, unsigned& taken, unsigned& iters, unsigned skip = 0u)
 {
     unsigned long long wm = __ballot(walking);
     if (wm == 0ull) return;
@@ -78,15 +79,28 @@ __device__ __forceinline__ void walk_steps(double& tMaxX, double& tMaxY, double&
         "v_mad_u32_u24 %[t0], %[t0], %[cd], %[t1]\n\t"                                                          \
         "v_lshrrev_b32_e32 %[t1], %[sh], %[Z]\n\t"                                                              \
         "v_mad_u32_u24 %[t0], %[t0], %[cd], %[t1]\n\t"
-#define HARE_WALK_TAIL                                                                                          \
+#define HARE_WALK_LOOKUP                                                                                        \
         "v_lshrrev_b32_e32 %[t1], 5, %[t0]\n\t"                                                                 \
         "v_lshl_add_u32 %[t1], %[t1], 2, %[base]\n\t"                                                           \
         "ds_read_b32 %[t1], %[t1]\n\t"                                                                          \
         "s_waitcnt lgkmcnt(0)\n\t"                                                                              \
-        "v_bfe_u32 %[t1], %[t1], %[t0], 1\n\t"       /* bit t0 & 31 of the word */                             \
+        "v_bfe_u32 %[t1], %[t1], %[t0], 1\n\t"       /* bit t0 & 31 of the word */
+#define HARE_WALK_STOP_FIRST                         /* a lane stops at the first occupied voxel (block) */     \
         "v_cmp_eq_u32_e32 vcc, 0, %[t1]\n\t"                                                                    \
-        "s_and_b64 exec, exec, vcc\n\t"              /* lanes in an occupied voxel (block) stop */             \
-        "s_cbranch_execz 2f\n\t"                                                                                \
+        "s_and_b64 exec, exec, vcc\n\t"                                                                         \
+        "s_cbranch_execz 2f\n\t"
+#define HARE_WALK_STOP_SKIP                          /* ... at the occupied voxel after `skip` others */        \
+        "v_cmp_ne_u32_e32 vcc, 0, %[t1]\n\t"                                                                    \
+        "s_and_b64 %[ma], exec, vcc\n\t"             /* lanes in an occupied voxel */                          \
+        "s_cbranch_scc0 3f\n\t"                                                                                 \
+        "s_mov_b64 %[mw], exec\n\t"                                                                             \
+        "s_mov_b64 exec, %[ma]\n\t"                                                                             \
+        "v_cmp_eq_u32_e32 vcc, 0, %[skip]\n\t"       /* it is theirs: they stop */                             \
+        "v_add_u32_e32 %[skip], -1, %[skip]\n\t"     /* the others have one fewer to pass */                   \
+        "s_andn2_b64 exec, %[mw], vcc\n\t"                                                                      \
+        "s_cbranch_execz 2f\n"                                                                                  \
+        "3:\n\t"
+#define HARE_WALK_END                                                                                           \
         "s_cmp_ge_u32 %[k], %[steps]\n\t"                                                                       \
         "s_cbranch_scc1 2f\n\t"                                                                                 \
         "s_bcnt1_i32_b64 %[cnt], exec\n\t"                                                                      \
@@ -99,22 +113,27 @@ __device__ __forceinline__ void walk_steps(double& tMaxX, double& tMaxY, double&
 #define HARE_WALK_OPERANDS                                                                                      \
         : [tx] "+&v"(tMaxX), [ty] "+&v"(tMaxY), [tz] "+&v"(tMaxZ), [X] "+&v"(X), [Y] "+&v"(Y), [Z] "+&v"(Z), [nt] "+&v"(nt),               \
           [wm] "+&s"(wm), [k] "+&s"(k), [sv] "=&s"(sv), [ma] "=&s"(ma), [mb] "=&s"(mb), [mw] "=&s"(mw), [cnt] "=&s"(cnt),             \
-          [t0] "=&v"(t0), [t1] "=&v"(t1), [still] "=&v"(still)                                                                      \
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [still] "=&v"(still), [skip] "+&v"(skip)                                                                    \
         : [dtx] "v"(tDeltaX), [dty] "v"(tDeltaY), [dtz] "v"(tDeltaZ), [dx1] "v"(dx1), [dy1] "v"(dy1), [dz1] "v"(dz1),               \
           [ct] "s"(s_ct), [steps] "s"(s_steps), [wmin] "s"(s_min), [base] "s"(s_base), [sh] "s"(s_sh), [cd] "s"(s_cd)             \
         : "vcc", "scc"
-    if (COARSE) {
-        if (COUNT) asm volatile(HARE_WALK_HEAD HARE_WALK_COUNT HARE_WALK_BIT_COARSE HARE_WALK_TAIL HARE_WALK_OPERANDS);
-        else       asm volatile(HARE_WALK_HEAD HARE_WALK_BIT_COARSE HARE_WALK_TAIL HARE_WALK_OPERANDS);
+#define HARE_WALK_ASM(COUNT_, BIT_, STOP_) asm volatile(HARE_WALK_HEAD COUNT_ BIT_ HARE_WALK_LOOKUP STOP_ HARE_WALK_END HARE_WALK_OPERANDS)
+    if (SKIP) {
+        if (COARSE) { if (COUNT) HARE_WALK_ASM(HARE_WALK_COUNT, HARE_WALK_BIT_COARSE, HARE_WALK_STOP_SKIP); else HARE_WALK_ASM("", HARE_WALK_BIT_COARSE, HARE_WALK_STOP_SKIP); }
+        else        { if (COUNT) HARE_WALK_ASM(HARE_WALK_COUNT, HARE_WALK_BIT_FINE, HARE_WALK_STOP_SKIP);   else HARE_WALK_ASM("", HARE_WALK_BIT_FINE, HARE_WALK_STOP_SKIP); }
     } else {
-        if (COUNT) asm volatile(HARE_WALK_HEAD HARE_WALK_COUNT HARE_WALK_BIT_FINE HARE_WALK_TAIL HARE_WALK_OPERANDS);
-        else       asm volatile(HARE_WALK_HEAD HARE_WALK_BIT_FINE HARE_WALK_TAIL HARE_WALK_OPERANDS);
+        if (COARSE) { if (COUNT) HARE_WALK_ASM(HARE_WALK_COUNT, HARE_WALK_BIT_COARSE, HARE_WALK_STOP_FIRST); else HARE_WALK_ASM("", HARE_WALK_BIT_COARSE, HARE_WALK_STOP_FIRST); }
+        else        { if (COUNT) HARE_WALK_ASM(HARE_WALK_COUNT, HARE_WALK_BIT_FINE, HARE_WALK_STOP_FIRST);   else HARE_WALK_ASM("", HARE_WALK_BIT_FINE, HARE_WALK_STOP_FIRST); }
     }
+#undef HARE_WALK_ASM
+#undef HARE_WALK_LOOKUP
+#undef HARE_WALK_STOP_FIRST
+#undef HARE_WALK_STOP_SKIP
+#undef HARE_WALK_END
 #undef HARE_WALK_HEAD
 #undef HARE_WALK_COUNT
 #undef HARE_WALK_BIT_FINE
 #undef HARE_WALK_BIT_COARSE
-#undef HARE_WALK_TAIL
 #undef HARE_WALK_OPERANDS
     walking = still != 0u;
     taken = nt;

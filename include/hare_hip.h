@@ -192,6 +192,8 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "coop_tail"       1 (default): a wave that has drawn its last rays traces the last few with all 64 lanes (heavy rays); 0: off
  *   "wide_drain"      1 (default): the pool kernel spends the lanes its finished rays leave on the rays that remain (several lanes per
  *                     ray: its candidates four per lane, the occupied voxels ahead one per lane); 0: off.  Results never depend on it
+ *   "voxel_walk"      1 (default): the pool kernel's DDA step loop (Voxel_Grid.cs:713-759) as written by hand for gfx950 -- the per-axis
+ *                     updates under the axis' own EXEC mask; 0: the compiler's loop (A/B).  The same steps in the same order: results never depend on it
  *   "octree_tight"    1 (default): the octree and kd-tree kernels drop a node whose subtree's polygons the ray cannot hit -- per node the box of
  *                     all polygons its subtree lists, built when the tree goes to the device; 0: every node the reference visits.  Results never
  *                     depend on it (an X_Event is the reference's bit for bit either way)

@@ -1,0 +1,158 @@
+"""Round 6.  K1q's DDA step loop written by hand for gfx950 (hare_amd/csrc/voxel_walk.h; scene option `voxel_walk`): the per-axis updates
+of Voxel_Grid.cs:713-759 under the axis' own EXEC mask instead of selects, in the pool's ordinary walk and in the wide walk of the drain.
+It must be the same steps in the same order -- same voxels, same tMax bit patterns, same events -- so every case is run three ways: the
+hand-written loop, the compiler's loop, the oracle.  The cases sit where a step loop can go wrong: grids of 1 ... 200 voxels a side (a
+bit per voxel, per 2^3 block at 128, per 4^3 at 200), origins outside the grid and exactly on voxel faces, directions with zero /
+negative-zero / denormal / huge components and NaN (every compare false: the z axis steps), both exclusions, exact ties, quadrilaterals,
+batches of one ray ... a million (a thin batch runs the wide walk from its second round on), the bounce loop cast by cast."""
+import numpy as np
+import pytest
+
+import hare_amd as H
+from oracle import pyoracle as po
+from tests.helpers import assert_events_equal, oracle_bounce_loop, soup, soup_rays
+from tests.test_gpu_ties import tie_rays, tie_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def three_ways(g, o, rays, what, **kw):
+    okw = {("excl1" if k == "poly_origin1" else "excl2"): v for k, v in kw.items() if k.startswith("poly_origin")}
+    ref, rc = o.shoot(rays, nthreads=16, **okw)
+    for walk in (1, 0):
+        g.set_option("voxel_walk", walk)
+        assert g.get_option("voxel_walk") == walk
+        ev, c = g.Shoot_batch(rays, **kw)
+        assert_events_equal(ev, ref, what=f"{what} voxel_walk={walk}")
+        assert c["hits"] == rc["hits"]
+    g.set_option("voxel_walk", 1)
+    return ref
+
+
+def awkward_rays(size, vd_hint, n=24_000, seed=5):
+    """Origins inside, outside and exactly on multiples of a voxel edge; directions with exact zeros, negative zeros, denormals, huge and
+    tiny magnitudes, axis-parallel, exact diagonals (tMax ties on every step), NaN and infinite components."""
+    rng = np.random.default_rng(seed)
+    r = soup_rays(n, size, seed=seed + 1)
+    k = np.arange(n)
+    r[k % 11 == 0, 3] = 0.0
+    r[k % 11 == 1, 4] = -0.0
+    r[k % 11 == 2, 5] = 5e-324
+    r[k % 13 == 3, 3:] *= 1e200
+    r[k % 13 == 4, 3:] *= 1e-200
+    ax = k % 17 == 5
+    r[ax, 3:] = np.eye(3)[rng.integers(0, 3, ax.sum())] * rng.choice([-1.0, 1.0], ax.sum())[:, None]
+    dg = k % 17 == 6
+    r[dg, 3:] = rng.choice([-1.0, 1.0], (dg.sum(), 3))                        # |dx| = |dy| = |dz|: the three tMax sequences tie again and again
+    on = k % 7 == 3
+    r[on, :3] = np.round(r[on, :3] / vd_hint) * vd_hint                       # origins on voxel faces / edges / corners of a lattice
+    r[k % 97 == 9, 3] = np.nan
+    r[k % 97 == 10, 1] = np.nan
+    r[k % 97 == 11, 4] = np.inf
+    r[k % 97 == 12, 5] = -np.inf
+    return np.ascontiguousarray(r)
+
+
+def test_hand_written_walk_equals_the_compilers_and_the_oracle_on_awkward_rays():
+    v, nv, size = soup(n_tri=700, n_quad=300, seed=21)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rng = np.random.default_rng(1)
+    for D in (1, 2, 7, 8, 33, 64, 67, 128, 200):
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        rays = awkward_rays(size, vd_hint=(size[0] + 0.202) / D, seed=D)
+        assert g.kernel_name(len(rays)).startswith("hare_voxel_pool"), (D, g.kernel_name(len(rays)))
+        ref = three_ways(g, o, rays, f"awkward D={D}")
+        e1 = np.where(rng.random(len(rays)) < 0.5, ref["poly_id"], rng.integers(-1, len(nv), len(rays))).astype(np.int32)
+        e2 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+        three_ways(g, o, rays, f"awkward D={D} excl", poly_origin1=e1, poly_origin2=e2)
+        if D in (8, 64, 128):                       # origin write-back (Voxel_Grid.cs:573-581 moves R): the moved origins too
+            refm, _, moved = o.shoot(rays, mutate=True)
+            for walk in (1, 0):
+                g.set_option("voxel_walk", walk)
+                r = rays.copy()
+                ev, _ = g.Shoot_batch(r, writeback_origin=True)
+                ok = ~np.isnan(moved).any(axis=1)   # NaN payload bits of a moved NaN origin are not part of the contract
+                assert_events_equal(ev, refm, what=f"awkward D={D} write-back voxel_walk={walk}")
+                assert np.array_equal(r[ok].view(np.int64), moved[ok].view(np.int64))
+                assert np.array_equal(np.isnan(r), np.isnan(moved))
+            g.set_option("voxel_walk", 1)
+
+
+def test_hand_written_walk_on_exact_ties():
+    v, nv, size = tie_scene()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = tie_rays(v, nv, size, n=6000)
+    for D in (1, 8, 21, 64, 128):
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        ref = three_ways(g, o, rays, f"ties D={D}")
+        three_ways(g, o, rays, f"ties D={D} excl", poly_origin1=ref["poly_id"].astype(np.int32))
+
+
+@pytest.mark.parametrize("scene,domain,n", [("hall", 64, 1 << 20), ("hall", 128, 300_000), ("hall", 200, 300_000), ("cathedral", 128, 400_000)])
+def test_hand_written_walk_at_bench_scale(scene, domain, n):
+    """The bench's own workloads: the 1M-ray burst into the hall at D = 64 in one piece; the per-block bitmaps (D = 128: 2^3, D = 200: 4^3)."""
+    m = H.scenes.SCENES[scene]()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    g, o = H.Voxel_Grid([T], domain), po.VoxelGrid([To], domain=domain)
+    rays = H.scenes.burst_rays(n, m.size)
+    ref, rc = o.shoot(rays, nthreads=32)
+    for walk in (1, 0):
+        g.set_option("voxel_walk", walk)
+        for wide in (1, 0):                         # the wide walk of the drain runs the hand-written loop too
+            g.set_option("wide_drain", wide)
+            ev, c = g.Shoot_batch(rays)
+            assert_events_equal(ev, ref, what=f"{scene} D={domain} voxel_walk={walk} wide_drain={wide}")
+            assert c["hits"] == rc["hits"]
+    g.set_option("voxel_walk", 1); g.set_option("wide_drain", 1)
+    # thin batches: spread over all waves, in the drain (wide walk, cooperative tail) from the second round on
+    for k in (1, 63, 64, 1000, 9216, 70_000):
+        for walk in (1, 0):
+            g.set_option("voxel_walk", walk)
+            ev, _ = g.Shoot_batch(rays[:k])
+            assert_events_equal(ev, ref[:k], what=f"{scene} D={domain} {k} rays voxel_walk={walk}")
+    g.set_option("voxel_walk", 1)
+
+
+def test_hand_written_walk_in_the_bounce_loop():
+    """Reflected rays start on a polygon, often exactly on a voxel face, and skim walls: cast by cast against the oracle's loop, a launch
+    per cast and the one-launch loop, hand-written and compiler's step loop."""
+    for scene, D, n in (("hall", 64, 120_000), ("cathedral", 128, 60_000)):
+        m = H.scenes.SCENES[scene]()
+        T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+        rays = H.scenes.burst_rays(n, m.size)
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        ref, rc = oracle_bounce_loop(po, To, o, rays, 6)
+        for walk in (1, 0):
+            g.set_option("voxel_walk", walk)
+            for fused in (0, 1):
+                g.set_option("bounce_fused", fused)
+                ev, c, pcs = g.Bounce_batch(rays, 6, per_cast=True, all_casts=True)
+                for b in range(6):
+                    assert_events_equal(ev[b], ref[b], what=f"{scene} bounce cast {b} voxel_walk={walk} fused={fused}")
+                assert [(p["rays"], p["hits"]) for p in pcs] == [(p["rays"], p["hits"]) for p in rc]
+        g.set_option("bounce_fused", 0); g.set_option("voxel_walk", 1)
+
+
+def test_own_work_counters_do_not_depend_on_the_step_loop():
+    """HARE_SHOOT_COUNT_OWN counts the voxels the kernel walks into inside the hand-written loop (a per-lane counter under EXEC): the same
+    totals as the compiler's loop counts, ray for ray the same events."""
+    import torch
+    from hare_amd import capi
+    for scene, D in (("hall", 64), ("cathedral", 128)):
+        m = H.scenes.SCENES[scene]()
+        g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], D)
+        n = 300_000
+        d_rays = torch.from_numpy(H.scenes.burst_rays(n, m.size)).cuda()
+        d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+        got = {}
+        for walk in (1, 0):
+            g.set_option("voxel_walk", walk)
+            d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+            assert g.kernel_name(n, flags=capi.SHOOT_COUNT_OWN).endswith("_own")
+            g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(), flags=capi.SHOOT_COUNT_OWN)
+            torch.cuda.synchronize()
+            got[walk] = (d_out.cpu().numpy().tobytes(), [int(x) for x in d_ctr.cpu()])
+        g.set_option("voxel_walk", 1)
+        assert got[1][0] == got[0][0], scene
+        assert got[1][1] == got[0][1], (scene, got[1][1], got[0][1])
+        assert got[1][1][0] == n and got[1][1][2] > 10 * n          # rays; voxels walked into
