@@ -188,8 +188,8 @@ void hare_scene_destroy(hare_scene* s)
             if (e) { (void)H->EventSynchronize(e); (void)H->EventDestroy(e); e = nullptr; }
         for (int k = 0; k < Scene::kOrderRing; ++k) {
             if (s->order_ev[k]) { (void)H->EventSynchronize(s->order_ev[k]); (void)H->EventDestroy(s->order_ev[k]); s->order_ev[k] = nullptr; }
-            dev_free(H, s->d_order[k]);
         }
+        dev_free(H, s->d_order);
         if (s->stream) (void)H->StreamDestroy(s->stream);
     }
     delete s;
@@ -878,6 +878,7 @@ const OptionEntry kOptionTable[] = {
         {"octree_tight", &SceneOptions::octree_tight, 0, 1},
         {"voxel_tight", &SceneOptions::voxel_tight, 0, 1},
         {"voxel_order", &SceneOptions::voxel_order, 0, 2},
+        {"voxel_order_max_rays", &SceneOptions::voxel_order_max_rays, 0, 0x7FFF0000},
         {"voxel_tight_max_mb", &SceneOptions::voxel_tight_max_mb, 0, 1 << 30},
         {"dev_fail_cellbox_alloc", &SceneOptions::dev_fail_cellbox_alloc, 0, 1},
         {"bounce_fused", &SceneOptions::bounce_fused, 0, 1},
@@ -905,6 +906,14 @@ int hare_scene_get_option(const hare_scene* s, const char* name, int64_t* value)
             for (void* p : s->d_cellbox)
                 if (p) bytes += (int64_t)s->vox.ct * s->vox.ct * s->vox.ct * 8 * (int64_t)sizeof(float);
         *value = bytes;
+        return HARE_OK;
+    }
+    if (strcmp(name, "voxel_order_bytes") == 0) {
+        *value = (int64_t)((size_t)Scene::kOrderRing * s->order_cap * sizeof(uint32_t));
+        return HARE_OK;
+    }
+    if (strcmp(name, "hip_malloc_calls") == 0 || strcmp(name, "hip_free_calls") == 0 || strcmp(name, "hip_sync_calls") == 0) {
+        *value = (int64_t)hip_call_count(name[4] == 'm' ? 0 : (name[4] == 'f' ? 1 : 2));
         return HARE_OK;
     }
     if (strcmp(name, "octree_scratch_bytes") == 0) {
@@ -942,6 +951,25 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
             // is not thread-safe against shoots on the same scene.
             const bool box_option = t.field == &SceneOptions::voxel_tight || t.field == &SceneOptions::voxel_tight_max_mb ||
                                     t.field == &SceneOptions::dev_fail_cellbox_alloc;
+            // the order ring follows "voxel_order" / "voxel_order_max_rays" the same way (reserve_order_ring: reserved, resized or released now,
+            // never inside a shoot)
+            const bool ring_option = t.field == &SceneOptions::voxel_order || t.field == &SceneOptions::voxel_order_max_rays;
+            if (ring_option && s->vox.built && !s->d_cells.empty() && s->module) {
+                const HipApi* H = hip_api(nullptr);
+                if (!H) return HARE_OK;
+                DeviceGuard dev_guard(H, s->device);
+                reserve_order_ring(*s, H);
+                return HARE_OK;
+            }
+            const bool oct_option = t.field == &SceneOptions::octree_kernel || t.field == &SceneOptions::octree_tail ||
+                                    t.field == &SceneOptions::k2p_tail_max || t.field == &SceneOptions::k2p_tail_patience;
+            if (oct_option && s->oct.built && s->d_oct_nodes && s->module) {        // the octree scratch ring is sized by these (reserve_oct_scratch)
+                const HipApi* H = hip_api(nullptr);
+                if (!H) return HARE_OK;
+                DeviceGuard dev_guard(H, s->device);
+                reserve_oct_scratch(*s, H);
+                return HARE_OK;
+            }
             if (box_option && s->vox.built && !s->d_cells.empty() && s->module) {
                 const bool rebuild = t.field == &SceneOptions::voxel_tight ? (value != 0 && s->cellbox_rad <= 0) : true;
                 if (rebuild) {

@@ -387,8 +387,37 @@ bool pool_can_serve(const Scene& s)
     const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u;
     return lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes <= 160u * 1024u && s.vox.ct <= 512;
 }
+// The order ring of the pool kernel (scene.h; launch.cpp: the order pass of hare_cost_order): reserved HERE, when the grid goes to the device
+// (every builder ends in upload_cell_boxes) and when the options that size it change -- single-caller moments by contract, nothing of the
+// scene in flight -- so that a shoot never allocates.  kOrderRing blocks of `voxel_order_max_rays` entries, one allocation; the ring
+// exists only while "voxel_order" is on and the pool kernel serves the grid.  A failed allocation is "no ring" (casts run in the caller's
+// order, same events), never a failed build; hare_scene_get_option "voxel_order_bytes" says what is held.
+void reserve_order_ring(Scene& s, const HipApi* H)
+{
+    if (!H) return;
+    const bool want_ring = s.opt.voxel_order != 0 && s.opt.voxel_order_max_rays > 0 && s.vox.built && pool_can_serve(s) && s.module && s.module->cost_order;
+    const size_t cap = !want_ring ? 0 : (((size_t)s.opt.voxel_order_max_rays + 65535u) & ~(size_t)65535u);
+    if (cap == s.order_cap && (cap == 0 || s.d_order)) return;
+    for (int k = 0; k < Scene::kOrderRing; ++k) {
+        if (s.order_ev[k] && s.order_used[k]) (void)H->EventSynchronize(s.order_ev[k]);
+        s.order_used[k] = false;
+    }
+    dev_free(H, s.d_order);
+    s.d_order = nullptr;
+    s.order_cap = 0;
+    if (cap == 0) return;
+    for (int k = 0; k < Scene::kOrderRing; ++k)
+        if (!s.order_ev[k] && H->EventCreateWithFlags(&s.order_ev[k], hipEventDisableTiming) != hipSuccess) { (void)H->GetLastError(); s.order_ev[k] = nullptr; return; }
+    if (s.opt.dev_fail_cellbox_alloc || H->Malloc(&s.d_order, (size_t)Scene::kOrderRing * cap * sizeof(uint32_t)) != hipSuccess) {
+        (void)H->GetLastError();
+        s.d_order = nullptr;
+        return;
+    }
+    s.order_cap = cap;
+}
 int upload_cell_boxes(Scene& s, const HipApi* H)
 {
+    reserve_order_ring(s, H);                 // the other reservation every voxel build ends in
     for (void*& p : s.d_cellbox) dev_free(H, p);
     s.d_cellbox.assign(s.topos.size(), nullptr);
     s.cellbox_rad = -1;
@@ -479,7 +508,14 @@ void reserve_oct_scratch(Scene& s, const HipApi* H)
     const size_t stride = ((size_t)kOctTailHead + 20u * levels + 15u) & ~(size_t)15u;
     const size_t rec_bytes = (cus * p_per_cu * 4u * 64u * stride + 255u) & ~(size_t)255u;
     const size_t tail_spill = cus * (size_t)HARE_K2G_WAVES_PER_EU * 4u * 8u * spill_entries * 24u;
-    const size_t need = std::max(need_group, rec_bytes + tail_spill);
+    // ... but only what the scene's OPTIONS can launch (ADVICE, round 5): by the library's rule -- K2g below 196 608 rays, K2d above, K2d handing
+    // nothing over -- no launch ever writes a hand-over record, and the blocks hold K2g's stack spill alone (nothing for trees up to
+    // (kGroupStack - 8) / 7 levels: the 8-level bench tree reserves 0 bytes where round 5 held 0.7 GB per scene).  Records are reserved when
+    // K2p is forced ("octree_kernel" 1), a developer hand-over rule is set, or the tree is too deep for K2d's LDS -- hare_scene_set_option
+    // calls this again when one of those changes.
+    const bool dense_fits = (unsigned)levels * 256u * 20u + kOctDenseExtra <= kLdsMax;
+    const bool handover = s.opt.octree_tail != 0 && (s.opt.octree_kernel == 1 || s.opt.k2p_tail_max > 0 || s.opt.k2p_tail_patience >= 0 || !dense_fits);
+    const size_t need = std::max(need_group, handover ? rec_bytes + tail_spill : (size_t)0);
     std::lock_guard<std::mutex> lk(s.oct_tail_mu);
     if (need <= s.oct_tail_block_bytes) return;
     if (s.d_oct_tail) {

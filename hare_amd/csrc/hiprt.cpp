@@ -1,5 +1,6 @@
 // hiprt.cpp -- run-time binding of the HIP runtime (see hiprt.h).
 #include "hiprt.h"
+#include <atomic>
 
 #include <dlfcn.h>
 #include <link.h>
@@ -35,6 +36,20 @@ bool bind(void* h, const char* name, F& fn, std::string& err)
     fn = reinterpret_cast<F>(p);
     return true;
 }
+
+struct RealCalls {
+    hipError_t (*Malloc)(void**, size_t) = nullptr;
+    hipError_t (*Free)(void*) = nullptr;
+    hipError_t (*DeviceSynchronize)(void) = nullptr;
+    hipError_t (*StreamSynchronize)(hipStream_t) = nullptr;
+    hipError_t (*EventSynchronize)(hipEvent_t) = nullptr;
+} g_real;
+std::atomic<long long> g_calls[3];      // 0 hipMalloc, 1 hipFree, 2 host-side waits (device / stream / event synchronise)
+hipError_t counted_malloc(void** p, size_t n) { g_calls[0]++; return g_real.Malloc(p, n); }
+hipError_t counted_free(void* p) { g_calls[1]++; return g_real.Free(p); }
+hipError_t counted_device_sync(void) { g_calls[2]++; return g_real.DeviceSynchronize(); }
+hipError_t counted_stream_sync(hipStream_t st) { g_calls[2]++; return g_real.StreamSynchronize(st); }
+hipError_t counted_event_sync(hipEvent_t e) { g_calls[2]++; return g_real.EventSynchronize(e); }
 
 void do_bind()
 {
@@ -80,10 +95,23 @@ void do_bind()
         g_err = e + " (" + g_api.path + ")";
         return;
     }
+    {
+        std::string ignored;                                   // optional entry points: absent from an old runtime = feature off
+        if (!bind(h, "hipStreamIsCapturing", g_api.StreamIsCapturing, ignored)) g_api.StreamIsCapturing = nullptr;
+    }
+    // the calls a stream-ordered entry point must never make are counted (hip_call_count; hare_scene_get_option "hip_malloc_calls", ...):
+    // tests hold hare_shoot_device to "no allocation, no free, no host-side wait"
+    g_real.Malloc = g_api.Malloc; g_api.Malloc = counted_malloc;
+    g_real.Free = g_api.Free; g_api.Free = counted_free;
+    g_real.DeviceSynchronize = g_api.DeviceSynchronize; g_api.DeviceSynchronize = counted_device_sync;
+    g_real.StreamSynchronize = g_api.StreamSynchronize; g_api.StreamSynchronize = counted_stream_sync;
+    g_real.EventSynchronize = g_api.EventSynchronize; g_api.EventSynchronize = counted_event_sync;
     g_ok = true;
 }
 
 }  // namespace
+
+long long hip_call_count(int which) { return which >= 0 && which < 3 ? g_calls[which].load() : -1; }
 
 const HipApi* hip_api(std::string* err)
 {

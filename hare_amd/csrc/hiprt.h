@@ -43,8 +43,13 @@ struct HipApi {
     hipError_t (*EventElapsedTime)(float*, hipEvent_t, hipEvent_t);
     hipError_t (*HostMalloc)(void**, size_t, unsigned int);
     hipError_t (*HostFree)(void*);
+    hipError_t (*StreamIsCapturing)(hipStream_t, hipStreamCaptureStatus*);   // optional (null when the runtime lacks it)
     std::string path;   // which runtime was bound
 };
+
+// hipMalloc (0) / hipFree (1) / host-side waits -- hipDeviceSynchronize, hipStreamSynchronize, hipEventSynchronize -- (2) this library has
+// made in this process so far (tests: a stream-ordered entry point makes none of them).
+long long hip_call_count(int which);
 
 // Binds on first call; returns nullptr and sets `err` if no runtime can be loaded.
 const HipApi* hip_api(std::string* err);

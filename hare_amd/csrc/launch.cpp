@@ -41,6 +41,15 @@ struct OctScratch {
     bool group_tail = false;
     int spill_entries = 0;
 };
+// A stream under capture (hipStreamBeginCapture) takes kernel launches but not this library's cross-launch event protocol in a form a
+// graph replay could honour twice: the order pass is skipped there (the cast runs in the caller's order: same events).
+static bool stream_is_capturing(const HipApi* H, hipStream_t st)
+{
+    if (!H->StreamIsCapturing || !st) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (H->StreamIsCapturing(st, &cs) != hipSuccess) { (void)H->GetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
 int launch_on_slot(Scene& s, const HipApi* H, hipFunction_t f, unsigned grid, unsigned block, unsigned lds, hipStream_t st, ShootIO& io,
                    void** args, bool coop_tail = false, const OctScratch& oc = OctScratch())
 {
@@ -159,7 +168,9 @@ void read_env_options(SceneOptions& o)
     if (const char* k = getenv("HARE_KDTREE_KERNEL")) o.kdtree_kernel = strcmp(k, "simple") == 0 ? 1 : (strcmp(k, "dense") == 0 ? 2 : 0);
     if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_TIGHT")) o.voxel_tight = atoi(t) != 0;
+    if (const char* t = getenv("HARE_VOXEL_WALK")) o.voxel_walk = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_ORDER")) o.voxel_order = std::max(0, std::min(2, atoi(t)));
+    if (const char* t = getenv("HARE_VOXEL_ORDER_MAX_RAYS")) o.voxel_order_max_rays = std::max(0, atoi(t));
     if (const char* t = getenv("HARE_VOXEL_TIGHT_MAX_MB")) o.voxel_tight_max_mb = std::max(0, atoi(t));
     if (const char* t = getenv("HARE_FAIL_CELLBOX_ALLOC")) o.dev_fail_cellbox_alloc = atoi(t) != 0;
     if (const char* t = getenv("HARE_BOUNCE_FUSED")) o.bounce_fused = atoi(t) != 0;
@@ -644,39 +655,27 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // rays: half of HBM's rate), which at 1M rays is what the order gains.  The scratch is a block of the scene's order ring
             // (stream-ordered allocation was tried first: hipMallocAsync / hipFreeAsync cost the stream more than the pass itself).
             const bool order_rule = s.opt.voxel_order == 2 || (s.opt.voxel_order == 1 && !d_e1 && !d_e2 && !(flags & SHOOT_RETIRED_RAYS) && n >= kOrderMinRays);
-            if (!io.order && order_rule && M.cost_order && n <= 0x7FFFFF00ll && (flags & 0xF000u) == 0) {
-                // a block of the scene's order ring (scene.h); held under the ring's lock across wait + launches + record
-                std::lock_guard<std::mutex> olk(s.order_mu);
-                const int ob = (int)(s.order_seq++ % (unsigned)Scene::kOrderRing);
-                bool have_block = true;
-                if (!s.order_ev[ob] && H->EventCreateWithFlags(&s.order_ev[ob], hipEventDisableTiming) != hipSuccess) { (void)H->GetLastError(); have_block = false; }
-                if (have_block && s.order_cap[ob] < (size_t)n) {
-                    if (s.order_used[ob]) (void)H->EventSynchronize(s.order_ev[ob]);        // its previous user has finished before it is replaced
-                    dev_free(H, s.d_order[ob]);
-                    s.order_cap[ob] = 0;
-                    s.order_used[ob] = false;
-                    const size_t cap = ((size_t)n + 65535u) & ~(size_t)65535u;
-                    if (H->Malloc(&s.d_order[ob], cap * sizeof(uint32_t)) == hipSuccess) s.order_cap[ob] = cap;
-                    else { (void)H->GetLastError(); s.d_order[ob] = nullptr; have_block = false; }      // no scratch: the cast runs in the caller's order
+            if (!io.order && order_rule && M.cost_order && (size_t)n <= s.order_cap && (flags & 0xF000u) == 0 && !stream_is_capturing(H, st)) {
+                // a block of the scene's order ring (scene.h), reserved when the grid went to the device: nothing is allocated, freed or
+                // synchronised here.  The block's mutex is held across wait + launches + record (four enqueues)
+                const int ob = (int)(s.order_seq.fetch_add(1) % (unsigned)Scene::kOrderRing);
+                std::lock_guard<std::mutex> olk(s.order_blk_mu[ob]);
+                if (s.order_used[ob]) HIP_TRY(H->StreamWaitEvent(st, s.order_ev[ob], 0));
+                const void* rp = d_rays;
+                void* d_order = static_cast<uint32_t*>(s.d_order) + (size_t)ob * s.order_cap;
+                long long nn = n;
+                float o0[3], o1[3], iv[3];
+                for (int a = 0; a < 3; ++a) { o0[a] = (float)s.vox.omin[a]; o1[a] = (float)s.vox.omax[a]; iv[a] = (float)(1.0 / s.vox.vd[a]); }
+                float bpv = (float)kOrderBins / (3.0f * (float)std::max(1, s.vox.ct));
+                void* oargs[] = {&rp, &nn, &o0[0], &o0[1], &o0[2], &o1[0], &o1[1], &o1[2], &iv[0], &iv[1], &iv[2], &bpv, &d_order};
+                int rc = launch(H, M.cost_order, (unsigned)((n + kOrderWindow - 1) / kOrderWindow), (unsigned)kOrderThreads, 0, st, oargs);
+                if (rc == HARE_OK) {
+                    io.order = (const uint32_t*)d_order;
+                    rc = launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
                 }
-                if (have_block) {
-                    if (s.order_used[ob]) HIP_TRY(H->StreamWaitEvent(st, s.order_ev[ob], 0));
-                    const void* rp = d_rays;
-                    void* d_order = s.d_order[ob];
-                    long long nn = n;
-                    float o0[3], o1[3], iv[3];
-                    for (int a = 0; a < 3; ++a) { o0[a] = (float)s.vox.omin[a]; o1[a] = (float)s.vox.omax[a]; iv[a] = (float)(1.0 / s.vox.vd[a]); }
-                    float bpv = (float)kOrderBins / (3.0f * (float)std::max(1, s.vox.ct));
-                    void* oargs[] = {&rp, &nn, &o0[0], &o0[1], &o0[2], &o1[0], &o1[1], &o1[2], &iv[0], &iv[1], &iv[2], &bpv, &d_order};
-                    int rc = launch(H, M.cost_order, (unsigned)((n + kOrderWindow - 1) / kOrderWindow), (unsigned)kOrderThreads, 0, st, oargs);
-                    if (rc == HARE_OK) {
-                        io.order = (const uint32_t*)d_order;
-                        rc = launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
-                    }
-                    if (H->EventRecord(s.order_ev[ob], st) == hipSuccess) s.order_used[ob] = true;
-                    else (void)H->GetLastError();
-                    return rc;
-                }
+                if (H->EventRecord(s.order_ev[ob], st) == hipSuccess) s.order_used[ob] = true;
+                else (void)H->GetLastError();
+                return rc;
             }
             return launch_on_slot(s, H, kc.f, pgrid, 64u * (unsigned)kPoolWaves, plds, st, io, args, true);
         }

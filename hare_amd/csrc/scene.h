@@ -41,6 +41,7 @@ struct SceneOptions {
     int bounce_fused = 0;      // 1: the bounce loop of a Voxel_Grid runs as ONE launch where the pool kernel serves (hare_voxel_bounce_*); 0 (default): a launch
                                // per cast -- measured: the hall +2.5 %, the cathedral -0 ... -10 % (a chip that works on all casts at once loses the L2 locality of one band)
     int voxel_tight = 1;       // 1: K1q sends a ray on past an occupied voxel whose polygons it cannot hit (the voxels' tight boxes, device_scene.cpp: upload_cell_boxes); 0: every list the reference scans (A/B)
+    int voxel_order_max_rays = 1 << 24;   // entries per block of the order ring reserved with the grid (scene.h: kOrderRing blocks x 4 B each); larger batches run unordered; 0: no ring
     int voxel_order = 1;       // the pool kernel takes a batch's rays, window by window, in the order of their estimated walk length (order_kernels.hip):
                                // 1 (default) batches of primary rays from 1 572 864 rays, 0 never, 2 every batch.  Results never depend on it
     int voxel_tight_max_mb = 0; // budget for those boxes (32 B per voxel and topology), MiB; 0 = none.  Over budget or out of memory: no boxes, same results
@@ -196,16 +197,20 @@ struct Scene {
     hipEvent_t oct_tail_ev[kOctTailRing] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool oct_tail_used[kOctTailRing] = {false, false, false, false, false, false, false, false};
     std::mutex oct_tail_mu;
-    // the ray orders of the pool kernel (order_kernels.hip): a ring of blocks of n uint32, one per launch in flight; a block comes round
-    // after kOrderRing launches and waits for the event its previous user recorded (as the octree scratch ring).  Grown on demand -- the
-    // first ordered launch of a new largest batch size synchronises the block's previous user, like every first-use allocation here
+    // the ray orders of the pool kernel (order_kernels.hip): a ring of kOrderRing blocks of order_cap uint32 each, ONE allocation, RESERVED when
+    // the grid goes to the device (device_scene.cpp: reserve_order_ring; option "voxel_order_max_rays", 16 Mi rays = 64 MiB a block by default)
+    // -- a shoot never allocates, frees or synchronises (round 5 grew the blocks inside hare_shoot_device: ADVICE).  A launch takes the next
+    // block (atomic counter), waits ON ITS STREAM for the event the block's previous user recorded, enqueues the order pass and the shoot and
+    // records the event again, under the block's own mutex (held for those four enqueues only).  A batch larger than a block, a stream that
+    // is being captured, or a failed reservation: the cast runs in the caller's order -- the same events.  More than kOrderRing ordered
+    // launches in flight on one scene queue behind each other's blocks (stream waits, never a host wait).
     static constexpr int kOrderRing = 4;
-    void* d_order[kOrderRing] = {nullptr, nullptr, nullptr, nullptr};
-    size_t order_cap[kOrderRing] = {0, 0, 0, 0};
+    void* d_order = nullptr;
+    size_t order_cap = 0;                                   // uint32 entries per block (0: no ring -- the order pass never runs)
     hipEvent_t order_ev[kOrderRing] = {nullptr, nullptr, nullptr, nullptr};
     bool order_used[kOrderRing] = {false, false, false, false};
-    unsigned order_seq = 0;
-    std::mutex order_mu;
+    std::atomic<unsigned> order_seq{0};
+    std::mutex order_blk_mu[kOrderRing];
 
     // staging for hare_shoot_batch: a small pool of contexts (device buffers + the three streams a batch is pipelined
     // over), so that host threads calling on one scene run side by side instead of queueing on one mutex; `mu` guards

@@ -120,7 +120,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         uint4* dst = reinterpret_cast<uint4*>(locc);
         for (int k = threadIdx.x; k < nw4; k += blockDim.x) dst[k] = src[k];
     }
-    const int wave = threadIdx.x >> 6;
+    // wave-uniform BY CONSTRUCTION, and said so to the compiler (readfirstlane): everything derived from the wave's number -- its ray chunk,
+    // `drained`, through them every queue head and count -- would otherwise count as divergent and live in vector registers, each `if`
+    // on it a v_cmp + saveexec + branch (round 6: that bookkeeping was two fifths of a wave's time)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     unsigned char* const wb = lds_raw + ((size_t)nw4 << 4) + (size_t)wave * kPoolWaveBytes;
@@ -164,9 +167,17 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     unsigned hR = 0, nR = 0;            // BOUNCE: slots whose hit stands and whose ray goes on to its next cast
 #ifdef HARE_K1Q_STATS                   // developer build (tools/k1q_stats.py): executions and active lanes of every phase; lane 0 counts
     unsigned long long kq_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, kq_l[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, kq_steps = 0;   // [8]: steps inside pend-walk tasks
-#define K1Q_STAT(i, act) { kq_n[i]++; kq_l[i] += (unsigned long long)__popcll(__ballot(act)); }
+    // ... and where a wave's TIME goes: every phase start closes the previous phase's interval on the shader clock ([9]: the round's own
+    // bookkeeping -- queue choice, refill rule, fences; [7]: the step loop inside walk tasks)
+    unsigned long long kq_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, kq_last_t = __builtin_amdgcn_s_memtime();
+    int kq_last_i = 9;
+    // (static indices under wave-uniform compares, and a second stamp when the bookkeeping is done: the clock's own cost is in no interval)
+#define K1Q_CLOCK(i) { const unsigned long long d_ = __builtin_amdgcn_s_memtime() - kq_last_t; _Pragma("unroll") for (int k_ = 0; k_ < 10; ++k_) if (kq_last_i == k_) kq_t[k_] += d_; \
+                       kq_last_i = (i); kq_last_t = __builtin_amdgcn_s_memtime(); }
+#define K1Q_STAT(i, act) { kq_n[i]++; kq_l[i] += (unsigned long long)__popcll(__ballot(act)); K1Q_CLOCK(i) }
 #else
 #define K1Q_STAT(i, act)
+#define K1Q_CLOCK(i)
 #endif
     auto push = [&](uint8_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
         const unsigned long long m = __ballot(flag);
@@ -310,9 +321,11 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     };
 
     // developer timeline (flag 0x2000, tools/timeline_prof.py): per wave {start, tickets dry, end, rounds} on the 100 MHz clock
+    // (every lane stores the same word: an `if (lane == 0)` here would be a DIVERGENT branch whose join the compiler's uniformity analysis
+    // shares with the wave-uniform state set beside it -- `drained` -- and through it every queue counter would count as divergent)
     auto timeline = [&](int slot, unsigned long long v) {
         if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
-            if (lane == 0) io.prof[32 + 4ull * (blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave) + slot] = v;
+            io.prof[32 + 4ull * (blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave) + slot] = v;
         }
     };
     timeline(0, __builtin_amdgcn_s_memrealtime());
@@ -327,6 +340,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     unsigned long long t_coop = 0;
     for (;;) {          // (BOUNCE: the cooperative tail can send a ray back to the pool for its next cast)
     for (unsigned round = 0; round < (1u << 24); ++round) {
+        K1Q_CLOCK(9)
         // ------------------------------------------------------------------ set-up of new rays into free slots
         if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP + nR == 0)) {
             if (cn >= ce) {
@@ -342,8 +356,10 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     chunk_live = false;
                     dyn <<= dead_run;
                 }
+                K1Q_CLOCK(8)
                 if (lane == 0) base = atomicAdd(io.work, dyn);
-                base = __shfl(base, 0, 64);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);      // lane 0's ticket, in a scalar register
+                K1Q_CLOCK(9)
                 cn = base + n_static;
                 if (cn >= n32) { drained = true; cn = ce = n32; timeline(1, __builtin_amdgcn_s_memrealtime()); }
                 else ce = (n32 - cn > dyn) ? cn + dyn : n32;
@@ -381,6 +397,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 push(Q_free, hF, nF, freed, slot);
             }
         }
+        K1Q_CLOCK(9)
 #ifndef HARE_K1Q_REARM_MIN
 #define HARE_K1Q_REARM_MIN 8      // BOUNCE: reflect + set up again when this many rays wait for it (or nothing else can run, or the launch drains); swept
                                   // 1 / 8 / 16 / 32 / 48: C5 shard 675 / 677 / 664 / 610 / 520 Mcasts/s -- a ray parked in this queue is a slot of the pool not working
@@ -450,9 +467,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             const unsigned gw = blockIdx.x * (unsigned)kPoolWaves + (unsigned)wave;
             const unsigned long long stamp = ((unsigned long long)__builtin_amdgcn_s_memrealtime() << 34) |
                                              ((unsigned long long)(drained ? 1u : 0u) << 32) | nW | (nC << 8) | (nE << 16) | (nP << 24);
-            if ((gw & 255u) == 5u && rounds_done < 1024u && lane == 0) io.prof[32 + 4 * 4096 + (gw >> 8) * 1024 + rounds_done] = stamp;
+            if ((gw & 255u) == 5u && rounds_done < 1024u) io.prof[32 + 4 * 4096 + (gw >> 8) * 1024 + rounds_done] = stamp;      // (every lane the same word: see timeline())
             // ... and EVERY wave its first 48 rounds after the tickets ran dry (what the latest waves of a launch are doing)
-            if (drained && tail_rounds <= 48u && tail_rounds > 0u && lane == 0) io.prof[32 + 4 * 4096 + 16 * 1024 + gw * 48u + (tail_rounds - 1u)] = stamp;
+            if (drained && tail_rounds <= 48u && tail_rounds > 0u) io.prof[32 + 4 * 4096 + 16 * 1024 + gw * 48u + (tail_rounds - 1u)] = stamp;
         }
 
         // ------------------------------------------------------------------ pick the phase for this round
@@ -635,6 +652,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             const int n0 = __popcll(__ballot(walking));
             const int walk_min = tail ? 1 : (n0 / 3 < HARE_K1Q_WALK_MIN ? n0 / 3 : HARE_K1Q_WALK_MIN);
             const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : HARE_K1Q_WALK_STEPS;   // end of the launch: fewer, longer tasks
+            K1Q_CLOCK(7)
             if (HARE_K1Q_HAND_WALK && hand_walk) {
                 // the step loop written by hand (voxel_walk.h): the same steps, the per-axis updates under the axis' own EXEC mask
                 unsigned taken = 0, iters = 0;
@@ -662,6 +680,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 }
             }
             }
+            K1Q_CLOCK(1)
             const bool exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
             bool to_cull = act && !walking && !exited;
             if (exited) store_miss(L_ray[slot]);                            // leaving the grid: miss
@@ -697,6 +716,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_free, hF, nF, exited, slot);
         }
+        K1Q_CLOCK(9)
         HARE_K1Q_PHASE_FENCE();
         if (wide && nC > 0) {
             K1Q_STAT(6, true)
@@ -934,6 +954,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_exact, hE, nE, to_exact, slot);
             push(Q_pend, hP, nP, to_pend, slot);
         }
+        K1Q_CLOCK(9)
         HARE_K1Q_PHASE_FENCE();
         if (tail ? nE > 0 : sel == 0) {
             // -------------------------------------------------------------- exact FP64 test of one candidate per ray
@@ -1006,6 +1027,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_pend, hP, nP, to_pend, slot);
         }
+        K1Q_CLOCK(9)
         HARE_K1Q_PHASE_FENCE();      // the exact phase's hit record, before the pending-hit walk reads it
         if (tail ? nP > 0 : sel == 1) {
             // -------------------------------------------------------------- walk with a pending hit (Voxel_Grid.cs:705-759)
@@ -1159,6 +1181,8 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         for (int k = 0; k < 8; ++k) { atomicAdd(&io.prof[2 * k], kq_n[k]); atomicAdd(&io.prof[2 * k + 1], kq_l[k]); }
         atomicAdd(&io.prof[16], (unsigned long long)rounds_done);
         atomicAdd(&io.prof[18], kq_n[8]); atomicAdd(&io.prof[19], kq_l[8]);
+        K1Q_CLOCK(9)
+        for (int k = 0; k < 10; ++k) atomicAdd(&io.prof[20 + k], kq_t[k]);
     }
     (void)kq_steps;
 #endif

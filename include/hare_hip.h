@@ -19,7 +19,11 @@
  *     several host threads on one scene: up to four calls run side by side, each on its own
  *     staging buffers and streams, further callers wait for a free set (what the reference's
  *     Ray.ThreadID / mailbox pool serve, Voxel_Grid.cs:334-342); hare_shoot_device is
- *     stream-ordered and takes no lock; hare_shoot_one takes no lock either.
+ *     stream-ordered: it enqueues and returns -- no allocation, no free, no wait on the device, a stream
+ *     or an event on the host (every scratch it uses was reserved when the partition went to the device;
+ *     hare_scene_get_option "hip_malloc_calls" ... let a caller check).  What it does take, for the few
+ *     enqueues of one call, is the mutex of the launch slot (and scratch block) the call uses: calls from
+ *     several threads contend only when they draw the same slot of the ring.  hare_shoot_one takes no lock.
  *   - devices: every call acts on the scene's own device and leaves the calling thread's current
  *     HIP device as it found it.
  *   - batches have NO CPU fallback: hare_shoot_batch / hare_shoot_device run the HIP kernels and fail
@@ -203,6 +207,9 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *   "voxel_order"     1 (default): the pool kernel takes the rays of a batch of primary rays (no exclusion arrays, from 1 572 864 rays), window by
  *                     window of 4 096, in the order of their estimated walk length -- a wave's rays then cost about the same; 0 never, 2 every
  *                     batch.  Rays and events stay where the caller has them; results never depend on it
+ *   "voxel_order_max_rays"  the largest batch that pass serves (default 16 777 216): its scratch -- a ring of 4 blocks of that many 4-byte entries,
+ *                     256 MiB by default -- is reserved when the grid goes to the device, so that no shoot ever allocates; a larger batch, a stream
+ *                     under capture, or a failed reservation runs in the caller's order (same results).  0: no ring
  *   "voxel_tight_max_mb"  budget for those boxes in MiB (0, the default: none).  Over budget -- or out of device memory -- the grid is
  *                     built and traced without them: never an error, never a different result
  *   "dev"             1: developer flag bits of hare_shoot_* (timeline, phase profile, cull audit) pass
@@ -213,6 +220,11 @@ HARE_API int hare_scene_set_option(hare_scene *s, const char *name, int64_t valu
  *   "voxel_tight_bytes"     device bytes the voxels' tight boxes take on this scene (32 B per voxel and topology; 0: none -- the option is
  *                           off, the grid is one the pool kernel does not serve, over "voxel_tight_max_mb", or their allocation failed:
  *                           the grid is then traced without them, same results)
+ *   "voxel_order_bytes"     device bytes of the pool kernel's order ring (0: none -- "voxel_order" off, "voxel_order_max_rays" 0, a grid the
+ *                           pool kernel does not serve, or the reservation failed)
+ *   "hip_malloc_calls", "hip_free_calls", "hip_sync_calls"   process-wide counts of hipMalloc / hipFree / host-side waits (hipDeviceSynchronize,
+ *                           hipStreamSynchronize, hipEventSynchronize) this library has made: a caller (or a test) can hold the stream-ordered
+ *                           entry points to "none of these"
  *   "octree_scratch_bytes"  device bytes of the octree kernels' scratch ring (hand-over records and stack spill; 0 before the first
  *                           octree launch that needs one)
  * No reference counterpart: Hare has no device memory to account for. */
@@ -300,7 +312,10 @@ HARE_API int hare_shoot_batch_sharded(hare_scene *const *scenes, int32_t n_scene
  * a device hare_counters that the kernel ACCUMULATES into.  Calls may be issued from several host
  * threads and on several streams; the scene keeps per-launch scratch (work tickets, counter shards) in a ring of
  * 64 slots: the 65th launch in flight is ordered behind the first (it waits for an event that launch recorded), so any
- * number of launches may be queued.  rays, the exclusion arrays, events and counters must not overlap (HARE_E_INVALID). */
+ * number of launches may be queued.  The same holds for the scratch rings some launches use beside it (the pool kernel's ray
+ * order: 4 blocks; the octree kernels' hand-over records and stack spill: 8): a block's next user waits ON ITS STREAM for the event the previous
+ * one recorded.  Under stream capture the order pass is skipped (results unchanged).  rays, the exclusion arrays, events and counters
+ * must not overlap (HARE_E_INVALID). */
 HARE_API int hare_shoot_device(hare_scene *s, int32_t kind, int32_t top_index, int64_t n, void *d_rays,
                       const void *d_excl1, const void *d_excl2, uint32_t flags, void *d_out,
                       void *d_counters, void *stream);

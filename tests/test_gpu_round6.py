@@ -156,3 +156,64 @@ def test_own_work_counters_do_not_depend_on_the_step_loop():
         assert got[1][0] == got[0][0], scene
         assert got[1][1] == got[0][1], (scene, got[1][1], got[0][1])
         assert got[1][1][0] == n and got[1][1][2] > 10 * n          # rays; voxels walked into
+
+
+def test_a_shoot_never_allocates_frees_or_waits():
+    """VERDICT round 5 / ADVICE: hare_shoot_device is documented as stream-ordered, so the FIRST large batch on a fresh grid -- the one that
+    used to grow the pool kernel's order ring inside the call (hipFree = a device-wide synchronisation) -- must make no hipMalloc, no
+    hipFree and no host-side wait.  The HIP runtime is bound through hiprt.cpp, which counts those calls (hare_scene_get_option).  The
+    ring is reserved with the grid: "voxel_order_bytes" says so; a batch beyond "voxel_order_max_rays", or a ring switched off, runs in
+    the caller's order with the same events.  The octree's first launches likewise (scratch reserved with the tree, and only what the
+    scene's options can launch: nothing for the library's own kernel rule on a shallow tree)."""
+    import torch
+    from hare_amd import capi
+    m = H.scenes.hall()
+    T = H.Topology(m.verts, m.nverts)
+    g = H.Voxel_Grid([T], 64)
+    assert g.get_option("voxel_order_max_rays") == 1 << 24
+    assert g.get_option("voxel_order_bytes") == 4 * (1 << 24) * 4
+    n = 2 << 20
+    d_rays = torch.from_numpy(H.scenes.burst_rays(n, m.size)).cuda()
+    d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    before = [g.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")]
+    for _ in range(6):                          # more launches than the ring has blocks: the fifth waits on its stream, not on the host
+        g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr())
+    after = [g.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")]
+    assert after == before, (before, after)
+    torch.cuda.synchronize()
+    ordered = d_out.cpu().numpy().tobytes()
+    g.set_option("voxel_order_max_rays", 1 << 20)          # smaller than the batch: no order pass
+    assert g.get_option("voxel_order_bytes") == 4 * (1 << 20) * 4
+    g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert d_out.cpu().numpy().tobytes() == ordered
+    g.set_option("voxel_order", 0)
+    assert g.get_option("voxel_order_bytes") == 0
+    g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert d_out.cpu().numpy().tobytes() == ordered
+    g.set_option("voxel_order", 2); g.set_option("voxel_order_max_rays", 1 << 22)      # every batch ordered, exclusions too
+    assert g.get_option("voxel_order_bytes") == 4 * (1 << 22) * 4
+    before = [g.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")]
+    g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr())
+    assert [g.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")] == before
+    torch.cuda.synchronize()
+    assert d_out.cpu().numpy().tobytes() == ordered
+
+    oc = H.Octree([T], 8, 16)
+    small = oc.get_option("octree_scratch_bytes")           # the library's rule (K2g / K2d, no hand-over): K2g's stack spill alone
+    assert 0 <= small <= 256 << 20
+    before = [oc.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")]
+    for k in (100_000, 1 << 20):
+        oc.shoot_device(k, d_rays.data_ptr(), d_out.data_ptr())
+    assert [oc.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")] == before
+    torch.cuda.synchronize()
+    want = d_out[: (1 << 20) * 56].cpu().numpy().tobytes()
+    oc.set_option("octree_kernel", 1)                       # K2p hands rays over: its records are reserved now, not in the launch
+    assert oc.get_option("octree_scratch_bytes") > 2 * small
+    before = [oc.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")]
+    oc.shoot_device(1 << 20, d_rays.data_ptr(), d_out.data_ptr())
+    assert [oc.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")] == before
+    torch.cuda.synchronize()
+    assert d_out[: (1 << 20) * 56].cpu().numpy().tobytes() == want

@@ -3,7 +3,7 @@
 # Counters in separate passes of at most ~8 (SQ slots); per-kernel sums of the hare_* shoot kernels are printed.  GPU box only.
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r4/pmc_$tag
+O=$R/gpurun_out/${PMC_DIR:-r6}/pmc_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 pass() {  # name, counters...
