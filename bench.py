@@ -74,6 +74,10 @@ def parse_args(argv=None):
     ap.add_argument("--extra-rays", type=int, default=0, help="cap the rays of the appended configs (tests; 0 = their real sizes)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed and run its code path even with one rank (tests the RCCL branch on one GPU)")
+    ap.add_argument("--inproc-scenes", type=int, default=-1,
+                    help="the single-process multi-GPU leg (`inproc_sharded`): ONE hare_shoot_batch_sharded and ONE hare_bounce_batch_sharded call "
+                         "over this many scenes, scene k on device k %% device_count.  -1 (default): one scene per visible device when N > 1, off at "
+                         "N = 1; 0: off; K > 0: K scenes (a one-GPU box runs it with two scenes on its one device)")
     ap.add_argument("--bounce-api", default="device", choices=["device", "batch"],
                     help="--bounces > 1: 'device' = hare_shoot_device + hare_reflect_device on resident buffers (the timed loop); "
                          "'batch' additionally times hare_bounce_batch from host buffers (PCIe-inclusive, reported beside it)")
@@ -509,6 +513,7 @@ def measure(w, env):
     roofline = None
     cpu = None
     parity = None
+    parity_rays = None
     parity_ranks = None
     fields = ("hit", "poly_id", "t", "x", "y", "z", "u", "v")
     if w["cpu_baseline"]:
@@ -610,6 +615,7 @@ def measure(w, env):
         if samp is not None:
             got = got[samp]
         parity = bool(all(np.array_equal(got[f], ref[f]) for f in fields))
+        parity_rays = len(got)            # how many rays the flag speaks for (a kd-tree on a large scene: a sample, see `samp`)
         del got
         bytes_pass = algorithmic_bytes(ctr, kind, links)
         pass_s = kern_ms * B * 1e-3                     # one pass of the hot path: B casts
@@ -642,12 +648,17 @@ def measure(w, env):
             del got_own
             if oc[0] == casts and own_parity:
                 cw = 8 if kind == "voxel" else 64
-                own_bytes = 104 * oc[0] + cw * oc[2] + 4 * oc[3] + 32 * oc[5] + 128 * oc[4] + 28 * links
+                kb = 48 if bool((np.asarray(mesh.nverts) == 4).any()) else 32      # a topology with quadrilaterals: 48-byte cull records (CullFrame::stride)
+                own_bytes = 104 * oc[0] + cw * oc[2] + 4 * oc[3] + kb * oc[5] + 128 * oc[4] + 28 * links
                 own = {"frac": round(own_bytes / pass_s / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(own_bytes / pass_s / 1e9, 1),
                        "bytes_per_launch": own_bytes // B, "bytes_per_cast": round(own_bytes / max(casts, 1), 1),
-                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), "L": round(oc[3] / max(casts, 1), 2),
+                       # S: DDA steps the kernel EXECUTES per cast.  It equals C' by construction: round 6 made the step cheap (voxel_walk.h: 17 / 20
+                       # vector instructions where the compiler wrote 40), it does not skip voxels -- see DESIGN.md 5 for why the closed-form block
+                       # skip loses to a cheap step on this machine
+                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), "S": round(oc[2] / max(casts, 1), 2) if kind == "voxel" else None,
+                                    "L": round(oc[3] / max(casts, 1), 2),
                                     "K": round(oc[5] / max(casts, 1), 2), "T": round(oc[4] / max(casts, 1), 2)},
-                       "formula": f"104+{cw}C'+4L'+32K'+128T' (+28/bounce), counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}
+                       "formula": f"104+{cw}C'+4L'+{kb}K'+128T' (+28/bounce), counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}
         except Exception as e:       # a batch whose kernel has no counting build (HARE_E_UNSUPPORTED): the line says so
             own = {"frac": None, "why": str(e)[:120]}
         # ---- roofline.issue: the bound the counters name (VALU issue), as a fraction: PMC wave-instruction counts by class x the measured
@@ -730,6 +741,8 @@ def measure(w, env):
         "x_event_parity_vs_oracle": parity if parity_ranks is None else bool(all(parity_ranks)),
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if parity_rays is not None and parity_rays != n:
+        line["parity_rays_checked"] = parity_rays          # fewer than the batch: the oracle got a stated sample (cpu_baseline.sample)
     if dist is not None:
         line["ranks_seen_in_reduce"] = ranks_seen        # from the all-reduced ray counter (RCCL at backend nccl)
         if parity_ranks is not None:
@@ -777,7 +790,7 @@ def compact_sub(sub: dict) -> dict:
     rf = sub.get("roofline") or {}
     own, issue, cpu = rf.get("own") or {}, rf.get("issue") or {}, sub.get("cpu_baseline")
     out = {k: sub[k] for k in ("value", "unit", "n_gpus", "scaling", "steps", "warmup", "ms_per_step", "kernel_only_mrays_s", "hits", "rays",
-                               "x_event_parity_vs_oracle", "parity_per_rank", "ranks_seen_in_reduce") if k in sub}
+                               "x_event_parity_vs_oracle", "parity_rays_checked", "parity_per_rank", "ranks_seen_in_reduce") if k in sub}
     out["config"] = {k: sub["config"][k] for k in ("rays_per_gpu", "rays_total", "backend")}
     out["config"]["workload"] = sub["config"]["workload_short"]
     r = {k: rf.get(k) for k in ("frac", "achieved", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "bytes_per_cast", "per_cast")}
@@ -803,7 +816,8 @@ def fit_line(line: dict) -> str:
     txt = dumps(line)
     line.get("config", {}).pop("workload_short", None)
     drops = [("cpu_baseline", "sample"), ("roofline", "measured_bound"), ("parity_sample",), ("config", "sharding"), ("config", "partition"),
-             ("roofline", "own", "formula"), ("roofline", "warning"), ("two_streams", "note")]
+             ("roofline", "own", "formula"), ("roofline", "warning"), ("two_streams", "note"),
+             ("inproc_sharded", "workload"), ("inproc_sharded", "parity_sample")]
     for path in drops:
         if len(txt) <= LINE_BUDGET:
             break
@@ -820,6 +834,79 @@ def fit_line(line: dict) -> str:
         line["configs"][name]["roofline"].pop("warning", None)
         txt = dumps(line)
     return txt
+
+
+def inproc_sharded(env, n_scenes: int, n_total: int, domain: int = 64, bounces: int = 8) -> dict:
+    """The path a ONE-process caller takes on a multi-GPU node -- what Pachyderm's C# host is (Spatial_Partition.cs:27-35: one object, one
+    caller): ONE hare_shoot_batch_sharded and ONE hare_bounce_batch_sharded call from host buffers over `n_scenes` equal scenes, scene k on
+    device k % device_count, contiguous ray shards, a host thread per scene inside the library (api.cpp, bounce.cpp).  The N ranks of this
+    bench measure the kernels; this leg measures that call: PCIe-inclusive (host rays in, host X_Events out), so its rate is the host
+    link's, not the kernels'.  Parity: the concatenated events against the oracle on every `stride`-th ray of the whole batch (so every
+    shard, i.e. every device, is sampled), all eight fields, both calls.  Rank 0 only, after the timed regions."""
+    import numpy as np
+
+    import hare_amd as H
+    from oracle import pyoracle as po
+
+    ndev = max(1, H.device_count())
+    mesh, topo = env.mesh(H, "hall")
+    devs = [k % ndev for k in range(n_scenes)]
+    t0 = time.time()
+    parts = [H.Voxel_Grid([topo], domain, device=d) for d in devs]
+    build_s = time.time() - t0
+    rays = H.scenes.burst_rays(n_total, mesh.size)
+    SP = H.Spatial_Partition
+    fields = ("hit", "poly_id", "t", "x", "y", "z", "u", "v")
+    out = {"scenes": n_scenes, "devices": devs, "device_count": ndev, "rays_total": n_total,
+           "workload": f"{n_total} burst rays -> {mesh.name}, Voxel_Grid Domain={domain}, host buffers, one call",
+           "kernels": sorted({p.kernel_name(max(1, n_total // n_scenes)) for p in parts}), "build_s": round(build_s, 2)}
+    try:
+        SP.Shoot_batch_sharded(parts, rays)                 # sizes every scene's staging buffers: not part of the measurement
+        best = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            ev, ctr = SP.Shoot_batch_sharded(parts, rays)
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        out["shoot"] = {"mrays_s": round(n_total / best / 1e6, 1), "ms": round(best * 1e3, 3), "hits": ctr["hits"], "rays": ctr["rays"]}
+        SP.Bounce_batch_sharded(parts, rays, bounces)
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            evb, ctrb = SP.Bounce_batch_sharded(parts, rays, bounces)
+            dt = time.perf_counter() - t1
+            best = dt if best is None else min(best, dt)
+        out["bounce"] = {"mcasts_s": round(ctrb["rays"] / best / 1e6, 1), "ms": round(best * 1e3, 3), "casts": ctrb["rays"], "bounces": bounces}
+        # the checker, on a sample that touches every shard
+        stride = max(1, n_total // 65536)
+        idx = np.arange(0, n_total, stride)
+        ot, og, _ = env.oracle(H, "hall", "voxel", domain)
+        nt = min(len(os.sched_getaffinity(0)), 64)
+        r = np.ascontiguousarray(rays[idx])
+        ref, _ = og.shoot(r, nthreads=nt)
+        ok1 = all(np.array_equal(ev[f][idx], ref[f]) for f in fields)
+        excl = None
+        cur = r
+        for b in range(bounces):
+            if excl is None:
+                e, _ = og.shoot(cur, nthreads=nt)
+            else:
+                live = excl >= 0
+                e = np.zeros(len(cur), po.XEVENT_DTYPE)
+                e["poly_id"] = -1
+                if live.any():
+                    e[live], _ = og.shoot(cur[live], excl1=excl[live], nthreads=nt)
+            if b + 1 < bounces:
+                cur = po.reflect_batch(ot, cur, e)
+                excl = np.where(e["hit"] != 0, e["poly_id"], -2).astype(np.int32)
+        okb = all(np.array_equal(evb[f][idx], e[f]) for f in fields)
+        out["parity_vs_oracle"] = bool(ok1 and okb)
+        out["parity_sample"] = f"every {stride}th ray of the batch ({len(idx)} rays, every shard), 8 fields: the shoot's events and the last cast's"
+    except Exception as ex:                                   # the leg must never take the line down with it
+        out["error"] = str(ex)[:200]
+    for p in parts:
+        p.close()
+    return out
 
 
 def main() -> None:
@@ -900,6 +987,12 @@ def main() -> None:
                 configs[name] = sub
         if rank == 0:
             line["configs"] = configs
+    # the single-process multi-GPU calls (hare_*_batch_sharded), on rank 0 while the other ranks wait at the final barrier
+    k_scenes = args.inproc_scenes
+    if k_scenes < 0:
+        k_scenes = ndev if world > 1 else 0
+    if rank == 0 and k_scenes > 0 and not args.no_cpu_baseline:
+        line["inproc_sharded"] = inproc_sharded(env, k_scenes, args.rays * world, args.domain if args.kind == "voxel" else 64)
     if rank == 0:
         print(fit_line(line), flush=True)
     if dist is not None:

@@ -512,18 +512,26 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
         return launch(H, M.counters_sum, 1, 64, 0, st, a);
     };
     if (int rc = sum_counters(-1)) return rc;            // the per-cast blocks are accumulated into: the totals get what THIS loop adds
+    // From here on the caller's totals have the per-cast blocks SUBTRACTED: whatever ends the loop early (a cast whose kernel has no counting
+    // build under HARE_SHOOT_COUNT_OWN, a failed launch) must put them back, or the totals stay short by what earlier loops counted (ADVICE)
+    auto fail = [&](int rc) {
+        const std::string msg = last_error();
+        (void)sum_counters(+1);
+        set_error(msg);
+        return rc;
+    };
     for (int32_t c = 0; c < casts; ++c) {
         hare_xevent* out_c = all ? all + (size_t)c * (size_t)n : last;
         void* ctr_c = d_ctr_casts ? (void*)((hare_counters*)d_ctr_casts + c) : d_ctr;
         const uint32_t f = flags | (c > 0 ? (uint32_t)HARE_SHOOT_RETIRED_RAYS : 0u);
-        if (int rc = shoot_device_impl(s, H, kind, top, n, d_rays, c == 0 ? d_e1 : work, c == 0 ? d_e2 : nullptr, f, out_c, ctr_c, st)) return rc;
+        if (int rc = shoot_device_impl(s, H, kind, top, n, d_rays, c == 0 ? d_e1 : work, c == 0 ? d_e2 : nullptr, f, out_c, ctr_c, st)) return fail(rc);
         if (c + 1 < casts) {
             const void* polys = s.d_polys[(size_t)top];
             const void* ev = out_c;
             void* ex = work;
             long long mm = n;
             void* a[] = {&polys, &d_rays, &ev, &ex, &mm};
-            if (int rc = launch(H, M.reflect, (unsigned)((n + 255) / 256), 256, 0, st, a)) return rc;
+            if (int rc = launch(H, M.reflect, (unsigned)((n + 255) / 256), 256, 0, st, a)) return fail(rc);
         }
     }
     if (all && d_last) HIP_TRY(H->MemcpyAsync(d_last, all + (size_t)(casts - 1) * (size_t)n, (size_t)n * sizeof(hare_xevent), hipMemcpyDeviceToDevice, st));

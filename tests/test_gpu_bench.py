@@ -146,3 +146,22 @@ def test_bench_single_gpu_lines_carry_roofline_and_cpu_baseline(extra, kernel):
         own = rf["own"]          # counted by the counting build of the kernel that was timed, on the same rays
         assert 0 < own["frac"] <= 1.0 and own["bytes_per_launch"] >= 104 * j["config"]["rays_per_gpu"]
         assert own["per_cast"]["L"] >= own["per_cast"]["K"] >= own["per_cast"]["T"] > 0
+
+
+def test_bench_inproc_sharded_leg_with_two_scenes_on_this_box_one_gpu():
+    """the path a one-process caller takes on a multi-GPU node -- ONE hare_shoot_batch_sharded and ONE
+    hare_bounce_batch_sharded call over one scene per device -- is in the line as `inproc_sharded` at every N > 1.  Here at N = 1 with two
+    scenes on this box's one device (the placement rule is scene k -> device k % device_count): rate, per-device kernel names, and
+    parity of the concatenated events (the shoot's, and the last cast of the 8-bounce loop) against the oracle on a sample that touches
+    both shards."""
+    n = 131072
+    j = _bench("--rays", str(n), "--steps", "2", "--warmup", "1", "--no-extra-configs", "--no-e2e", "--inproc-scenes", "2")
+    s = j["inproc_sharded"]
+    assert "error" not in s, s
+    assert s["scenes"] == 2 and s["devices"] == [0, 0] and s["rays_total"] == n
+    assert s["kernels"] == ["hare_voxel_pool_tri"]
+    assert s["shoot"]["rays"] == n and s["shoot"]["hits"] == j["hits"] and s["shoot"]["mrays_s"] > 0
+    assert n < s["bounce"]["casts"] <= 8 * n and s["bounce"]["mcasts_s"] > 0
+    assert s["parity_vs_oracle"] is True
+    k = _bench("--rays", str(n), "--steps", "2", "--warmup", "1", "--no-extra-configs", "--no-e2e")
+    assert "inproc_sharded" not in k                       # off by default at N = 1
