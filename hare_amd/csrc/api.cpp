@@ -746,7 +746,9 @@ int hare_reflect_device(hare_scene* s, int32_t top_index, int64_t n, void* d_ray
         return HARE_E_STATE;
     }
     const void* polys = s->d_polys[top_index];
-    void* args[] = {&polys, &d_rays, &d_events, &d_excl_out, &n};
+    int32_t marks_valid = 0;         // the caller's array: whatever it holds, it is output only here
+    unsigned char* no_bytes = nullptr;
+    void* args[] = {&polys, &d_rays, &d_events, &d_excl_out, &n, &marks_valid, &no_bytes};
     const unsigned block = 256;
     return launch(H, s->module->reflect, (unsigned)((n + block - 1) / block), block, 0, (hipStream_t)stream, args);
     GUARD_END
@@ -890,6 +892,7 @@ const OptionEntry kOptionTable[] = {
         {"batch_chunks", &SceneOptions::batch_chunks, 0, 16},
         {"coop_tail", &SceneOptions::coop_tail, 0, 1},
         {"wide_drain", &SceneOptions::wide_drain, 0, 1},
+        {"bounce_pack", &SceneOptions::bounce_pack, 0, 1},
         {"voxel_walk", &SceneOptions::voxel_walk, 0, 1},
 };
 }  // namespace

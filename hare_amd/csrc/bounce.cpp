@@ -188,7 +188,9 @@ int bounce_on_scene(Scene& s, const HipApi* H, Scene::BatchCtx& c, int32_t kind,
                 void* r = b.rays[cur];
                 const void* ev = b.ev[cast & 1];
                 void* ex = b.excl[cur];
-                void* a[] = {&polys, &r, &ev, &ex, &mm};
+                int32_t marks_valid = marks ? 1 : 0;       // excl[cur] carries the previous in-place reflection's marks: retired rays are not read again
+                unsigned char* no_bytes = nullptr;
+                void* a[] = {&polys, &r, &ev, &ex, &mm, &marks_valid, &no_bytes};
                 if ((rc = launch(H, M.reflect, (unsigned)((m + blk - 1) / blk), blk, 0, st, a))) return rc;
                 marks = true;
             }

@@ -102,6 +102,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_octree_occl", &m->octree_occl},
         {"hare_octree_occl_any", &m->octree_occl_any},
         {"hare_events_pack_slim", &m->events_pack_slim},
+        {"hare_live_blocks", &m->live_blocks},
         {"hare_live_count", &m->live_count},
         {"hare_scan_tiles", &m->scan_tiles},
         {"hare_reflect_compact", &m->reflect_compact},

@@ -29,6 +29,7 @@ static_assert(sizeof(CellRec) == 16, "cell record size");
 enum : uint32_t {
     SHOOT_WRITEBACK_ORIGIN = 1u,  // reproduce AABB.Intersect's origin move on the caller's rays (F11)
     SHOOT_SIMPLE_KERNEL = 4u,     // use the one-ray-per-lane kernel instead of the persistent one (A/B, diagnostics)
+    SHOOT_RETIRED_SILENT = 0x80000u,   // internal (bounce loop into ONE event buffer, launch.cpp): a retired ray's slot already holds its miss record -- the pool kernel writes nothing for it
     SHOOT_RETIRED_RAYS = 8u,      // bounce loop: excl1 == -2 marks a ray hare_reflect retired -> miss record, no traversal, not counted
     SHOOT_SLIM_EVENTS = 16u,      // host-buffer calls: 16 / 32-byte result records (hare_slim_event*).  To the voxel kernels it means: for a
                                   // ray whose origin AABB.Intersect moved, leave tmin (t measured from the moved origin) in X_Event.u, which
@@ -442,6 +443,10 @@ struct ShootIO {
     unsigned long long* ctr_casts;   // nullable: bounce_casts counter blocks (rays = rays that started the cast, hits), accumulated
     const uint32_t* order;     // K1q, nullable: the ORDER in which the launch takes the batch's rays -- position k of the static chunks / tickets is ray
                                // order[k] (a permutation of 0 .. n-1; rays, events and exclusions stay where the caller has them)
+    // K1q, a cast of the bounce loop behind hare_reflect + hare_live_blocks (launch.cpp; null otherwise):
+    const uint32_t* blocks;    // the ascending LIST of the blocks of 64 consecutive rays in which a ray still lives: position k of the static chunks / tickets is
+                               // ray blocks[k >> 6] * 64 + (k & 63); blocks in which every ray is retired are not in it and cost the cast nothing
+    const uint32_t* blk_words; // [0]: the list's length, in device memory (no host round trip)
     int32_t hand_walk;         // K1q: 1 = the DDA step loop written by hand (voxel_walk.h), 0 = the compiler's (scene option "voxel_walk")
     unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
     int32_t oct_spill_cap;

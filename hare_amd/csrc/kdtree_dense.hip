@@ -66,7 +66,6 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
     constexpr int P = HARE_K3D_PEND;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     const int slots = g.max_depth + 2;
     int* const st_node = reinterpret_cast<int*>(lds);                          // [slots][nt] nodes pushed and not yet popped (the `second`s)
     float* const st_un = reinterpret_cast<float*>(st_node + (size_t)slots * nt);   // [slots][nt] lower bound of the entry into their tight box
@@ -163,7 +162,7 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                     if (cn >= n32) { drained = true; timeline(1); break; }
                     ce = (n32 - cn > dyn) ? cn + dyn : n32;
                 }
-                const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
+                const unsigned int mine = cn + rank_below(wm);
                 const bool got = want && mine < ce;
                 cn += (unsigned int)__popcll(__ballot(got));
                 bool live_lane = false;

@@ -32,6 +32,13 @@
 
 using namespace hare;
 
+// Lanes of `m` below the calling lane: v_mbcnt_lo + v_mbcnt_hi on the (usually scalar) mask -- two instructions and no register held, where
+// `__popcll(m & lane_lt)` kept a 64-bit per-lane constant alive through the whole kernel (two VGPRs, spilled to scratch in K2d: round 6).
+__device__ __forceinline__ unsigned rank_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 #include "voxel_coop.hip"      // coop_trace: one ray traced by a whole wave (the cooperative tail of K1p and K1q)
 #include "octree_coop.hip"     // coop_octree: the same for Octree.Shoot (kernel K2t behind K2p)
 
@@ -90,7 +97,7 @@ __device__ __forceinline__ void launch_epilogue(const ShootIO& io, unsigned int 
     const unsigned long long r = wave_sum_u32(nrays), h = wave_sum_u32(nhits);               // valid in lane 0
     int last = 0;
     if (lane == 0) {
-        if (io.ctr) {
+        if (io.ctr && (r | h) != 0ull) {                  // (a wave that cast nothing has nothing to add: an empty cast of the bounce loop is all epilogue)
             const unsigned shard = (blockIdx.x * waves_per_block + (threadIdx.x >> 6)) & 63u;
             unsigned long long a = atomicAdd(&acc[2u * shard], r);
             unsigned long long b = atomicAdd(&acc[2u * shard + 1u], h);
@@ -198,6 +205,58 @@ __device__ __forceinline__ void voxel_shoot_body(const VoxelArgs& g, const Shoot
 }
 
 
+
+// The live blocks of a bounce cast, ascending, and their number, from hare_reflect's byte per block: ONE workgroup of NT lanes
+// (hare_live_blocks), each lane a contiguous share of the bytes (a byte per 64 rays: 64 KB for four million rays) -- count, one
+// workgroup-wide exclusive scan, write.  Two barriers whatever the batch size.  Deterministic -- no atomics: the waves meet the same rays in
+// the same positions run after run.  (wsum: NT / 64 words of LDS.)
+template <int NT>
+__device__ __forceinline__ void build_live_list(const unsigned char* block_live, uint32_t nblk, uint32_t* list, uint32_t* count, uint32_t* wsum)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t per = ((nblk + (uint32_t)NT - 1u) / (uint32_t)NT + 15u) & ~15u;         // bytes per lane, whole 16-byte words
+    const uint32_t b0 = threadIdx.x * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    uint32_t c = 0;
+    for (uint32_t b = b0; b < b1; b += 16u) {
+        if (b + 16u <= b1) {
+            const uint4 w = *reinterpret_cast<const uint4*>(block_live + b);       // bytes are 0 / 1: a popcount per word
+            c += (uint32_t)__popc(w.x) + (uint32_t)__popc(w.y) + (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w);
+        } else {
+            for (uint32_t k = b; k < b1; ++k) c += block_live[k] != 0 ? 1u : 0u;
+        }
+    }
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t o = inc - c;
+    for (int w = 0; w < wid; ++w) o += wsum[w];
+    for (uint32_t b = b0; b < b1; b += 16u) {               // again sixteen bytes per load (a byte at a time: 64 dependent loads a lane, 30 us)
+        if (b + 16u <= b1) {
+            const uint4 w4 = *reinterpret_cast<const uint4*>(block_live + b);
+            const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t m = ws[q];
+                while (m) {
+                    const int bit = __ffs((int)m) - 1;      // bytes are 0 / 1: the set bit is bit 0 of its byte
+                    list[o++] = b + 4u * (uint32_t)q + ((uint32_t)bit >> 3);
+                    m &= m - 1u;
+                }
+            }
+        } else {
+            for (uint32_t k = b; k < b1; ++k)
+                if (block_live[k] != 0) list[o++] = k;
+        }
+    }
+    if (threadIdx.x == NT - 1) count[0] = o;          // the last lane's end = the total
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1p: Voxel_Grid.Shoot as a persistent, wave-scheduled kernel.
 //
@@ -284,7 +343,6 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
     const int ct = g.ct;
     const double fct = (double)ct;
     const int lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     // developer timeline (flag 0x2000, tools/timeline_prof.py): per wave {start, last refill, end} on the
     // 100 MHz wall clock, stored straight to memory so that nothing stays live across the loop
     auto timeline = [&](int slot) {
@@ -424,7 +482,7 @@ __device__ __forceinline__ void voxel_persist_body(const VoxelArgs& g, const Sho
                     if (cn >= n32) { drained = true; break; }
                     ce = (n32 - cn > dyn) ? cn + dyn : n32;
                 }
-                const unsigned int rank = (unsigned int)__popcll(wm & lane_lt);
+                const unsigned int rank = rank_below(wm);
                 const unsigned int mine = cn + rank;
                 const bool got = want && mine < ce;
                 cn += (unsigned int)__popcll(__ballot(got));
@@ -836,7 +894,6 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     int* const seg_mark = pend_w + (size_t)P * nt + (tid >> 6) * 64;
 
     const int lane = tid & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     // developer timeline (flag 0x2000, tools/timeline_oct.py): per wave {start, tickets dry, end} on the 100 MHz wall clock
     auto timeline = [&](int slot) {
         if (__builtin_expect((io.flags & 0x2000u) != 0 && io.prof != nullptr, 0)) {
@@ -1069,7 +1126,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     if (cn >= n32) { drained = true; timeline(1); break; }
                     ce = (n32 - cn > dyn) ? cn + dyn : n32;
                 }
-                const unsigned int mine = cn + (unsigned int)__popcll(wm & lane_lt);
+                const unsigned int mine = cn + rank_below(wm);
                 const bool got = want && mine < ce;
                 cn += (unsigned int)__popcll(__ballot(got));
                 bool live_lane = false;
@@ -1442,7 +1499,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             if (lane == 0) base = atomicAdd(&reinterpret_cast<LaunchSlotMem*>(io.work)->oct_tail_count, (unsigned)__popcll(am));
             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             if (alive) {
-                unsigned char* rec = io.oct_tail + (size_t)(base + (unsigned)__popcll(am & lane_lt)) * (size_t)io.oct_tail_stride;
+                unsigned char* rec = io.oct_tail + (size_t)(base + rank_below(am)) * (size_t)io.oct_tail_stride;
                 OctTailRec h;
                 h.ray = ray; h.lvl = lvl; h.q = q; h.qe = qe; h.leaf_ca = leaf_ca;
                 h.closestT = closestT; h.bu = bu; h.bv = bv; h.pid = pid; h.hit = hit ? 1 : 0; h.pad = 0;
@@ -1625,17 +1682,17 @@ __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense_
 __global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }
 __global__ __launch_bounds__(256) void hare_kdtree_shoot_count(KdArgs g, ShootIO io) { kdtree_shoot_body<true>(g, io); }
 
-// K3: specular bounce (harness-defined): o' = X_Point, d' = d - (2*(d.n))*n,
-// next exclusion = the polygon just hit; rays that missed are marked dead (-2).
-__global__ __launch_bounds__(256) void hare_reflect(const PolyRec* polys, RayRec* rays, const XEventRec* ev,
-                                                    int32_t* excl_out, int64_t n)
+// K3: specular bounce (harness-defined): o' = X_Point, d' = d - (2*(d.n))*n, next exclusion = the polygon just hit; rays
+// that missed are marked dead (-2).  Returns whether the ray lives on.
+// marks_valid (the bounce loop from its second reflection on): excl_out already holds the previous reflection's marks, and a ray marked -2 is
+// retired -- its event is a miss record whatever it says, so neither the event (56 B) nor anything else of it is read.
+__device__ __forceinline__ bool reflect_one(const PolyRec* polys, RayRec* rays, const XEventRec* ev, int32_t* excl_out, int64_t i, bool marks_valid)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (marks_valid && excl_out[i] == -2) return false;
     const XEventRec e = ev[i];
     if (!e.hit) {
         excl_out[i] = -2;
-        return;
+        return false;
     }
     const RayRec r = rays[i];
     const PolyRec& p = polys[e.poly_id];
@@ -1648,6 +1705,33 @@ __global__ __launch_bounds__(256) void hare_reflect(const PolyRec* polys, RayRec
     o.dz = r.dz - k * p.n[2];
     rays[i] = o;
     excl_out[i] = e.poly_id;
+    return true;
+}
+// block_live (nullable; the bounce loop's launch-per-cast path on a grid the pool kernel serves, launch.cpp): one byte per block of 64
+// consecutive rays (a wave of this kernel), 1 when any ray of the block lives on.  hare_live_blocks turns the bytes into the list of live
+// blocks the pool kernel's next cast walks instead of the ray array: blocks in which every ray is retired cost it nothing -- open scenes,
+// round 6.
+__global__ __launch_bounds__(256) void hare_reflect(const PolyRec* polys, RayRec* rays, const XEventRec* ev,
+                                                    int32_t* excl_out, int64_t n, int32_t marks_valid, unsigned char* block_live)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n && reflect_one(polys, rays, ev, excl_out, i, marks_valid != 0);
+    if (block_live) {
+        const unsigned long long bm = __ballot(live);
+        const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && blk * 64 < n) block_live[blk] = bm != 0ull ? 1 : 0;
+    }
+}
+// One workgroup, behind hare_reflect on the stream: 5 us for four million rays.  What was tried instead, to save this launch where nothing
+// dies (a closed room pays ~1 % for it): the list built by hare_reflect's last workgroup behind a done-count (a fence + an atomic on one word
+// per workgroup: 1.1 ms per million rays -- an agent-scope release writes back an XCD's L2); the reflection itself as <= 512 persistent
+// workgroups that exchange their counts (0.8 ms as a chain, and with the counts read all at once still slower than the plain kernel's many small
+// workgroups on LIVE rays: C5 -4 %); the list built by the pool kernel's first workgroup while the others wait (the same fences: a cast over
+// retired rays 119 us instead of 59) -- profiles/r06_experiments/README.md.
+__global__ __launch_bounds__(1024) void hare_live_blocks(const unsigned char* block_live, uint32_t nblk, uint32_t* list, uint32_t* count)
+{
+    __shared__ uint32_t wsum[16];
+    build_live_list<1024>(block_live, nblk, list, count, wsum);
 }
 
 // ---- dead-ray compaction of the bounce loop (hare_bounce_batch; SURVEY.md 7.1 step 9, 8(a) A9 "reflect_compact") ----
@@ -1722,7 +1806,7 @@ __global__ __launch_bounds__(256) void hare_reflect_compact(const PolyRec* polys
         const unsigned long long bm = __ballot(live);
         if (lane == 0) wc[wid] = (uint32_t)__popcll(bm);
         __syncthreads();
-        uint32_t off = run + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+        uint32_t off = run + rank_below(bm);
         for (int w = 0; w < wid; ++w) off += wc[w];
         run += wc[0] + wc[1] + wc[2] + wc[3];
         __syncthreads();

@@ -169,6 +169,7 @@ void read_env_options(SceneOptions& o)
     if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_TIGHT")) o.voxel_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_WALK")) o.voxel_walk = atoi(t) != 0;
+    if (const char* t = getenv("HARE_BOUNCE_PACK")) o.bounce_pack = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_ORDER")) o.voxel_order = std::max(0, std::min(2, atoi(t)));
     if (const char* t = getenv("HARE_VOXEL_ORDER_MAX_RAYS")) o.voxel_order_max_rays = std::max(0, atoi(t));
     if (const char* t = getenv("HARE_VOXEL_TIGHT_MAX_MB")) o.voxel_tight_max_mb = std::max(0, atoi(t));
@@ -511,6 +512,21 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
         void* a[] = {&pc, &cc, &d_ctr, &sign};
         return launch(H, M.counters_sum, 1, 64, 0, st, a);
     };
+    // Open scenes (round 6): behind every reflection the live BLOCKS of 64 rays are listed (hare_reflect: a byte per block; hare_live_blocks: the list), and
+    // the pool kernel's next cast walks that list instead of the ray array: a block in which every ray has been retired costs the cast nothing
+    // -- not a ticket, not a byte.  Device-side throughout (the count stays in device memory; no host round trip), no launch more than
+    // the plain loop makes.  The list lives in the second half of the caller's work array (2 n int32: the first half carries the marks; the
+    // second only serves the one-launch loop): n / 64 bytes, n / 64 words, the count.  A closed room, where nothing dies, pays the one-workgroup launch per cast (~1 %; scene option "bounce_pack" 0 switches it off).  Events and counters are those of the plain loop
+    // (tests: every cast against the oracle's loop, open soups and closed rooms).  Voxel_Grid batches the pool kernel serves only; other
+    // kernels cast all n rays and skip the retired ones as before.
+    const int64_t nblk = (n + 63) / 64;
+    unsigned char* const blk_live = (unsigned char*)(work + n);
+    uint32_t* const blk_list = (uint32_t*)(blk_live + ((nblk + 15) & ~(int64_t)15));
+    uint32_t* const blk_words = blk_list + nblk;          // {list length, epoch of the last dead block, epoch whose list is ready}
+    // (Not with a buffer per cast, `all`: there every slot of every cast is written, a retired ray's with its miss record.)
+    const bool use_blocks = !all && kind == HARE_KIND_VOXEL && M.live_blocks != nullptr && s.opt.bounce_pack != 0 && n >= 4096 && nblk <= 0x7FFFFFF0ll &&
+                            (size_t)((nblk + 15) & ~(int64_t)15) + (size_t)(nblk + 4) * 4u <= (size_t)n * 4u &&
+                            choose_kernel(s, &M, kind, (size_t)top, n, flags | HARE_SHOOT_RETIRED_RAYS).k == Kern::VoxelPool;
     if (int rc = sum_counters(-1)) return rc;            // the per-cast blocks are accumulated into: the totals get what THIS loop adds
     // From here on the caller's totals have the per-cast blocks SUBTRACTED: whatever ends the loop early (a cast whose kernel has no counting
     // build under HARE_SHOOT_COUNT_OWN, a failed launch) must put them back, or the totals stay short by what earlier loops counted (ADVICE)
@@ -524,14 +540,29 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
         hare_xevent* out_c = all ? all + (size_t)c * (size_t)n : last;
         void* ctr_c = d_ctr_casts ? (void*)((hare_counters*)d_ctr_casts + c) : d_ctr;
         const uint32_t f = flags | (c > 0 ? (uint32_t)HARE_SHOOT_RETIRED_RAYS : 0u);
-        if (int rc = shoot_device_impl(s, H, kind, top, n, d_rays, c == 0 ? d_e1 : work, c == 0 ? d_e2 : nullptr, f, out_c, ctr_c, st)) return fail(rc);
+        // every cast into ONE event buffer (`last`): a ray retired before this cast left its miss record there in the cast it died in, and the
+        // pool kernel need not write it again (SHOOT_RETIRED_SILENT); with a buffer per cast (`all`) every slot is written as before
+        ShootExtra extra;
+        extra.internal_flags = (c > 0 && !all) ? (uint32_t)SHOOT_RETIRED_SILENT : 0u;
+        if (c > 0 && use_blocks) { extra.blocks = blk_list; extra.blk_words = blk_words; }
+        if (int rc = shoot_device_impl(s, H, kind, top, n, d_rays, c == 0 ? d_e1 : work, c == 0 ? d_e2 : nullptr, f, out_c, ctr_c, st, nullptr, nullptr, &extra)) return fail(rc);
         if (c + 1 < casts) {
             const void* polys = s.d_polys[(size_t)top];
             const void* ev = out_c;
             void* ex = work;
             long long mm = n;
-            void* a[] = {&polys, &d_rays, &ev, &ex, &mm};
+            int32_t marks_valid = c > 0 ? 1 : 0;       // `work` holds the previous reflection's marks from the second reflection on
+            unsigned char* bl = use_blocks ? blk_live : nullptr;
+            void* a[] = {&polys, &d_rays, &ev, &ex, &mm, &marks_valid, &bl};
             if (int rc = launch(H, M.reflect, (unsigned)((n + 255) / 256), 256, 0, st, a)) return fail(rc);
+            if (use_blocks) {
+                uint32_t nb = (uint32_t)nblk;
+                const unsigned char* blc = blk_live;
+                uint32_t* lst = blk_list;
+                uint32_t* cnt = blk_words;
+                void* a2[] = {&blc, &nb, &lst, &cnt};
+                if (int rc = launch(H, M.live_blocks, 1, 1024, 0, st, a2)) return fail(rc);
+            }
         }
     }
     if (all && d_last) HIP_TRY(H->MemcpyAsync(d_last, all + (size_t)(casts - 1) * (size_t)n, (size_t)n * sizeof(hare_xevent), hipMemcpyDeviceToDevice, st));
@@ -541,7 +572,7 @@ int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int
 
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays,
                       const void* d_e1, const void* d_e2, uint32_t flags, void* d_out, void* d_ctr, hipStream_t st, const void* d_tmax,
-                      void* d_occ)
+                      void* d_occ, const ShootExtra* extra)
 {
     if (d_out && d_occ) {
         // events AND flags: the closest-hit cast as it is, then one compare per ray on the events it wrote (hare_occlusion)
@@ -598,7 +629,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
     io.tmax = (const double*)d_tmax;
     io.occluded = (int32_t*)d_occ;
     io.n = n;
-    io.flags = flags;
+    io.flags = flags | (extra ? extra->internal_flags : 0u);        // (internal bits -- SHOOT_RETIRED_SILENT -- come from this library's own loops, never through sanitize_flags)
     io.steps_per_round = 10;
     io.refill_min_idle = 16;
     io.ray_chunk = 128;
@@ -654,7 +685,8 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(128, (per_wave + 7) / 8 * 8));
             if (s.opt.k1p_static_rays > 0) io.static_rays = std::max(8, std::min(1024, s.opt.k1p_static_rays / 8 * 8));   // developer sweeps (tools/k1q_ticket_sweep.py)
             io.ticket_rays = ticket_rays_for(s, n, true);
-            if (s.opt.dev && s.opt.dev_order_ptr) io.order = (const uint32_t*)(uintptr_t)s.opt.dev_order_ptr;
+            if (extra && extra->blocks) { io.blocks = extra->blocks; io.blk_words = extra->blk_words; }      // a cast of the bounce loop: live blocks only
+            if (s.opt.dev && s.opt.dev_order_ptr && !io.blocks) io.order = (const uint32_t*)(uintptr_t)s.opt.dev_order_ptr;
             // The order in which K1q takes the rays (order_kernels.hip): inside every window of 4 096 consecutive rays, by an estimate of
             // the walk length -- a pool of rays of similar cost wastes fewer lane-steps (C4 shard -6.8 %, C2 -5.3 % of the kernel's time with
             // the order given; window_sort_*.log), the batch's own locality stays.  Rule ("voxel_order" 1, the default): batches of PRIMARY
@@ -662,7 +694,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // (+5 ... +8 %, window_sort_cathedral_bounce5.log) -- from kOrderMinRays: the pass reads every ray once more (12 us per million
             // rays: half of HBM's rate), which at 1M rays is what the order gains.  The scratch is a block of the scene's order ring
             // (stream-ordered allocation was tried first: hipMallocAsync / hipFreeAsync cost the stream more than the pass itself).
-            const bool order_rule = s.opt.voxel_order == 2 || (s.opt.voxel_order == 1 && !d_e1 && !d_e2 && !(flags & SHOOT_RETIRED_RAYS) && n >= kOrderMinRays);
+            const bool order_rule = io.blocks ? false : s.opt.voxel_order == 2 || (s.opt.voxel_order == 1 && !d_e1 && !d_e2 && !(flags & SHOOT_RETIRED_RAYS) && n >= kOrderMinRays);
             if (!io.order && order_rule && M.cost_order && (size_t)n <= s.order_cap && (flags & 0xF000u) == 0 && !stream_is_capturing(H, st)) {
                 // a block of the scene's order ring (scene.h), reserved when the grid went to the device: nothing is allocated, freed or
                 // synchronised here.  The block's mutex is held across wait + launches + record (four enqueues)

@@ -43,7 +43,6 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
     constexpr unsigned S = kOctPoolSlots, R = kOctPoolRing, SM = kOctPoolRing - 1;
     const int wave = threadIdx.x >> 6;
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     unsigned char* const wb = lds_raw + (size_t)wave * kOctPoolWaveBytes;
     double* const L_ct = reinterpret_cast<double*>(wb);      // closestT
     double* const L_fa = L_ct + S;                           // top frame: interval of its node
@@ -80,7 +79,7 @@ __device__ __forceinline__ void octree_pool_body(const OctreeArgs& g, const Shoo
     unsigned hD = 0, nD = 0, hC = 0, nC = 0, hE = 0, nE = 0, hF = 0, nF = S;
     auto push = [&](uint8_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
         const unsigned long long m = __ballot(flag);
-        if (flag) Q[(head + cnt + (unsigned)__popcll(m & lane_lt)) & SM] = (uint8_t)slot;
+        if (flag) Q[(head + cnt + rank_below(m)) & SM] = (uint8_t)slot;
         cnt += (unsigned)__popcll(m);
     };
     auto pop = [&](const uint8_t* Q, unsigned& head, unsigned& cnt, bool& active) -> unsigned {

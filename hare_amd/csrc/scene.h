@@ -54,6 +54,8 @@ struct SceneOptions {
     int batch_chunks = 0;      // chunks hare_shoot_batch pipelines a batch over (0 = the host's rule)
     int coop_tail = 1;         // 1: a drained wave traces its last rays with all 64 lanes (voxel_coop.hip); 0: as lanes of the pool to the end (A/B)
     int voxel_walk = 1;        // 1: K1q's DDA step loop as written by hand for gfx950 (voxel_walk.h: per-axis updates under EXEC masks); 0: the compiler's loop (A/B)
+    int bounce_pack = 1;       // 1: the launch-per-cast bounce loop of a Voxel_Grid lists the blocks of 64 rays in which a ray still lives behind every reflection (one
+                               // more one-workgroup launch per cast) and the next cast walks the list: open scenes; 0: off (a closed room saves ~1 %)
     int wide_drain = 1;        // 1: K1q's wide cull / wide walk in the drain of a launch (voxel_pool.hip); 0: the pool's ordinary phases to the end (A/B)
     long long dev_order_ptr = 0;   // developer experiments (a `dev` scene only): a device array of n uint32, the order K1q takes the rays in (ShootIO::order)
     int tune[5] = {0, 0, 0, 0, 0};   // HARE_TUNE: steps,refill,chunk,blocks_per_cu,exact (profiling build; blocks_per_cu: K1p)
@@ -113,6 +115,7 @@ struct DeviceModule {
     hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr, octree_occl_any = nullptr;
     hipFunction_t events_pack_slim = nullptr;
+    hipFunction_t live_blocks = nullptr;                                   // kernels.hip: hare_live_blocks (the bounce loop's block list)
     hipFunction_t live_count = nullptr, scan_tiles = nullptr, reflect_compact = nullptr, events_fill_miss = nullptr, events_expand = nullptr;
     hipFunction_t cull_audit = nullptr;
     hipFunction_t voxel_persist_prof = nullptr;
@@ -277,7 +280,15 @@ const char* last_error();
 // the launcher behind every shoot entry point (launch.cpp)
 // d_occ != null: also (d_out != null) or only (d_out == null) the occlusion flags against d_tmax (nullable: any hit)
 int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays, const void* d_e1, const void* d_e2,
-                      uint32_t flags, void* d_out, void* d_ctr, hipStream_t st, const void* d_tmax = nullptr, void* d_occ = nullptr);
+                      uint32_t flags, void* d_out, void* d_ctr, hipStream_t st, const void* d_tmax = nullptr, void* d_occ = nullptr,
+                      const struct ShootExtra* extra = nullptr);
+// what this library's own loops add to a cast (never a caller): internal flag bits (SHOOT_RETIRED_SILENT) and the bounce loop's block list
+struct ShootExtra {
+    uint32_t internal_flags = 0;
+    // the bounce loop's block list (ShootIO, hare_device.h); only the pool kernel K1q reads it, other kernels cast all n rays
+    const uint32_t* blocks = nullptr;
+    const uint32_t* blk_words = nullptr;
+};
 int bounce_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int64_t n, void* d_rays, const void* d_e1, const void* d_e2,
                        int32_t casts, uint32_t flags, void* d_work, void* d_all, void* d_last, void* d_ctr, void* d_ctr_casts, hipStream_t st);
 uint32_t sanitize_flags(const Scene& s, uint32_t flags);

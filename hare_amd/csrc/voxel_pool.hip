@@ -125,7 +125,6 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     // on it a v_cmp + saveexec + branch (round 6: that bookkeeping was two fifths of a wave's time)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     unsigned char* const wb = lds_raw + ((size_t)nw4 << 4) + (size_t)wave * kPoolWaveBytes;
     double* const L_tmx = reinterpret_cast<double*>(wb);
     double* const L_tmy = L_tmx + S;
@@ -181,7 +180,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #endif
     auto push = [&](uint8_t* Q, unsigned head, unsigned& cnt, bool flag, unsigned slot) {
         const unsigned long long m = __ballot(flag);
-        if (flag) Q[(head + cnt + (unsigned)__popcll(m & lane_lt)) & SM] = (uint8_t)slot;
+        if (flag) Q[(head + cnt + rank_below(m)) & SM] = (uint8_t)slot;
         cnt += (unsigned)__popcll(m);
     };
     auto pop = [&](const uint8_t* Q, unsigned& head, unsigned& cnt, bool& active) -> unsigned {
@@ -194,7 +193,18 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     };
 
     // ray chunks: static first chunk per wave (XCD-contiguous), then tickets -- as in K1p
-    const unsigned n32 = (unsigned)io.n;
+    // the batch: io.n rays, or -- a cast of the bounce loop behind hare_reflect's block list -- the rays of the listed blocks (n_real guards the batch's
+    // last, partial block)
+    const unsigned n_real = (unsigned)io.n;
+    unsigned n32 = n_real;
+    // ... or -- a cast of the bounce loop behind hare_live_blocks (kernels.hip) -- the rays of the listed blocks of 64: a block in which every ray
+    // has been retired is not in the list and costs this cast nothing.  A list that holds EVERY block (a closed room: nothing dies) is not
+    // consulted at all.
+    const uint32_t* blocks = nullptr;
+    if (io.blocks) {
+        const unsigned nb = (unsigned)__builtin_amdgcn_readfirstlane((int)io.blk_words[0]);
+        if (nb < (n_real + 63u) / 64u) { blocks = io.blocks; n32 = nb * 64u; }     // (the batch's last block may reach past n_real: those lanes hold no ray)
+    }
 #ifndef HARE_K1Q_STATIC
 #define HARE_K1Q_STATIC 128
 #endif
@@ -343,7 +353,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         K1Q_CLOCK(9)
         // ------------------------------------------------------------------ set-up of new rays into free slots
         if (!drained && (nF >= (unsigned)HARE_K1Q_REFILL_MIN || nW + nC + nE + nP + nR == 0)) {
-            if (cn >= ce) {
+            if (cn >= ce && n_static >= n32) {
+                // the static first chunks cover the whole batch (a small batch; a bounce cast whose block list is short or empty): there is no
+                // ticket to draw -- 3 072 waves drawing one each from one address is 34 us, half of what an EMPTY cast used to cost
+                drained = true;
+                cn = ce = n32;
+                timeline(1, __builtin_amdgcn_s_memrealtime());
+            } else if (cn >= ce) {
                 unsigned base = 0;
                 unsigned dyn = (unsigned)io.ticket_rays;
                 if (io.flags & SHOOT_RETIRED_RAYS) {
@@ -373,18 +389,26 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const unsigned slot = Q_free[(hF + (act ? lane : 0u)) & SM];
                 hF = (hF + m) & SM;
                 nF -= m;
-                const unsigned ray = (io.order != nullptr && act) ? io.order[cn + lane] : cn + lane;
+                unsigned ray = (io.order != nullptr && act) ? io.order[cn + lane] : cn + lane;
+                if (blocks != nullptr && act) ray = (blocks[(cn + lane) >> 6] << 6) | ((cn + lane) & 63u);
                 cn += m;
                 bool to_walk = false, to_cull = false, freed = false, retired_lane = false;
                 if (act) {
-                    const RayRec r = io.rays[ray];
-                    const V3 o = {r.x, r.y, r.z};
-                    const V3 d = {r.dx, r.dy, r.dz};
-                    if ((io.flags & SHOOT_RETIRED_RAYS) && io.excl1 && io.excl1[ray] == -2) {   // retired by the bounce loop: miss, not counted
-                        store_miss(ray);
+                    // a ray the bounce loop retired (hare_reflect marked it -2): a miss record, no traversal, not counted -- and NOTHING ELSE of it
+                    // is touched under SHOOT_RETIRED_SILENT -- the loop writes every
+                    // cast into ONE event buffer, so the slot already holds the miss record of the cast the ray died in -- nothing is written
+                    // (round 6: a cast over a million retired rays 72 -> see profiles/r06_experiments/bounce_open_scene.log)
+                    const bool past_end = ray >= n_real;                 // the tail of the batch's last block (a block list only)
+                    // (the record is requested together with the mark, not behind it: a set-up round waits for ONE round of loads.  Blocks in
+                    //  which every ray is retired never get here -- the block list -- so the record of a retired ray is read only next to live ones)
+                    const RayRec r = io.rays[past_end ? 0u : ray];
+                    retired_lane = past_end || ((io.flags & SHOOT_RETIRED_RAYS) && io.excl1 && io.excl1[ray] == -2);
+                    if (retired_lane) {
+                        if (!past_end && !(io.flags & SHOOT_RETIRED_SILENT)) store_miss(ray);
                         freed = true;
-                        retired_lane = true;
                     } else {
+                        const V3 o = {r.x, r.y, r.z};
+                        const V3 d = {r.dx, r.dy, r.dz};
                         nrays++;
                         if (BOUNCE) { L_cast[slot] = 0; atomicAdd(&C_rays[0], 1u); }
                         arm(slot, ray, o, d, to_walk, to_cull, freed);

@@ -187,6 +187,9 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *                     2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray), 4: hare_octree_dense (K2d: K2p with its leaf
  *                     entries spread densely over the wave and its exact tests deferred)
  *   "bounce_fused"    1: hare_bounce_device / hare_bounce_batch (last cast's events only) run a Voxel_Grid's bounce loop as ONE launch where they can; 0 (default): a launch per cast
+ *   "bounce_pack"     1 (default): behind every reflection of a Voxel_Grid's launch-per-cast loop (last cast's events only) the blocks of 64 consecutive rays
+ *                     in which a ray still lives are listed on the device, and the next cast walks that list: a cast costs nothing for rays retired in
+ *                     whole blocks (open scenes: 72 -> 14 us per million retired rays).  One more one-workgroup launch per cast: 0 saves a closed room ~1 %
  *   "octree_tail"     what finishes the rays K2p's waves still walk at the end of a launch: 2 (default) hare_octree_group_tail (eight lanes per
  *                     ray, every ray a wave holds 32 rounds after its tickets ran dry), 1 hare_octree_tail (a wave per ray, a wave's last 16), 0 nothing
  *   "k2p_tail_max", "k2p_tail_patience"   the hand-over rule (0 / -1: the library's)
