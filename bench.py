@@ -48,7 +48,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-KERNEL_SOURCES = ("hare_amd/csrc/kernels.hip", "hare_amd/csrc/voxel_pool.hip", "hare_amd/csrc/voxel_coop.hip", "hare_amd/csrc/octree_pool.hip",
+KERNEL_SOURCES = ("hare_amd/csrc/kernels.hip", "hare_amd/csrc/voxel_pool.hip", "hare_amd/csrc/voxel_walk.h", "hare_amd/csrc/voxel_coop.hip", "hare_amd/csrc/octree_pool.hip",
                   "hare_amd/csrc/octree_coop.hip", "hare_amd/csrc/octree_group.hip", "hare_amd/csrc/kdtree_dense.hip", "hare_amd/csrc/order_kernels.hip", "hare_amd/csrc/hare_math.h",
                   "hare_amd/csrc/hare_trace.h", "hare_amd/csrc/hare_device.h")
 
@@ -655,7 +655,7 @@ def measure(w, env):
                        # S: DDA steps the kernel EXECUTES per cast.  It equals C' by construction: round 6 made the step cheap (voxel_walk.h: 17 / 20
                        # vector instructions where the compiler wrote 40), it does not skip voxels -- see DESIGN.md 5 for why the closed-form block
                        # skip loses to a cheap step on this machine
-                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), "S": round(oc[2] / max(casts, 1), 2) if kind == "voxel" else None,
+                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), **({"S": round(oc[2] / max(casts, 1), 2)} if kind == "voxel" else {}),
                                     "L": round(oc[3] / max(casts, 1), 2),
                                     "K": round(oc[5] / max(casts, 1), 2), "T": round(oc[4] / max(casts, 1), 2)},
                        "formula": f"104+{cw}C'+4L'+{kb}K'+128T' (+28/bounce), counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}

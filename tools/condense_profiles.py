@@ -13,10 +13,11 @@ SHOOT = ("hare_voxel_persist", "hare_voxel_pool", "hare_octree_persist", "hare_o
          "hare_cost_order",        # the order pass in front of the pool kernel on large batches of primary rays: part of the cast
          "hare_reflect")
 NSHOOT = len(SHOOT) - 1          # the kernels a shoot consists of (hare_reflect is listed in the summary, not priced)
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 KEYS = {"c2": "hall-voxel-D64-n1048576", "c2_4M": "hall-voxel-D64-n4194304", "c3": "hall-octree-n1048576", "c3_262k": "hall-octree-n262144",
         "c4shard": "cathedral-voxel-D128-n2097152", "c5": "cathedral-voxel-D128-n1048576-b8", "kd": "shoebox-kdtree-n1048576",
-        "kd_hall": "hall-kdtree-n1048576", "c2_quads": "hall_quads-voxel-D64-n1048576"}
+        "kd_hall": "hall-kdtree-n1048576", "c2_quads": "hall_quads-voxel-D64-n1048576",
+        "c4": "cathedral-voxel-D128-n16777216", "c5full": "cathedral-voxel-D128-n8388608-b8"}
 
 
 def counters(d):

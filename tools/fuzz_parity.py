@@ -48,6 +48,32 @@ def main():
             bad = same(got, refm) or (None if np.array_equal(r.view(np.int64), movedref.view(np.int64)) else "moved origins differ")
             if bad: print("MISMATCH", cfg, "writeback", bad); return 1
         g.set_option("voxel_kernel", 0)
+        # round 6: the pool kernel's step loop as the compiler writes it (the default is the hand-written one, voxel_walk.h), the drain's wide modes off too
+        g.set_option("voxel_kernel", 2); g.set_option("voxel_walk", 0)
+        for wide in (1, 0):
+            g.set_option("wide_drain", wide)
+            cfg = "seed %d voxel D=%d n=%d pool kernel, compiler's step loop, wide_drain %d" % (seed, D, n, wide)
+            for what, got, want in (("plain", g.Shoot_batch(rays)[0], ref), ("excl", g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], refx)):
+                bad = same(got, want); checks += 1
+                if bad: print("MISMATCH", cfg, what, bad); return 1
+        g.set_option("voxel_walk", 1)
+        if seed % 3 == 1:       # ... and the hand-written loop with the wide drain off (the pool's ordinary walk to the end)
+            g.set_option("wide_drain", 0)
+            bad = same(g.Shoot_batch(rays)[0], ref); checks += 1
+            if bad: print("MISMATCH seed %d voxel D=%d n=%d hand-written loop, wide_drain 0" % (seed, D, n), bad); return 1
+        g.set_option("wide_drain", 1); g.set_option("voxel_kernel", 0)
+        if seed % 5 == 2:
+            # round 6: hare_bounce_batch, last cast's events only: the launch-per-cast loop with the live-block list (bounce_pack 1: from
+            # 4 096 rays) and without, against the oracle's loop -- open soups: rays leave, whole blocks of 64 die
+            from tests.helpers import oracle_bounce_loop
+            rb = np.ascontiguousarray(np.concatenate([rays, rays[::-1] * np.array([1, 1, 1, -1, -1, -1.0])]))[:int(rng.choice([4096, 5000, 8000]))]
+            refb, _ = oracle_bounce_loop(po, To, o, rb, 5)
+            for pack in (1, 0):
+                g.set_option("bounce_pack", pack)
+                evb, _ = g.Bounce_batch(rb, 5)
+                bad = same(evb, refb[4]); checks += 1
+                if bad: print("MISMATCH seed %d voxel D=%d bounce loop n=%d bounce_pack %d" % (seed, D, len(rb), pack), bad); return 1
+            g.set_option("bounce_pack", 1)
         depth, maxp = int(rng.integers(0, 9)), int(rng.integers(1, 40))
         # the reference pads child boxes by an ABSOLUTE 0.1 m ("Octree - alt.cs":99-111): below ~0.4 m a node's
         # polygons land in all eight children and the tree grows 8x per level in ANY implementation -- keep nodes above 1 m

@@ -1,9 +1,10 @@
-# Round-5 profiles (run on the MI355X box): rocprofv3 kernel-trace stats and PMC passes for the bench configurations.
+# Profiles of a round (ROUND=r06 by default; run on the MI355X box): rocprofv3 kernel-trace stats and PMC passes for the bench configurations.
 # FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), the SQ counters in two more, TA / TCP in a fifth; never combined with other
-# trace domains.  Condensed into profiles/r05_* by tools/condense_profiles.py (ROUND=r05).
+# trace domains.  Condensed into profiles/<round>_* by tools/condense_profiles.py.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05prof
+ROUND=${ROUND:-r06}
+O=$R/gpurun_out/${ROUND}prof
 mkdir -p $O
 pmc() {  # tag, pass name, counters..., then "--", bench args
   tag=$1; name=$2; shift 2
@@ -40,5 +41,8 @@ want c5 && prof c5 --scene cathedral --domain 128 --bounces 8 --steps 3 --warmup
 want kd && prof kd --kind kdtree --scene shoebox --rays 1048576 --steps 5 --warmup 1
 want kd_hall && prof kd_hall --kind kdtree --scene hall --rays 1048576 --steps 5 --warmup 1
 want c2_quads && prof c2_quads --scene hall_quads --steps 10 --warmup 2
+# configs 4 and 5 at FULL size on one GPU (the N = 1 point of the strong-scaling curve): their traffic / issue figures
+want c4 && prof c4 --scene cathedral --domain 128 --rays 16777216 --steps 3 --warmup 1
+want c5full && prof c5full --scene cathedral --domain 128 --rays 8388608 --bounces 8 --steps 2 --warmup 1
 echo "done: $ONLY" >> $O/progress.log
-[ -n "$NO_CONDENSE" ] || ROUND=r05 python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1
+[ -n "$NO_CONDENSE" ] || ROUND=$ROUND python3 $R/tools/condense_profiles.py $O > $O/summary.txt 2>&1

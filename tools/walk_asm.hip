@@ -3,6 +3,10 @@
 // occupied voxel or when it leaves the grid, twelve waves per CU, all lanes walking.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I hare_amd/csrc tools/walk_asm.hip -o /tmp/walk_asm && /tmp/walk_asm
 // Both kernels must report the same steps and the same checksum (the voxels visited and the tMax bits at every stop).
+// MODE 2 (round 6): the EXACT closed-form skip over empty aligned 4^3 blocks that round 4 wrote down -- the DDA is a merge of
+// three sequences tMax + j tDelta (sequential adds) under "smaller first, the later axis on a tie", so the axis that leaves the block first
+// and the steps the other two have taken by then follow from <= 3 adds and compares per axis -- beside the compiler's step (a lane jumps when
+// its block is empty, steps otherwise).  Same checksum (it IS exact); its rate against the hand-written step is the measurement asked for.
 #include <hip/hip_runtime.h>
 #pragma clang diagnostic ignored "-Wunused-value"
 #include <cmath>
@@ -18,6 +22,16 @@ __global__ __launch_bounds__(768) void walk(const double* rays, const unsigned* 
     extern __shared__ unsigned locc[];
     const int cdw = occ_shift ? (occ_cd * occ_cd * occ_cd + 31) / 32 : ct * ct * ct / 32;
     for (int k = threadIdx.x; k < cdw; k += blockDim.x) locc[k] = occ[k];
+    if (MODE == 2) {
+        const int nb = (ct + 3) >> 2, nbw = (nb * nb * nb + 31) / 32;
+        for (int k = threadIdx.x; k < nbw; k += blockDim.x) locc[cdw + k] = 0u;
+        __syncthreads();
+        for (int c = threadIdx.x; c < ct * ct * ct; c += blockDim.x)
+            if ((locc[c >> 5] >> (c & 31)) & 1u) {
+                const int z = c % ct, y = (c / ct) % ct, x = c / (ct * ct), b = ((x >> 2) * nb + (y >> 2)) * nb + (z >> 2);
+                atomicOr(&locc[cdw + (b >> 5)], 1u << (b & 31));
+            }
+    }
     __syncthreads();
     unsigned long long steps = 0, sum = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -52,6 +66,56 @@ __global__ __launch_bounds__(768) void walk(const double* rays, const unsigned* 
                         if (!o) ++steps;
                     }
                 }
+            } else if (MODE == 2) {
+                // exact block skip: `bocc` (LDS, behind the voxel bitmap) has a bit per aligned 4^3 block that holds an occupied voxel
+                const unsigned* bocc = locc + cdw;
+                const int nb = (ct + 3) >> 2;
+#pragma unroll 1
+                for (int k = 0; k < 16; ++k) {
+                    const unsigned long long wm = __ballot(walking);
+                    if (wm == 0) break;
+                    if (walking) {
+                        const int bxi = ((X >> 2) * nb + (Y >> 2)) * nb + (Z >> 2);
+                        const bool finite = fabs(tMaxX) < 1e300 && fabs(tMaxY) < 1e300 && fabs(tMaxZ) < 1e300 && fabs(tDeltaX) < 1e300 && fabs(tDeltaY) < 1e300 && fabs(tDeltaZ) < 1e300;
+                        const bool empty_block = finite && !((bocc[bxi >> 5] >> (bxi & 31)) & 1u);
+                        if (empty_block) {
+                            const int kx = dx1 > 0 ? 4 - (X & 3) : (X & 3) + 1, ky = dy1 > 0 ? 4 - (Y & 3) : (Y & 3) + 1, kz = dz1 > 0 ? 4 - (Z & 3) : (Z & 3) + 1;
+                            const double ax1 = tMaxX + tDeltaX, ax2 = ax1 + tDeltaX, ax3 = ax2 + tDeltaX, ax4 = ax3 + tDeltaX;
+                            const double ay1 = tMaxY + tDeltaY, ay2 = ay1 + tDeltaY, ay3 = ay2 + tDeltaY, ay4 = ay3 + tDeltaY;
+                            const double az1 = tMaxZ + tDeltaZ, az2 = az1 + tDeltaZ, az3 = az2 + tDeltaZ, az4 = az3 + tDeltaZ;
+                            auto sel = [](int j, double a0, double a1, double a2, double a3, double a4) { return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : (j == 3 ? a3 : a4))); };
+                            const double Ex = sel(kx - 1, tMaxX, ax1, ax2, ax3, ax4), Ey = sel(ky - 1, tMaxY, ay1, ay2, ay3, ay4), Ez = sel(kz - 1, tMaxZ, az1, az2, az3, az4);
+                            // the exit axis: the DDA's own choice among the three exit elements (x iff Ex < Ey && Ex < Ez; else y iff Ey < Ez; else z)
+                            const bool ex = (Ex < Ey) & (Ex < Ez), ey = (!(Ex < Ey)) & (Ey < Ez), ez = !(ex | ey);
+                            const double E = ex ? Ex : (ey ? Ey : Ez);
+                            // elements of another axis that come BEFORE the exit element: a < E, or a == E when that axis is the later one
+                            auto cnt = [&](bool later, int kk, double a0, double a1, double a2) {
+                                int c = 0;
+                                c += (kk > 1 && (a0 < E || (later && a0 == E))) ? 1 : 0;
+                                c += (kk > 2 && (a1 < E || (later && a1 == E))) ? 1 : 0;
+                                c += (kk > 3 && (a2 < E || (later && a2 == E))) ? 1 : 0;
+                                return c;
+                            };
+                            const int nx = ex ? kx : cnt(false, kx, tMaxX, ax1, ax2);                 // x is never the later axis
+                            const int ny = ey ? ky : cnt(ex, ky, tMaxY, ay1, ay2);                    // y is later than x only
+                            const int nz = ez ? kz : cnt(true, kz, tMaxZ, az1, az2);                  // z is later than both
+                            X += dx1 * nx; Y += dy1 * ny; Z += dz1 * nz;
+                            tMaxX = sel(nx, tMaxX, ax1, ax2, ax3, ax4); tMaxY = sel(ny, tMaxY, ay1, ay2, ay3, ay4); tMaxZ = sel(nz, tMaxZ, az1, az2, az3, az4);
+                            steps += (unsigned)(nx + ny + nz) - 1u;        // the voxels passed on the way count as walked (the arrival is counted below)
+                        } else {
+                            const bool cxy = tMaxX < tMaxY, cxz = tMaxX < tMaxZ, cyz = tMaxY < tMaxZ;
+                            const bool sx = cxy & cxz, sy = (!cxy) & cyz, sz = !(sx | sy);
+                            const double nX = tMaxX + tDeltaX, nY = tMaxY + tDeltaY, nZ = tMaxZ + tDeltaZ;
+                            X += sx ? dx1 : 0; Y += sy ? dy1 : 0; Z += sz ? dz1 : 0;
+                            tMaxX = sx ? nX : tMaxX; tMaxY = sy ? nY : tMaxY; tMaxZ = sz ? nZ : tMaxZ;
+                        }
+                        const bool o = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
+                        const int cell = o ? 0 : (X * ct + Y) * ct + Z;
+                        const bool oc = (locc[cell >> 5] >> (cell & 31)) & 1u;
+                        walking = !o && !oc;
+                        if (!o) ++steps;
+                    }
+                }
             } else {
                 const int n0 = __popcll(__ballot(walking));
                 const int walk_min = n0 / 3 < 20 ? n0 / 3 : 20;
@@ -82,10 +146,15 @@ int main()
             rays[6 * i + 3] = r * std::cos(phi); rays[6 * i + 4] = r * std::sin(phi); rays[6 * i + 5] = z;
         }
         std::vector<unsigned> occ((size_t)occ_cd * occ_cd * occ_cd / 32, 0u);
+        // a room: walls one voxel (block) inside the grid's faces, a balcony slab, 1 % clutter -- most aligned 4^3 blocks are empty, as in the hall
         unsigned long long h = 88172645463325252ull;
-        for (size_t c = 0; c < (size_t)occ_cd * occ_cd * occ_cd; ++c) {
+        const int cd = occ_cd;
+        for (size_t c = 0; c < (size_t)cd * cd * cd; ++c) {
             h ^= h << 13; h ^= h >> 7; h ^= h << 17;
-            if (h % 10 == 0) occ[c >> 5] |= 1u << (c & 31);
+            const int z = (int)(c % cd), y = (int)((c / cd) % cd), x = (int)(c / ((size_t)cd * cd));
+            const bool wall = x == 1 || y == 1 || z == 1 || x == cd - 2 || y == cd - 2 || z == cd - 2;
+            const bool balcony = z == cd / 3 && x < cd / 3;
+            if (wall || balcony || h % 100 == 0) occ[c >> 5] |= 1u << (c & 31);
         }
         double* d_rays; unsigned* d_occ; unsigned long long* d_out;
         hipMalloc(&d_rays, rays.size() * 8); hipMalloc(&d_occ, occ.size() * 4); hipMalloc(&d_out, 16);
@@ -108,6 +177,10 @@ int main()
         hipFuncSetAttribute((const void*)walk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         run("compiler (selects)", walk<0>);
         run("hand-written step loop", walk<1>);
+        if (!occ_shift) {
+            hipFuncSetAttribute((const void*)walk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            run("exact 4^3 block skip + step", walk<2>);
+        }
         hipFree(d_rays); hipFree(d_occ); hipFree(d_out);
     }
     return 0;
