@@ -447,6 +447,7 @@ struct ShootIO {
     const uint32_t* blocks;    // the ascending LIST of the blocks of 64 consecutive rays in which a ray still lives: position k of the static chunks / tickets is
                                // ray blocks[k >> 6] * 64 + (k & 63); blocks in which every ray is retired are not in it and cost the cast nothing
     const uint32_t* blk_words; // [0]: the list's length, in device memory (no host round trip)
+    int32_t walk_steps;        // K1q: DDA steps per walk task at most (0: HARE_K1Q_WALK_STEPS); the host's rule by batch size (launch.cpp)
     int32_t hand_walk;         // K1q: 1 = the DDA step loop written by hand (voxel_walk.h), 0 = the compiler's (scene option "voxel_walk")
     unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
     int32_t oct_spill_cap;

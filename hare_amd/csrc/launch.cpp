@@ -685,6 +685,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             io.static_rays = (int32_t)std::max<int64_t>(8, std::min<int64_t>(128, (per_wave + 7) / 8 * 8));
             if (s.opt.k1p_static_rays > 0) io.static_rays = std::max(8, std::min(1024, s.opt.k1p_static_rays / 8 * 8));   // developer sweeps (tools/k1q_ticket_sweep.py)
             io.ticket_rays = ticket_rays_for(s, n, true);
+            io.walk_steps = n >= 2 * (int64_t)cus * kPoolWaves * kPoolSlots ? 32 : 16;      // long walk tasks once the batch is two pool fills of the chip (786 432 rays on 256 CUs)
             if (extra && extra->blocks) { io.blocks = extra->blocks; io.blk_words = extra->blk_words; }      // a cast of the bounce loop: live blocks only
             if (s.opt.dev && s.opt.dev_order_ptr && !io.blocks) io.order = (const uint32_t*)(uintptr_t)s.opt.dev_order_ptr;
             // The order in which K1q takes the rays (order_kernels.hip): inside every window of 4 096 consecutive rays, by an estimate of

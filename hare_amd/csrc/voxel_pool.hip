@@ -155,6 +155,12 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     constexpr uint32_t F_NX = 1u << 27, F_NY = 1u << 28, F_NZ = 1u << 29;   // direction component < 0 (Voxel_Grid.cs:589-632)
     constexpr uint32_t F_MOVED = 1u << 30;                                   // origin clipped to OBox: t_start in the scratch
     constexpr uint32_t F_HIT = 1u << 31;                                     // a hit is pending (tmin, point, polygon in the scratch)
+    // Round 6: the pending hit's point lies in the voxel it was FOUND in -- bit 31 of the slot's list end L_qe (list positions stay below 2^31),
+    // set by the exact phase when it accepts a hit, gone with the next voxel's list.  Voxel_Grid.cs:705 asks that question when the voxel's list
+    // has been scanned, of the voxel the ray is still in: the same voxel, the same point, so the answer may be formed at the accept.  A ray whose
+    // list ends with the flag up is FINISHED there and then (its event already holds t, the point and the polygon; u and v are zeroed) instead of
+    // going through the pending-hit walk's own round: 1.38 -> 0.79 pend tasks per ray in the hall, 1.27 -> 0.58 in the cathedral.  Not for rays whose origin was moved (t = tmin + t_start is formed by the pend phase) nor in the BOUNCE build.
+    constexpr uint32_t QE_HERE = 1u << 31;
 
     for (unsigned k = lane; k < S; k += 64) Q_free[k] = (uint8_t)k;
     __syncthreads();      // the bitmap is shared by the workgroup; everything after this point is wave-private
@@ -257,6 +263,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
         const bool near_scene = fabs(ox - g.cellbox_mid[0]) <= g.cellbox_rad && fabs(oy - g.cellbox_mid[1]) <= g.cellbox_rad &&
                                 fabs(oz - g.cellbox_mid[2]) <= g.cellbox_rad && fabs(dx) < 1e300 && fabs(dy) < 1e300 && fabs(dz) < 1e300;
         return near_scene && ((tf < tn) | (tf < 0));
+    };
+    // Voxel_Grid.cs:705 / AABB_Main.cs:75-84: the point inside the padded box of voxel (X, Y, Z), inclusive (six strict-reject compares)
+    auto point_in_voxel = [&](int X, int Y, int Z, double hx, double hy, double hz) -> bool {
+        const double lox = voxel_lo(X, g.vd[0], g.omin[0]), hix = voxel_hi(X, g.vd[0], g.omin[0]);
+        const double loy = voxel_lo(Y, g.vd[1], g.omin[1]), hiy = voxel_hi(Y, g.vd[1], g.omin[1]);
+        const double loz = voxel_lo(Z, g.vd[2], g.omin[2]), hiz = voxel_hi(Z, g.vd[2], g.omin[2]);
+        return !(hx < lox) && !(hy < loy) && !(hz < loz) && !(hx > hix) && !(hy > hiy) && !(hz > hiz);
     };
     // one DDA step, Voxel_Grid.cs:713-759 written with selects (same booleans, same order; see K1p)
 #define HARE_K1Q_STEP()                                                                          \
@@ -675,7 +688,9 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // started with, so that a thin batch -- the end of the launch -- is not cut down to one step per round
             const int n0 = __popcll(__ballot(walking));
             const int walk_min = tail ? 1 : (n0 / 3 < HARE_K1Q_WALK_MIN ? n0 / 3 : HARE_K1Q_WALK_MIN);
-            const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : HARE_K1Q_WALK_STEPS;   // end of the launch: fewer, longer tasks
+            // (steps per task: 16, or -- the host's rule for batches of a pool fill's double and more, ShootIO::walk_steps -- 32: with the hand-written
+            //  step a task's set-up weighs more than its steps; C2 +1.3 %, 4M rays +1.9 %, C4 shard +2.8 %, but -2.7 % at 262k rays)
+            const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : (io.walk_steps > 0 ? io.walk_steps : HARE_K1Q_WALK_STEPS);   // end of the launch: fewer, longer tasks
             K1Q_CLOCK(7)
             if (HARE_K1Q_HAND_WALK && hand_walk) {
                 // the step loop written by hand (voxel_walk.h): the same steps, the per-axis updates under the axis' own EXEC mask
@@ -769,7 +784,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             if (act) {
                 const unsigned ray = L_ray[slot];
                 q = L_q[slot];
-                qe = L_qe[slot];
+                qe = L_qe[slot] & ~QE_HERE;
                 xf = L_xyzf[slot];
                 const int done1 = L_d1[slot];
                 int e1 = -1, e2 = -1;
@@ -825,12 +840,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             bool act;
             const unsigned slot = pop(Q_cull, hC, nC, act);
             K1Q_STAT(2, act)
-            bool to_walk = false, to_cull = false, to_exact = false, to_pend = false;
+            bool to_walk = false, to_cull = false, to_exact = false, to_pend = false, done_here = false;
             int share_idx = -1;
             if (act) {
                 const unsigned ray = L_ray[slot];
                 unsigned q = L_q[slot];
-                const unsigned qe = L_qe[slot];
+                const unsigned qe_word = L_qe[slot];
+                const unsigned qe = qe_word & ~QE_HERE;
                 int idx = L_idx[slot], nexti = L_nexti[slot], done1 = L_d1[slot];
                 const uint32_t xf = L_xyzf[slot];
                 int e1 = -1, e2 = -1;
@@ -959,6 +975,16 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 const bool exhausted = !parked && !culling;
                 to_pend = exhausted && (xf & F_HIT);
                 to_walk = exhausted && !(xf & F_HIT);
+                if (!BOUNCE && to_pend && (qe_word & QE_HERE) && !(xf & F_MOVED)) {
+                    // the list is scanned and the pending hit lies in this voxel (QE_HERE, above): Voxel_Grid.cs:705-709 returns it.  The event
+                    // slot holds t, the point, {Hit, Poly_id} since the accept; u and v are the record's (0, 0)
+                    double* sc = reinterpret_cast<double*>(&io.out[ray]);
+                    sc[1] = 0.0;
+                    sc[2] = 0.0;
+                    nhits++;
+                    to_pend = false;
+                    done_here = true;
+                }
             }
             if (__builtin_expect((io.flags & 0x3000u) == 0x3000u && io.prof != nullptr, 0)) {
                 // developer statistic (tools/share_stat.py; both developer bits, so that the timeline alone stays cheap): how many DIFFERENT polygons do the lanes of one cull batch look at?
@@ -977,6 +1003,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_exact, hE, nE, to_exact, slot);
             push(Q_pend, hP, nP, to_pend, slot);
+            push(Q_free, hF, nF, done_here, slot);
         }
         K1Q_CLOCK(9)
         HARE_K1Q_PHASE_FENCE();
@@ -985,12 +1012,13 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             bool act;
             const unsigned slot = pop(Q_exact, hE, nE, act);
             K1Q_STAT(3, act)
-            bool to_walk = false, to_cull = false, to_pend = false;
+            bool to_walk = false, to_cull = false, to_pend = false, done_here = false;
             if (act) {
                 const unsigned ray = L_ray[slot];
                 const int i = L_idx[slot];
                 unsigned q = L_q[slot];
-                const unsigned qe = L_qe[slot];
+                unsigned qe_word = L_qe[slot];
+                const unsigned qe = qe_word & ~QE_HERE;
                 uint32_t xf = L_xyzf[slot];
                 double* sc = reinterpret_cast<double*>(&io.out[ray]);
                 const unsigned qa = q + 2 < qe ? q + 2 : qe - 1;
@@ -1029,13 +1057,18 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if (!ok && qnv == 4) ok = tri_fast(o, d, c, v3, a, t);     // (P2,P3,P0) / (P0,P3,P2)
                 }
                 if (ok && t > kTMin && t < tmin) {                              // Voxel_Grid.cs:691-693
+                    const double hx = o.x + d.x * t, hy = o.y + d.y * t, hz = o.z + d.z * t;      // X_Point (Polygons.cs:652)
                     sc[0] = t;
-                    sc[3] = o.x + d.x * t;                                      // X_Point (Polygons.cs:652)
-                    sc[4] = o.y + d.y * t;
-                    sc[5] = o.z + d.z * t;
+                    sc[3] = hx;
+                    sc[4] = hy;
+                    sc[5] = hz;
                     sc[6] = __hiloint2double(1, i);
                     xf |= F_HIT;
                     L_xyzf[slot] = xf;
+                    // ... and is that point in the voxel the ray is in (QE_HERE, above)?
+                    const bool here = point_in_voxel((int)(xf & 511u), (int)((xf >> 9) & 511u), (int)((xf >> 18) & 511u), hx, hy, hz);
+                    qe_word = here ? (qe_word | QE_HERE) : (qe_word & ~QE_HERE);
+                    L_qe[slot] = qe_word;
                 }
                 L_d1[slot] = i;
                 // next_candidate()
@@ -1046,10 +1079,18 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                 to_cull = q < qe;
                 to_pend = !to_cull && (xf & F_HIT);
                 to_walk = !to_cull && !to_pend;
+                if (!BOUNCE && to_pend && (qe_word & QE_HERE) && !(xf & F_MOVED)) {     // the list ends with this candidate and the hit lies here: finished (see the cull phase)
+                    sc[1] = 0.0;
+                    sc[2] = 0.0;
+                    nhits++;
+                    to_pend = false;
+                    done_here = true;
+                }
             }
             push(Q_walk, hW, nW, to_walk, slot);
             push(Q_cull, hC, nC, to_cull, slot);
             push(Q_pend, hP, nP, to_pend, slot);
+            push(Q_free, hF, nF, done_here, slot);
         }
         K1Q_CLOCK(9)
         HARE_K1Q_PHASE_FENCE();      // the exact phase's hit record, before the pending-hit walk reads it
