@@ -77,6 +77,10 @@
 #ifndef HARE_K1Q_WIDE_WALK
 #define HARE_K1Q_WIDE_WALK 1      // ... and the walk looks several occupied voxels ahead, one per lane of the ray's group
 #endif
+#ifndef HARE_K1Q_WALK_SEGS
+#define HARE_K1Q_WALK_SEGS 3      // segments of steps per walk task at most: lanes that an occupied voxel sends on (empty list, tight box) walk on in the same task ...
+#define HARE_K1Q_WALK_RESUME_MIN 8   // ... when at least this many of the task's lanes were sent on
+#endif
 #ifndef HARE_K1Q_HAND_WALK
 #define HARE_K1Q_HAND_WALK 1      // the DDA step loop of the walk phases as written by hand (voxel_walk.h); 0: the compiler's (A/B)
 #endif
@@ -691,21 +695,33 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // (steps per task: 16, or -- the host's rule for batches of a pool fill's double and more, ShootIO::walk_steps -- 32: with the hand-written
             //  step a task's set-up weighs more than its steps; C2 +1.3 %, 4M rays +1.9 %, C4 shard +2.8 %, but -2.7 % at 262k rays)
             const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : (io.walk_steps > 0 ? io.walk_steps : HARE_K1Q_WALK_STEPS);   // end of the launch: fewer, longer tasks
+            // A task is up to HARE_K1Q_WALK_SEGS SEGMENTS of steps (round 6).  A lane that stops in an occupied voxel fetches the cell record and tests the
+            // voxel's tight box at the end of its segment; when that sends it on -- the list is empty (a per-block bitmap) or the ray cannot hit anything
+            // of it -- it used to go back to the walk queue for its next ROUND (state to LDS, a push, a pop, the state back: a reflected ray in the
+            // cathedral is sent on from 2.4 of the 5.2 occupied voxels it meets, and made 15 walk tasks at 25 lanes a step).  Now, when enough lanes
+            // of the task are sent on, they walk on in the same task with what is left of its step budget.
+            bool exited = false, to_cull = false;
+            unsigned q = 0, qe = 0;
+            int idx = -1, nexti = -1;
+            int steps_left = walk_steps;
+#pragma unroll 1
+            for (int seg = 0; seg < HARE_K1Q_WALK_SEGS; ++seg) {
             K1Q_CLOCK(7)
             if (HARE_K1Q_HAND_WALK && hand_walk) {
                 // the step loop written by hand (voxel_walk.h): the same steps, the per-axis updates under the axis' own EXEC mask
                 unsigned taken = 0, iters = 0;
                 hare_walk::walk_steps<COARSE, OWN || kK1qStats>(tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, X, Y, Z, dx1, dy1, dz1, walking, (unsigned)ct,
-                                                             (unsigned)walk_steps, (unsigned)walk_min, lds_bitmap, (unsigned)g.occ_shift, (unsigned)g.occ_cd, taken, iters);
+                                                             (unsigned)steps_left, (unsigned)(seg == 0 ? walk_min : 1), lds_bitmap, (unsigned)g.occ_shift, (unsigned)g.occ_cd, taken, iters);
                 if (OWN) own.cells += taken;
+                steps_left -= (int)iters;
 #ifdef HARE_K1Q_STATS
                 kq_n[7] += iters; kq_l[7] += wave_sum_u32(taken);      // executions of the step; voxels walked into (lane 0 holds the sum)
 #endif
             } else {
 #pragma unroll 1
-            for (int k = 0; k < walk_steps; ++k) {
+            for (int k = 0; k < steps_left; ++k) {
                 const unsigned long long wm = __ballot(walking);
-                if (wm == 0 || (k > 0 && __popcll(wm) < walk_min)) break;
+                if (wm == 0 || (k > 0 && __popcll(wm) < (seg == 0 ? walk_min : 1))) break;
 #ifdef HARE_K1Q_STATS
                 kq_n[7]++; kq_l[7] += (unsigned long long)__popcll(wm);
 #endif
@@ -718,24 +734,26 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                     if (OWN && !out) own.cells++;
                 }
             }
+            steps_left = 0;          // (the compiler's loop, A/B: one segment)
             }
             K1Q_CLOCK(1)
-            const bool exited = act && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
-            bool to_cull = act && !walking && !exited;
-            if (exited) store_miss(L_ray[slot]);                            // leaving the grid: miss
-            unsigned q = 0, qe = 0;
-            int idx = -1, nexti = -1;
-            if (to_cull) {
+            const bool out_now = act && !exited && !to_cull && (((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct));
+            const bool stopped = act && !exited && !to_cull && !walking && !out_now;       // in an occupied voxel (block), not yet looked at
+            if (out_now) store_miss(L_ray[slot]);                           // leaving the grid: miss
+            exited = exited || out_now;
+            bool sent_on = false;
+            if (stopped) {
                 const int cell = (X * ct + Y) * ct + Z;
                 const CellRec c = g.cells[cell];
                 q = c.start; qe = c.start + c.count; idx = c.i0; nexti = c.i1;
-                if (COARSE && c.count == 0) { to_cull = false; walking = true; }   // the block is occupied, this voxel is not: walk on
+                bool keep = true;
+                if (COARSE && c.count == 0) keep = false;                       // the block is occupied, this voxel is not: walk on
                 // the voxel's tight box (above): the ray cannot hit anything of this list -- it walks on as if the voxel were empty.  (A wall
                 // next to the ray's path: its polygons lie in the voxels the ray crosses, but their box is a thin slab the ray never
                 // reaches -- two in five of the list entries a reflected ray scans in the cathedral.)  Only here, where a ray without
                 // a hit meets an occupied voxel in the pool's ordinary walk: the same test in the wide walk of the drain and in the
                 // cooperative tail was measured and is worth nothing (C4 shard -2.5 % with it in the tail; k1q_box_variants.log).
-                if (g.cellbox != nullptr && to_cull) {
+                if (g.cellbox != nullptr && keep) {
                     const unsigned ray = L_ray[slot];
                     const RayRec r = io.rays[ray];
                     double ox = r.x, oy = r.y, oz = r.z;
@@ -743,8 +761,14 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
                         const double ts = reinterpret_cast<const double*>(&io.out[ray])[1];
                         ox = ox + r.dx * ts; oy = oy + r.dy * ts; oz = oz + r.dz * ts;
                     }
-                    if (misses_cell_box(cell, ox, oy, oz, r.dx, r.dy, r.dz)) { to_cull = false; walking = true; }
+                    if (misses_cell_box(cell, ox, oy, oz, r.dx, r.dy, r.dz)) keep = false;
                 }
+                to_cull = keep;
+                sent_on = !keep;
+                walking = walking || sent_on;
+            }
+            // walk on in this task?  Only the lanes just sent on and those the budget stopped; not worth it for a few
+            if (seg + 1 >= HARE_K1Q_WALK_SEGS || steps_left < 4 || (int)__popcll(__ballot(sent_on)) < HARE_K1Q_WALK_RESUME_MIN) break;
             }
             if (act && !exited) {
                 L_tmx[slot] = tMaxX; L_tmy[slot] = tMaxY; L_tmz[slot] = tMaxZ;
