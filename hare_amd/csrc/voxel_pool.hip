@@ -43,7 +43,10 @@
 #define HARE_K1Q_WALK_STEPS 16    // DDA steps per walk task at most
 #endif
 #ifndef HARE_K1Q_WALK_MIN
-#define HARE_K1Q_WALK_MIN 20      // a walk task ends early when fewer lanes than this are still walking
+#define HARE_K1Q_WALK_MIN 20      // a walk task ends early when fewer lanes than this are still walking ...
+#endif
+#ifndef HARE_K1Q_WALK_DIV
+#define HARE_K1Q_WALK_DIV 3       // ... or than this fraction of the lanes it started with, whichever is less
 #endif
 #ifndef HARE_K1Q_CULL_PAIRS
 #define HARE_K1Q_CULL_PAIRS 4     // pairs of candidates per cull task (swept 1..8: DESIGN.md section 9)
@@ -691,7 +694,7 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
             // the task ends early once few of its lanes still walk (the others have found their voxel): a third of what it
             // started with, so that a thin batch -- the end of the launch -- is not cut down to one step per round
             const int n0 = __popcll(__ballot(walking));
-            const int walk_min = tail ? 1 : (n0 / 3 < HARE_K1Q_WALK_MIN ? n0 / 3 : HARE_K1Q_WALK_MIN);
+            const int walk_min = tail ? 1 : (n0 / HARE_K1Q_WALK_DIV < HARE_K1Q_WALK_MIN ? n0 / HARE_K1Q_WALK_DIV : HARE_K1Q_WALK_MIN);
             // (steps per task: 16, or -- the host's rule for batches of a pool fill's double and more, ShootIO::walk_steps -- 32: with the hand-written
             //  step a task's set-up weighs more than its steps; C2 +1.3 %, 4M rays +1.9 %, C4 shard +2.8 %, but -2.7 % at 262k rays)
             const int walk_steps = tail ? HARE_K1Q_TAIL_STEPS : (io.walk_steps > 0 ? io.walk_steps : HARE_K1Q_WALK_STEPS);   // end of the launch: fewer, longer tasks
