@@ -652,10 +652,10 @@ def measure(w, env):
                 own_bytes = 104 * oc[0] + cw * oc[2] + 4 * oc[3] + kb * oc[5] + 128 * oc[4] + 28 * links
                 own = {"frac": round(own_bytes / pass_s / 1e9 / HBM_PEAK_GBS, 4), "achieved": round(own_bytes / pass_s / 1e9, 1),
                        "bytes_per_launch": own_bytes // B, "bytes_per_cast": round(own_bytes / max(casts, 1), 1),
-                       # S: DDA steps the kernel EXECUTES per cast.  It equals C' by construction: round 6 made the step cheap (voxel_walk.h: 17 / 20
-                       # vector instructions where the compiler wrote 40), it does not skip voxels -- see DESIGN.md 5 for why the closed-form block
-                       # skip loses to a cheap step on this machine
-                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), **({"S": round(oc[2] / max(casts, 1), 2)} if kind == "voxel" else {}),
+                       # S: walk operations the kernel EXECUTES per cast (counters word 6).  By default it equals C' (up to the drain's wide walk): round 6 made
+                       # the step cheap (voxel_walk.h: 17 / 20 vector instructions where the compiler wrote 40) instead of skipping voxels; with the scene
+                       # option "voxel_skip" -- the exact closed-form skip over empty 4^3 blocks -- S falls below C' and the kernel gets slower
+                       "per_cast": {"C": round(oc[2] / max(casts, 1), 2), **({"S": round((oc[6] or oc[2]) / max(casts, 1), 2)} if kind == "voxel" else {}),
                                     "L": round(oc[3] / max(casts, 1), 2),
                                     "K": round(oc[5] / max(casts, 1), 2), "T": round(oc[4] / max(casts, 1), 2)},
                        "formula": f"104+{cw}C'+4L'+{kb}K'+128T' (+28/bounce), counted by " + part.kernel_name(n, flags=H.capi.SHOOT_COUNT_OWN)}

@@ -42,6 +42,7 @@ class Counters(C.Structure):
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k in ("rays", "hits", "cells", "entries", "tests")}
         d["culls"] = int(self.reserved[0])       # HARE_SHOOT_COUNT_OWN: candidates pre-culled
+        d["steps"] = int(self.reserved[1])       # HARE_SHOOT_COUNT_OWN, Voxel_Grid: walk operations executed (steps, or block jumps under "voxel_skip")
         return d
 
 

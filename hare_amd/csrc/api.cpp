@@ -165,7 +165,7 @@ void hare_scene_destroy(hare_scene* s)
     if (H && (s->module || s->stream)) {
         DeviceGuard dev_guard(H, s->device);   // act on the scene's device, leave the caller's current device as it was
         if (s->stream) (void)H->StreamSynchronize(s->stream);
-        for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ, &s->d_cellbox})
+        for (auto* v : {&s->d_polys, &s->d_cull, &s->d_quads, &s->d_cells, &s->d_items, &s->d_occ, &s->d_cellbox, &s->d_bocc})
             for (void*& p : *v) dev_free(H, p);
         for (void** p : {&s->d_oct_nodes, &s->d_oct_items, &s->d_kd_nodes, &s->d_kd_items, &s->d_work, &s->d_oct_tail})
             dev_free(H, *p);
@@ -894,6 +894,7 @@ const OptionEntry kOptionTable[] = {
         {"wide_drain", &SceneOptions::wide_drain, 0, 1},
         {"bounce_pack", &SceneOptions::bounce_pack, 0, 1},
         {"voxel_walk", &SceneOptions::voxel_walk, 0, 1},
+        {"voxel_skip", &SceneOptions::voxel_skip, 0, 1},
 };
 }  // namespace
 
@@ -962,6 +963,13 @@ int hare_scene_set_option(hare_scene* s, const char* name, int64_t value)
                 if (!H) return HARE_OK;
                 DeviceGuard dev_guard(H, s->device);
                 reserve_order_ring(*s, H);
+                return HARE_OK;
+            }
+            if (t.field == &SceneOptions::voxel_skip && s->vox.built && !s->d_cells.empty() && s->module) {     // the block-level occupancy exists only while the option is on
+                const HipApi* H = hip_api(nullptr);
+                if (!H) return HARE_OK;
+                DeviceGuard dev_guard(H, s->device);
+                upload_block_occ(*s, H);
                 return HARE_OK;
             }
             const bool oct_option = t.field == &SceneOptions::octree_kernel || t.field == &SceneOptions::octree_tail ||

@@ -328,6 +328,17 @@ __global__ __launch_bounds__(256) void hare_ob_fill(BuildArgs b, const OctTask* 
     octree_task<true>(b, tasks, pitems, nullptr, oitems);
 }
 
+// The block-level occupancy of the pool kernel's exact multi-voxel skip (scene option "voxel_skip", voxel_pool.hip): one bit per ALIGNED block of
+// 4 x 4 x 4 voxels, set when any voxel of the block has a list.  nb = ceil(ct / 4) blocks per axis; the words are zeroed by the host first.
+__global__ __launch_bounds__(256) void hare_block_occ(const CellRec* cells, long long ncell, int ct, int nb, uint32_t* bocc)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell || cells[c].count == 0) return;
+    const int z = (int)(c % ct), y = (int)((c / ct) % ct), x = (int)(c / ((long long)ct * ct));
+    const int b = ((x >> 2) * nb + (y >> 2)) * nb + (z >> 2);
+    atomicOr(&bocc[b >> 5], 1u << (b & 31));
+}
+
 // The voxels' TIGHT boxes (device_scene.cpp: upload_cell_boxes; used by K1q, voxel_pool.hip): per voxel the bounding box of ALL polygons its list
 // holds -- whole polygons, not clipped to the voxel: Voxel_Grid.Shoot records a hit wherever it lies on the polygon (Voxel_Grid.cs:691-699)
 // -- grown by `delta` and rounded outwards to floats.  8 floats per voxel: lo xyz, hi xyz, two spare; an empty voxel gets an empty box.

@@ -120,6 +120,7 @@ int get_module(const HipApi* H, int device, const DeviceModule** out)
         {"hare_vb_sort_block", &m->vb_sort_block},
         {"hare_vb_finalize", &m->vb_finalize},
         {"hare_cell_boxes", &m->cell_boxes},
+        {"hare_block_occ", &m->block_occ},
         {"hare_vb_find_big", &m->vb_find_big},
         {"hare_vb_fill_big", &m->vb_fill_big},
         {"hare_ob_count", &m->ob_count},
@@ -416,9 +417,45 @@ void reserve_order_ring(Scene& s, const HipApi* H)
     }
     s.order_cap = cap;
 }
+// The block-level occupancy behind the scene option "voxel_skip" (hare_block_occ, build_kernels.hip): per topology one bit per aligned block of 4^3
+// voxels, from the grid as it stands on the device.  Exists only while the option is on, the pool kernel serves the grid, and the bits fit the
+// LDS the pools leave (they are staged behind them); otherwise the option is simply without effect.  Never an error.
+void upload_block_occ(Scene& s, const HipApi* H)
+{
+    for (void*& p : s.d_bocc) dev_free(H, p);
+    s.d_bocc.assign(s.topos.size(), nullptr);
+    s.bocc_nb = 0;
+    s.bocc_words = 0;
+    if (!s.opt.voxel_skip || !pool_can_serve(s) || !s.module || !s.module->block_occ || !s.vox.built || s.d_cells.size() != s.topos.size()) return;
+    const int nb = (s.vox.ct + 3) / 4;
+    const long long words = ((long long)nb * nb * nb + 31) / 32;
+    const unsigned lds = (unsigned)((s.occ_words + 3) / 4) * 16u + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
+    if (lds + (unsigned long long)((words + 3) / 4) * 16ull + 256ull > 160ull * 1024ull) return;       // (256: the kernel's static LDS)
+    const long long ncell = (long long)s.vox.ct * s.vox.ct * s.vox.ct;
+    for (size_t m = 0; m < s.topos.size(); ++m) {
+        if (!s.d_cells[m]) continue;
+        const size_t bytes = (size_t)((words + 3) / 4) * 16u;
+        if (H->Malloc(&s.d_bocc[m], bytes) != hipSuccess) { (void)H->GetLastError(); s.d_bocc[m] = nullptr; continue; }
+        if (H->Memset(s.d_bocc[m], 0, bytes) != hipSuccess) { (void)H->GetLastError(); dev_free(H, s.d_bocc[m]); continue; }
+        const void* cells = s.d_cells[m];
+        long long nc = ncell;
+        int ct = s.vox.ct, nbb = nb;
+        void* out = s.d_bocc[m];
+        void* args[] = {&cells, &nc, &ct, &nbb, &out};
+        if (launch(H, s.module->block_occ, (unsigned)((ncell + 255) / 256), 256, 0, nullptr, args)) { dev_free(H, s.d_bocc[m]); continue; }
+    }
+    if (H->StreamSynchronize(nullptr) != hipSuccess) {
+        (void)H->GetLastError();
+        for (void*& p : s.d_bocc) dev_free(H, p);
+        return;
+    }
+    s.bocc_nb = nb;
+    s.bocc_words = (int32_t)words;
+}
 int upload_cell_boxes(Scene& s, const HipApi* H)
 {
     reserve_order_ring(s, H);                 // the other reservation every voxel build ends in
+    upload_block_occ(s, H);
     for (void*& p : s.d_cellbox) dev_free(H, p);
     s.d_cellbox.assign(s.topos.size(), nullptr);
     s.cellbox_rad = -1;

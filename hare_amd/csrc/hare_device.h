@@ -38,9 +38,10 @@ enum : uint32_t {
 };
 
 // Device counters (one block per scene, accumulated with atomics; 8 x u64)
-enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_CULLS = 5 /* HARE_SHOOT_COUNT_OWN: candidates pre-culled */, CTR_WORDS = 8 };
+enum { CTR_RAYS = 0, CTR_HITS = 1, CTR_CELLS = 2, CTR_ENTRIES = 3, CTR_TESTS = 4, CTR_CULLS = 5 /* HARE_SHOOT_COUNT_OWN: candidates pre-culled */,
+       CTR_STEPS = 6 /* HARE_SHOOT_COUNT_OWN, Voxel_Grid: walk operations executed (a step or a block jump) */, CTR_WORDS = 8 };
 // what one lane of a counting build (HARE_SHOOT_COUNT_OWN, the *_own kernels) has seen its rays do
-struct OwnWork { unsigned cells = 0, entries = 0, culls = 0, tests = 0; };
+struct OwnWork { unsigned cells = 0, entries = 0, culls = 0, tests = 0, steps = 0; };     // steps: DDA steps / block jumps EXECUTED (= cells unless "voxel_skip")
 
 // The FP32 pre-cull's operands (v0, e1f, e2f) live in a dense array of their own, apart from the 128-byte records the exact test
 // reads.  Cell and leaf lists hold runs of consecutive polygon ids (82 % of neighbouring entries differ by one in the bench scenes,
@@ -89,6 +90,10 @@ struct VoxelArgs {
                                // outwards (build_kernels.hip: hare_cell_boxes).  A ray that misses it cannot hit any of them (K1q, voxel_pool.hip)
     double cellbox_mid[3];     // ... for origins with |o - cellbox_mid|_inf <= cellbox_rad only (the margin is sized for those)
     double cellbox_rad;
+    const uint32_t* bocc;      // nullable (scene option "voxel_skip"): one bit per aligned block of 4^3 voxels that holds an occupied voxel (build_kernels.hip:
+                               // hare_block_occ), staged in LDS behind the pools by the pool kernel; bocc_nb blocks per axis
+    int32_t bocc_nb;
+    int32_t bocc_words;
 };
 
 struct OctNode {               // 64 bytes

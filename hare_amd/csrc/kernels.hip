@@ -139,11 +139,13 @@ __device__ __forceinline__ void flush_own(unsigned long long* ctr, const OwnWork
 {
     if (!ctr) return;
     const unsigned long long c = wave_sum_u32(w.cells), e = wave_sum_u32(w.entries), k = wave_sum_u32(w.culls), t = wave_sum_u32(w.tests);
+    const unsigned long long st = wave_sum_u32(w.steps);
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&ctr[CTR_CELLS], c);
         atomicAdd(&ctr[CTR_ENTRIES], e);
         atomicAdd(&ctr[CTR_TESTS], t);
         atomicAdd(&ctr[CTR_CULLS], k);
+        if (st) atomicAdd(&ctr[CTR_STEPS], st);
     }
 }
 

@@ -169,6 +169,7 @@ void read_env_options(SceneOptions& o)
     if (const char* t = getenv("HARE_OCTREE_TIGHT")) o.octree_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_TIGHT")) o.voxel_tight = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_WALK")) o.voxel_walk = atoi(t) != 0;
+    if (const char* t = getenv("HARE_VOXEL_SKIP")) o.voxel_skip = atoi(t) != 0;
     if (const char* t = getenv("HARE_BOUNCE_PACK")) o.bounce_pack = atoi(t) != 0;
     if (const char* t = getenv("HARE_VOXEL_ORDER")) o.voxel_order = std::max(0, std::min(2, atoi(t)));
     if (const char* t = getenv("HARE_VOXEL_ORDER_MAX_RAYS")) o.voxel_order_max_rays = std::max(0, atoi(t));
@@ -412,6 +413,14 @@ static void fill_voxel_args(const Scene& s, int32_t top, VoxelArgs& g)
     g.occ_words = s.occ_words;
     g.occ_shift = s.occ_shift;
     g.occ_cd = s.occ_cd;
+    g.bocc = nullptr;
+    g.bocc_nb = 0;
+    g.bocc_words = 0;
+    if (s.opt.voxel_skip && (size_t)top < s.d_bocc.size() && s.d_bocc[(size_t)top] && s.bocc_nb > 0) {
+        g.bocc = (const uint32_t*)s.d_bocc[(size_t)top];
+        g.bocc_nb = s.bocc_nb;
+        g.bocc_words = s.bocc_words;
+    }
     if (s.opt.voxel_tight && (size_t)top < s.d_cellbox.size() && s.cellbox_rad > 0) {
         g.cellbox = (const float*)s.d_cellbox[(size_t)top];
         for (int a = 0; a < 3; ++a) g.cellbox_mid[a] = s.cellbox_mid[a];
@@ -676,7 +685,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
         if ((flags & 0x3000u) && d_ctr) io.prof = (unsigned long long*)d_ctr + CTR_WORDS;   // developer timeline (0x2000) / round trace (0x1000)
         if (kc.k == Kern::VoxelPool) {
             // K1q (voxel_pool.hip): more rays than lanes, ray state in LDS, one workgroup per CU
-            const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes;
+            const unsigned plds = lds + (unsigned)kPoolWaves * (unsigned)kPoolWaveBytes + (g.bocc ? (unsigned)((g.bocc_words + 3) / 4) * 16u : 0u);     // + the block bits of "voxel_skip"
             // a workgroup per CU whenever the batch has a ray for every wave; the static first chunk is what the batch has for each wave,
             // in steps of 8, at most 128 (a small batch: few rays per wave, each with several lanes from its second round on)
             unsigned pgrid = std::min<unsigned>(cus, (unsigned)((n + kPoolWaves - 1) / kPoolWaves));

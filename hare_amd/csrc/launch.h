@@ -28,6 +28,7 @@ constexpr unsigned kLdsMax = 160u * 1024u;
 int get_module(const HipApi* H, int device, const DeviceModule** out);
 bool pool_can_serve(const Scene& s);                     // the pool kernel K1q can serve this grid (ct <= 512, bitmap + pools fit LDS)
 int upload_cell_boxes(Scene& s, const HipApi* H);        // the voxels' tight boxes: only where they are used; never an error when they cannot be had
+void upload_block_occ(Scene& s, const HipApi* H);        // option "voxel_skip": the block-level occupancy (device_scene.cpp)
 void reserve_order_ring(Scene& s, const HipApi* H);      // the pool kernel's order ring (scene.h), sized by "voxel_order_max_rays"; called with every voxel build
 void reserve_oct_scratch(Scene& s, const HipApi* H);     // the octree kernels' scratch ring, sized once for the largest launch the tree can get
 int sync_partition_to_device(Scene& s, int kind);        // after a build: records, lists, tight boxes, kd device nodes

@@ -53,6 +53,8 @@ struct SceneOptions {
     int k2p_tail_patience = -1; // ... after this many rounds (-1 = the rule)
     int batch_chunks = 0;      // chunks hare_shoot_batch pipelines a batch over (0 = the host's rule)
     int coop_tail = 1;         // 1: a drained wave traces its last rays with all 64 lanes (voxel_coop.hip); 0: as lanes of the pool to the end (A/B)
+    int voxel_skip = 0;        // 1: K1q's walk crosses an EMPTY aligned block of 4^3 voxels in one operation -- the exact closed-form skip (voxel_pool.hip); bit-identical
+                               // results, and slower than the hand-written step: off by default, kept as a tested option
     int voxel_walk = 1;        // 1: K1q's DDA step loop as written by hand for gfx950 (voxel_walk.h: per-axis updates under EXEC masks); 0: the compiler's loop (A/B)
     int bounce_pack = 1;       // 1: the launch-per-cast bounce loop of a Voxel_Grid lists the blocks of 64 rays in which a ray still lives behind every reflection (one
                                // more one-workgroup launch per cast) and the next cast walks the list: open scenes; 0: off (a closed room saves ~1 %)
@@ -115,6 +117,7 @@ struct DeviceModule {
     hipFunction_t reflect = nullptr, occlusion = nullptr;
     hipFunction_t voxel_occl_tri = nullptr, voxel_occl_quad = nullptr, voxel_occl_tri_g = nullptr, voxel_occl_quad_g = nullptr, octree_occl = nullptr, octree_occl_any = nullptr;
     hipFunction_t events_pack_slim = nullptr;
+    hipFunction_t block_occ = nullptr;                                     // build_kernels.hip: hare_block_occ
     hipFunction_t live_blocks = nullptr;                                   // kernels.hip: hare_live_blocks (the bounce loop's block list)
     hipFunction_t live_count = nullptr, scan_tiles = nullptr, reflect_compact = nullptr, events_fill_miss = nullptr, events_expand = nullptr;
     hipFunction_t cull_audit = nullptr;
@@ -166,6 +169,8 @@ struct Scene {
     std::vector<CullFrame> cull_frames;          // per topo: how those records decode
     std::vector<void*> d_quads;                  // per topo: QuadRec[P] or null (all triangles)
     std::vector<void*> d_cells, d_items, d_occ;  // per topo (voxel)
+    std::vector<void*> d_bocc;                   // per topo: occupancy of the aligned 4^3 blocks of voxels (option "voxel_skip"; device_scene.cpp: upload_block_occ); null = none
+    int32_t bocc_nb = 0, bocc_words = 0;
     std::vector<void*> d_cellbox;                // per topo: the voxels' tight boxes, 8 floats per voxel (device_scene.cpp: upload_cell_boxes); null = none
     double cellbox_mid[3] = {0, 0, 0}, cellbox_rad = -1;   // ray origins they may be used for: |o - mid|_inf <= rad
     int32_t occ_words = 0;                       // words of the occupancy bitmap the persistent kernel stages in LDS

@@ -170,6 +170,14 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
     constexpr uint32_t QE_HERE = 1u << 31;
 
     for (unsigned k = lane; k < S; k += 64) Q_free[k] = (uint8_t)k;
+    // scene option "voxel_skip": the occupancy of the aligned 4^3 blocks of voxels, behind the pools (the host sized the launch's LDS for it)
+    const bool skip_on = !BOUNCE && g.bocc != nullptr;
+    uint32_t* const lbocc = reinterpret_cast<uint32_t*>(lds_raw + ((size_t)nw4 << 4) + (size_t)kPoolWaves * kPoolWaveBytes);
+    if (skip_on) {
+        const uint4* src = reinterpret_cast<const uint4*>(g.bocc);
+        uint4* dst = reinterpret_cast<uint4*>(lbocc);
+        for (int k = threadIdx.x; k < (g.bocc_words + 3) >> 2; k += blockDim.x) dst[k] = src[k];
+    }
     __syncthreads();      // the bitmap is shared by the workgroup; everything after this point is wave-private
 
     const int ct = g.ct;
@@ -710,12 +718,69 @@ __device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootI
 #pragma unroll 1
             for (int seg = 0; seg < HARE_K1Q_WALK_SEGS; ++seg) {
             K1Q_CLOCK(7)
-            if (HARE_K1Q_HAND_WALK && hand_walk) {
+            if (skip_on) {
+                // ---- the EXACT multi-voxel skip (scene option "voxel_skip"; round 4's construction, built in round 6).  The DDA is a merge
+                // of three sequences a_c[j] = tMax_c + j tDelta_c -- each formed by SEQUENTIAL adds, as the reference forms them -- under the order
+                // "smaller value first, the later axis on a tie" (Voxel_Grid.cs:713-757: x steps iff tx < ty && tx < tz; else y iff ty < tz; else z).
+                // A lane whose aligned 4^3 block holds no occupied voxel leaves it in ONE operation: k_c = steps on axis c that leave the block; the
+                // exit element E = the first, in that order, of the three a_c[k_c - 1]; every other axis has taken as many steps as it has elements
+                // in front of E (a < E, or a == E on the later axis); the exit axis all k, and one more add.  The voxels in between lie in the
+                // empty block -- no list, and a ray of the walk queue holds no hit -- so nothing else would have happened there: the lane stands
+                // where the stepping loop would stand, with the same three tMax bit patterns.  Used only when all six values are finite (then
+                // tDelta > 0 and the sequences rise); other lanes step.  A block that reaches past the grid's edge is no exception: a ray
+                // that leaves the grid inside it has left it for good, and ends as the miss it is.
+                // It is exact -- and slower than the hand-written step (38 vector instructions per voxel crossed against 17: DESIGN.md section 5,
+                // profiles/r06_experiments): off by default.
+                const int nb = g.bocc_nb;
+#pragma unroll 1
+                for (int k = 0; k < steps_left; ++k) {
+                    const unsigned long long wm = __ballot(walking);
+                    if (wm == 0 || (k > 0 && __popcll(wm) < (seg == 0 ? walk_min : 1))) break;
+                    if (walking) {
+                        const int bxi = ((X >> 2) * nb + (Y >> 2)) * nb + (Z >> 2);
+                        const bool finite = fabs(tMaxX) < 1e300 && fabs(tMaxY) < 1e300 && fabs(tMaxZ) < 1e300 && fabs(tDeltaX) < 1e300 && fabs(tDeltaY) < 1e300 &&
+                                            fabs(tDeltaZ) < 1e300;
+                        const bool jump = finite && !((lbocc[bxi >> 5] >> (bxi & 31)) & 1u);
+                        unsigned crossed = 1;
+                        if (jump) {
+                            const int kx = dx1 > 0 ? 4 - (X & 3) : (X & 3) + 1, ky = dy1 > 0 ? 4 - (Y & 3) : (Y & 3) + 1, kz = dz1 > 0 ? 4 - (Z & 3) : (Z & 3) + 1;
+                            const double ax1 = tMaxX + tDeltaX, ax2 = ax1 + tDeltaX, ax3 = ax2 + tDeltaX, ax4 = ax3 + tDeltaX;
+                            const double ay1 = tMaxY + tDeltaY, ay2 = ay1 + tDeltaY, ay3 = ay2 + tDeltaY, ay4 = ay3 + tDeltaY;
+                            const double az1 = tMaxZ + tDeltaZ, az2 = az1 + tDeltaZ, az3 = az2 + tDeltaZ, az4 = az3 + tDeltaZ;
+                            auto sel5 = [](int j, double a0, double a1, double a2, double a3, double a4) { return j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : (j == 3 ? a3 : a4))); };
+                            const double Ex = sel5(kx - 1, tMaxX, ax1, ax2, ax3, ax4), Ey = sel5(ky - 1, tMaxY, ay1, ay2, ay3, ay4), Ez = sel5(kz - 1, tMaxZ, az1, az2, az3, az4);
+                            const bool ex = (Ex < Ey) & (Ex < Ez), ey = (!(Ex < Ey)) & (Ey < Ez), ez = !(ex | ey);
+                            const double E = ex ? Ex : (ey ? Ey : Ez);
+                            auto before = [&](bool later, int kk, double a0, double a1, double a2) {
+                                int c = 0;
+                                c += (kk > 1 && (a0 < E || (later && a0 == E))) ? 1 : 0;
+                                c += (kk > 2 && (a1 < E || (later && a1 == E))) ? 1 : 0;
+                                c += (kk > 3 && (a2 < E || (later && a2 == E))) ? 1 : 0;
+                                return c;
+                            };
+                            const int nx = ex ? kx : before(false, kx, tMaxX, ax1, ax2);              // x is never the later axis
+                            const int ny = ey ? ky : before(ex, ky, tMaxY, ay1, ay2);                 // y is later than x only
+                            const int nz = ez ? kz : before(true, kz, tMaxZ, az1, az2);               // z is later than both
+                            X += dx1 * nx; Y += dy1 * ny; Z += dz1 * nz;
+                            tMaxX = sel5(nx, tMaxX, ax1, ax2, ax3, ax4); tMaxY = sel5(ny, tMaxY, ay1, ay2, ay3, ay4); tMaxZ = sel5(nz, tMaxZ, az1, az2, az3, az4);
+                            crossed = (unsigned)(nx + ny + nz);
+                        } else {
+                            HARE_K1Q_STEP();
+                        }
+                        const bool out = ((unsigned)X >= (unsigned)ct) | ((unsigned)Y >= (unsigned)ct) | ((unsigned)Z >= (unsigned)ct);
+                        const int cell = out ? 0 : (X * ct + Y) * ct + Z;
+                        const bool occ = occupied(out ? 0 : X, out ? 0 : Y, out ? 0 : Z, cell);
+                        walking = !out && !occ;
+                        if (OWN) { own.cells += out ? crossed - 1u : crossed; own.steps++; }       // voxels walked into; operations executed
+                    }
+                }
+                steps_left = 0;
+            } else if (HARE_K1Q_HAND_WALK && hand_walk) {
                 // the step loop written by hand (voxel_walk.h): the same steps, the per-axis updates under the axis' own EXEC mask
                 unsigned taken = 0, iters = 0;
                 hare_walk::walk_steps<COARSE, OWN || kK1qStats>(tMaxX, tMaxY, tMaxZ, tDeltaX, tDeltaY, tDeltaZ, X, Y, Z, dx1, dy1, dz1, walking, (unsigned)ct,
                                                              (unsigned)steps_left, (unsigned)(seg == 0 ? walk_min : 1), lds_bitmap, (unsigned)g.occ_shift, (unsigned)g.occ_cd, taken, iters);
-                if (OWN) own.cells += taken;
+                if (OWN) { own.cells += taken; own.steps += taken; }
                 steps_left -= (int)iters;
 #ifdef HARE_K1Q_STATS
                 kq_n[7] += iters; kq_l[7] += wave_sum_u32(taken);      // executions of the step; voxels walked into (lane 0 holds the sum)

@@ -201,6 +201,9 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  *                     ray: its candidates four per lane, the occupied voxels ahead one per lane); 0: off.  Results never depend on it
  *   "voxel_walk"      1 (default): the pool kernel's DDA step loop (Voxel_Grid.cs:713-759) as written by hand for gfx950 -- the per-axis
  *                     updates under the axis' own EXEC mask; 0: the compiler's loop (A/B).  The same steps in the same order: results never depend on it
+ *   "voxel_skip"      1: the pool kernel's walk crosses an EMPTY aligned block of 4 x 4 x 4 voxels in one operation -- the exact closed-form skip (the DDA as a
+ *                     merge of three sequences of sequential adds): the same voxel, the same tMax bit patterns, the same results.  0 (default): it is
+ *                     slower than the hand-written step on this hardware; kept as a tested option
  *   "octree_tight"    1 (default): the octree and kd-tree kernels drop a node whose subtree's polygons the ray cannot hit -- per node the box of
  *                     all polygons its subtree lists, built when the tree goes to the device; 0: every node the reference visits.  Results never
  *                     depend on it (an X_Event is the reference's bit for bit either way)

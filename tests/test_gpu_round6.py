@@ -222,3 +222,67 @@ def test_a_shoot_never_allocates_frees_or_waits():
     assert [oc.get_option(k) for k in ("hip_malloc_calls", "hip_free_calls", "hip_sync_calls")] == before
     torch.cuda.synchronize()
     assert d_out[: (1 << 20) * 56].cpu().numpy().tobytes() == want
+
+
+def test_exact_block_skip_option_changes_nothing_but_the_step_count():
+    """Scene option `voxel_skip`: K1q's walk crosses an EMPTY aligned block of 4^3 voxels in one operation --
+    the closed-form construction (the DDA as a merge of three sequences of sequential adds).  It must land in the same voxel with the same tMax
+    bit patterns, so: the same events with the option on, off and from the oracle -- at D = 64 (a bit per voxel), 128 (per 2^3 block), 200 (per
+    4^3 block) and sizes that are no multiple of four, on awkward rays (origins outside the grid and on voxel faces, zero / denormal / huge / NaN
+    components: lanes that are not finite step), exact diagonals and ties, both exclusions, the bench's burst, and the bounce loop cast by cast.
+    The counting build says what it does: fewer operations executed (word 6) for the same voxels crossed (word 2)."""
+    import torch
+    from hare_amd import capi
+    v, nv, size = soup(n_tri=700, n_quad=300, seed=21)
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rng = np.random.default_rng(2)
+    for D in (7, 33, 64, 66, 128, 200):
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        rays = awkward_rays(size, vd_hint=(size[0] + 0.202) / D, seed=100 + D)
+        ref, rc = o.shoot(rays, nthreads=16)
+        e1 = np.where(rng.random(len(rays)) < 0.5, ref["poly_id"], rng.integers(-1, len(nv), len(rays))).astype(np.int32)
+        e2 = rng.integers(-1, len(nv), len(rays)).astype(np.int32)
+        refx, _ = o.shoot(rays, excl1=e1, excl2=e2, nthreads=16)
+        for skip in (1, 0):
+            g.set_option("voxel_skip", skip)
+            assert g.get_option("voxel_skip") == skip
+            assert_events_equal(g.Shoot_batch(rays)[0], ref, what=f"awkward D={D} voxel_skip={skip}")
+            assert_events_equal(g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], refx, what=f"awkward D={D} excl voxel_skip={skip}")
+    v, nv, size = tie_scene()
+    T, To = H.Topology(v, nv), po.Topology(v, nv)
+    rays = tie_rays(v, nv, size, n=6000)
+    for D in (8, 21, 64, 128):
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        g.set_option("voxel_skip", 1)
+        assert_events_equal(g.Shoot_batch(rays)[0], o.shoot(rays)[0], what=f"ties D={D} voxel_skip=1")
+    for scene, D, n in (("hall", 64, 400_000), ("hall", 128, 200_000), ("hall", 200, 200_000), ("cathedral", 128, 300_000)):
+        m = H.scenes.SCENES[scene]()
+        T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+        g, o = H.Voxel_Grid([T], D), po.VoxelGrid([To], domain=D)
+        rays = H.scenes.burst_rays(n, m.size)
+        ref, rc = o.shoot(rays, nthreads=32)
+        got = {}
+        d_rays = torch.from_numpy(rays).cuda()
+        d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+        for skip in (1, 0):
+            g.set_option("voxel_skip", skip)
+            ev, c = g.Shoot_batch(rays)
+            assert_events_equal(ev, ref, what=f"{scene} D={D} voxel_skip={skip}")
+            assert c["hits"] == rc["hits"]
+            for k in (1, 64, 5000):
+                assert_events_equal(g.Shoot_batch(rays[:k])[0], ref[:k], what=f"{scene} D={D} {k} rays voxel_skip={skip}")
+            d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+            g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(), flags=capi.SHOOT_COUNT_OWN)
+            torch.cuda.synchronize()
+            got[skip] = [int(x) for x in d_ctr.cpu()]
+        # the same voxels crossed (to within the drain's re-walks), in fewer operations
+        assert abs(got[1][2] - got[0][2]) <= 0.02 * got[0][2], (scene, D, got)
+        assert got[1][6] < 0.8 * got[1][2] and got[0][6] >= 0.95 * got[0][2], (scene, D, got)
+        if scene == "hall" and D == 64:
+            refb, rcb = oracle_bounce_loop(po, To, o, rays[:100_000], 5)
+            for skip in (1, 0):
+                g.set_option("voxel_skip", skip)
+                evb, _, pcs = g.Bounce_batch(rays[:100_000], 5, per_cast=True, all_casts=True)
+                for b in range(5):
+                    assert_events_equal(evb[b], refb[b], what=f"bounce cast {b} voxel_skip={skip}")
+        g.set_option("voxel_skip", 0)

@@ -61,7 +61,14 @@ def main():
             g.set_option("wide_drain", 0)
             bad = same(g.Shoot_batch(rays)[0], ref); checks += 1
             if bad: print("MISMATCH seed %d voxel D=%d n=%d hand-written loop, wide_drain 0" % (seed, D, n), bad); return 1
-        g.set_option("wide_drain", 1); g.set_option("voxel_kernel", 0)
+        g.set_option("wide_drain", 1)
+        if seed % 2 == 0:       # ... and the exact multi-voxel skip (scene option voxel_skip: empty 4^3 blocks crossed in one operation)
+            g.set_option("voxel_skip", 1)
+            for what, got, want in (("plain", g.Shoot_batch(rays)[0], ref), ("excl", g.Shoot_batch(rays, poly_origin1=e1, poly_origin2=e2)[0], refx)):
+                bad = same(got, want); checks += 1
+                if bad: print("MISMATCH seed %d voxel D=%d n=%d voxel_skip %s" % (seed, D, n, what), bad); return 1
+            g.set_option("voxel_skip", 0)
+        g.set_option("voxel_kernel", 0)
         if seed % 5 == 2:
             # round 6: hare_bounce_batch, last cast's events only: the launch-per-cast loop with the live-block list (bounce_pack 1: from
             # 4 096 rays) and without, against the oracle's loop -- open soups: rays leave, whole blocks of 64 die
