@@ -253,6 +253,11 @@ static_assert(sizeof(KdDevNode) == 128, "kd device node: one cache line");
                                    // polygons and the walk behind a survivor is mostly pruned by its hit: testing it at once beats walking on without
                                    // (profiles/r05_experiments/k3d_variants*.log)
 #endif
+#ifndef HARE_K3D_AHEAD
+#define HARE_K3D_AHEAD 0            // the dense windows as a pipeline, as K2d's (HARE_K2D_AHEAD): no gain here (four waves per SIMD hide the
+                                   // gathers: hall 683 / 678, shoebox 1 334 / 1 340 Mrays/s without / with; at three waves per SIMD -8 % either way;
+                                   // profiles/r06_experiments/k3d_windows_pipelined_not_kept.log)
+#endif
 #ifndef HARE_K3D_WAVES_PER_EU
 #define HARE_K3D_WAVES_PER_EU 4
 #endif
@@ -344,6 +349,10 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 #endif
 #ifndef HARE_K2D_POP_MIN
 #define HARE_K2D_POP_MIN 1         // lanes that make a second, third ... pop step of a round worth its instructions
+#endif
+#ifndef HARE_K2D_AHEAD
+#define HARE_K2D_AHEAD 1           // the dense passes as a pipeline: list entries two windows ahead, pre-cull records one (round 6; with three
+                                   // waves per SIMD: hall 1M rays 773 -> 808 Mrays/s, 4M 1 024 -> 1 058, cathedral 550 -> 601)
 #endif
 constexpr unsigned kOctDenseExtra = 256u * 12u * (unsigned)HARE_K2D_PEND + 4u * 64u * 4u;
 

@@ -290,8 +290,8 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
             const int total = __builtin_amdgcn_readlane(inc, 63);
             const int q0 = q;
             bool stop = false;
-#pragma unroll 1
-            for (int base = 0; base < total; base += 64) {
+            // the owner of item (base + lane) and the item's list position (as K2d, kernels.hip: lanes past the end read entry 0)
+            auto window = [&](int base, int& ow) -> int {
                 seg_mark[lane] = -1;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -300,8 +300,41 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                 __builtin_amdgcn_wave_barrier();
                 const int owner = wave_scan_max(seg_mark[lane]);
                 const bool valid = base + lane < total;
-                const int ow = valid ? owner : lane;
+                ow = valid ? owner : lane;
                 const int rel_o = __shfl(q0 - off, ow, 64);
+                return valid ? rel_o + base + lane : 0;
+            };
+#if HARE_K3D_AHEAD
+            // the windows as a pipeline (round 6, as K2d): list entries two windows ahead, pre-cull records one
+            int ow1 = lane, ow2 = lane, i1 = 0, i2 = 0;
+            CullRaw rec1;
+            if (total > 0) {
+                const int p0 = window(0, ow1);
+                const int p1 = total > 64 ? window(64, ow2) : 0;
+                i1 = g.items[p0];
+                i2 = g.items[p1];
+                rec1 = cull_load(g, i1);
+            }
+#endif
+#pragma unroll 1
+            for (int base = 0; base < total; base += 64) {
+                const bool valid = base + lane < total;
+#if HARE_K3D_AHEAD
+                const int ow = ow1, i_now = i1;
+                const CullRaw rec = rec1;
+                ow1 = ow2; i1 = i2;
+                rec1 = cull_load(g, i1);
+                {
+                    int own_ = lane;
+                    const int p2 = base + 128 < total ? window(base + 128, own_) : 0;
+                    ow2 = own_;
+                    i2 = g.items[p2];
+                }
+#else
+                int ow;
+                const int i_now = g.items[window(base, ow)];
+                const CullRaw rec = cull_load(g, i_now);
+#endif
                 CullRay cr;
                 cr.ox = __shfl(cray.ox, ow, 64); cr.oy = __shfl(cray.oy, ow, 64); cr.oz = __shfl(cray.oz, ow, 64);
                 cr.dfx = __shfl(cray.dfx, ow, 64); cr.dfy = __shfl(cray.dfy, ow, 64); cr.dfz = __shfl(cray.dfz, ow, 64);
@@ -309,13 +342,9 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                 cr.err = __builtin_fmaf(2.3841858e-07f /* 2^-22 */, fabsf(cr.ox) + fabsf(cr.oy) + fabsf(cr.oz), g.cf.err0);   // as cull_ray
 #endif
                 cr.dm = fabsf(cr.dfx) + fabsf(cr.dfy) + fabsf(cr.dfz);
-                int i = -1;
-                bool surv = false;
-                if (valid) {
-                    i = g.items[rel_o + base + lane];
-                    surv = !cull_test(g, cr, cull_load(g, i));
-                    if (OWN) { ownw.entries++; ownw.culls++; }
-                }
+                const int i = valid ? i_now : -1;
+                const bool surv = valid && !cull_test(g, cr, rec);
+                if (OWN && valid) { ownw.entries++; ownw.culls++; }
                 const unsigned long long sb = __ballot(surv);
                 const int lo = off > base ? off - base : 0;
                 const int hi = off + cnt - base < 64 ? off + cnt - base : 64;

@@ -953,6 +953,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     bool cur_skip = false;              // DENSE, replay: the reference skipped the leaf of the survivors being replayed (:210)
     bool leaving = false;               // DENSE: the wave hands its rays over after one more exact phase
 #ifdef HARE_K2P_STATS                   // developer build (tools/k2p_stats.py): what a round of the loop is made of; lane 0 counts
+    unsigned long long dr_t[4] = {0, 0, 0, 0}, dr_last = 0;   // ticks (100 MHz) in the pop steps / dense windows / exact phase / rest of a round, rounds with <= 8 rays after dry
+    bool dr_few = false;
+    unsigned dr_round = 0, dr_p = 0, dr_c = 0, dr_e = 0;   // the same per wave, after its tickets ran dry (timeline slot 3)
     unsigned long long sp_round = 0, sp_alive = 0, sp_p = 0, sp_pl = 0, sp_c = 0, sp_cl = 0, sp_e = 0, sp_el = 0, sp_visit = 0;
     unsigned long long sp_is = 0, sp_il = 0, sp_ls = 0, sp_ll = 0, sp_xl = 0, sp_fl = 0;   // steps with an interior visit / their lanes; leaf visits; exhausted frames; failed pops
     int st_kind = 0;                    // what this lane's last pop step did: 1 frame exhausted, 2 popped and dropped, 3 leaf, 4 interior
@@ -1201,7 +1204,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             }
         }
 
-        K2P_STAT(sp_round++; sp_alive += __popcll(__ballot(alive));)
+        K2P_STAT(sp_round++; sp_alive += __popcll(__ballot(alive)); if (drained) dr_round++;)
+        K2P_STAT({ const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (dr_few) dr_t[3] += now - dr_last; dr_last = now;
+                   dr_few = drained && __popcll(__ballot(alive)) <= 8; })
         // ------------------------------------------------------------------ phase P: one child per step
         // (DENSE) once the tickets are dry the chip empties and a wave's time is the chain of dependent loads of its last rays, a node
         // record per pop: more pop steps per round then (HARE_K2D_STEPS_DRAIN), which the steady state cannot afford
@@ -1215,7 +1220,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 const unsigned long long pm = __ballot(pop);
                 if (pm == 0 || (DENSE && k > 0 && __popcll(pm) < HARE_K2D_POP_MIN)) break;     // a further step only when enough lanes take it
             }
-            K2P_STAT(sp_p++; sp_pl += __popcll(__ballot(pop));)
+            K2P_STAT(sp_p++; sp_pl += __popcll(__ballot(pop)); if (drained) dr_p++;)
             // Rays whose components are all finite and far from overflow never produce a NaN here (1/d is finite and non-zero,
             // boxes are finite), so for them Math.Max / Math.Min are the hardware's v_max_f64 / v_min_f64 (the sign of a zero
             // result is only ever compared); anything else takes the NaN-propagating compare-selects.
@@ -1293,6 +1298,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                        sp_ls += nl ? 1 : 0; sp_ll += nl; sp_xl += __popcll(__ballot(st_kind == 1)); sp_fl += __popcll(__ballot(st_kind == 2)); })
         }
 
+        K2P_STAT({ const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (dr_few) dr_t[0] += now - dr_last; dr_last = now; })
         if (DENSE) {
         // ------------------------------------------------------------------ DENSE B1: every leaf entry in hand, one per lane
         {
@@ -1303,11 +1309,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
             const int total = __builtin_amdgcn_readlane(inc, 63);
             const int q0 = q;                                                // where this lane's segment starts in its list
             bool stop = false;                                               // owner: its list is full, the rest of its segment waits
-#pragma unroll 1
-            for (int base = 0; base < total; base += 64) {
-                K2P_STAT(sp_c++; sp_cl += (total - base < 64 ? total - base : 64);)
-                // which owner does item (base + lane) belong to?  Owners mark the start of their segment inside this window (or position
-                // 0 when the segment began before it); an inclusive max-scan spreads the owner's lane number over its items
+            // which owner does item (base + lane) belong to?  Owners mark the start of their segment inside this window (or position
+            // 0 when the segment began before it); an inclusive max-scan spreads the owner's lane number over its items.  Returns the
+            // item's list position (a lane past the end: position 0 -- total > 0, so the list has an entry to load)
+            auto window = [&](int base, int& ow) -> int {
                 seg_mark[lane] = -1;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1316,10 +1321,49 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 __builtin_amdgcn_wave_barrier();
                 const int owner = wave_scan_max(seg_mark[lane]);
                 const bool valid = base + lane < total;
-                const int ow = valid ? owner : lane;
-                // the owner's list position and pre-cull operands: seven shuffles (what can be rebuilt from them is rebuilt: cull_ray's
-                // |d|_1 and error bound; the owner's exclusions are applied by the owner, below)
+                ow = valid ? owner : lane;
                 const int rel_o = __shfl(q0 - off, ow, 64);                   // list index of item x = rel_o + x
+                return valid ? rel_o + base + lane : 0;
+            };
+#if HARE_K2D_AHEAD
+            // Round 6: the windows as a pipeline.  A window is two dependent gathers -- the list entry, then that polygon's pre-cull
+            // record -- and a caller-sized batch leaves a wave nothing to hide them behind (profiles/r06_experiments: a round is ~9
+            // dependent round trips, 5.7 of them these).  What a window reads depends on nothing the windows before it decide (counts
+            // and offsets are fixed at the top), so the entries are requested two windows ahead and the records one: a window's
+            // loads fly during the window before it.  Loads are unconditional (lanes past the end read entry 0) so that no branch
+            // sits between an issue and its use.
+            int ow1 = lane, ow2 = lane, i1 = 0, i2 = 0;
+            CullRaw rec1;
+            if (total > 0) {
+                const int p0 = window(0, ow1);
+                const int p1 = total > 64 ? window(64, ow2) : 0;
+                i1 = g.items[p0];
+                i2 = g.items[p1];
+                rec1 = cull_load(g, i1);
+            }
+#endif
+#pragma unroll 1
+            for (int base = 0; base < total; base += 64) {
+                K2P_STAT(sp_c++; sp_cl += (total - base < 64 ? total - base : 64); if (drained) dr_c++;)
+                const bool valid = base + lane < total;
+#if HARE_K2D_AHEAD
+                const int ow = ow1, i_now = i1;
+                const CullRaw rec = rec1;
+                ow1 = ow2; i1 = i2;
+                rec1 = cull_load(g, i1);                                      // the next window's records (entry 0 again when there is none)
+                {
+                    int own_ = lane;
+                    const int p2 = base + 128 < total ? window(base + 128, own_) : 0;
+                    ow2 = own_;
+                    i2 = g.items[p2];
+                }
+#else
+                int ow;
+                const int i_now = g.items[window(base, ow)];
+                const CullRaw rec = cull_load(g, i_now);
+#endif
+                // the owner's pre-cull operands: six shuffles (what can be rebuilt from them is rebuilt: cull_ray's |d|_1 and error
+                // bound; the owner's exclusions are applied by the owner, below)
                 CullRay cr;
                 cr.ox = __shfl(cray.ox, ow, 64); cr.oy = __shfl(cray.oy, ow, 64); cr.oz = __shfl(cray.oz, ow, 64);
                 cr.dfx = __shfl(cray.dfx, ow, 64); cr.dfy = __shfl(cray.dfy, ow, 64); cr.dfz = __shfl(cray.dfz, ow, 64);
@@ -1327,13 +1371,9 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 cr.err = __builtin_fmaf(2.3841858e-07f /* 2^-22 */, fabsf(cr.ox) + fabsf(cr.oy) + fabsf(cr.oz), g.cf.err0);   // as cull_ray
 #endif
                 cr.dm = fabsf(cr.dfx) + fabsf(cr.dfy) + fabsf(cr.dfz);
-                int i = -1;
-                bool surv = false;
-                if (valid) {
-                    i = g.items[rel_o + base + lane];
-                    surv = !cull_test(g, cr, cull_load(g, i));
-                    if (OWN) { ownw.entries++; ownw.culls++; }
-                }
+                const int i = valid ? i_now : -1;
+                const bool surv = valid && !cull_test(g, cr, rec);
+                if (OWN && valid) { ownw.entries++; ownw.culls++; }
                 const unsigned long long sb = __ballot(surv);
                 // owner side: the survivors of its segment, in list order, as far as its pending list has room
                 const int lo = off > base ? off - base : 0;
@@ -1367,13 +1407,14 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 if (mine) q += consumed;
             }
         }
+        K2P_STAT({ const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (dr_few) dr_t[1] += now - dr_last; dr_last = now; })
         // ------------------------------------------------------------------ DENSE B2: the noted survivors, each lane its own, in order
         {
             const bool over = alive && lvl < 0 && q == qe;                   // nothing left to visit
             const unsigned long long holding = __ballot(alive && np > 0);
             const unsigned long long blocked = __ballot(alive && np > 0 && (np >= P || over));
             if (holding != 0 && (blocked != 0 || leaving || __popcll(holding) >= HARE_K2D_EXACT_MIN)) {
-                K2P_STAT(sp_e++; sp_el += __popcll(holding);)
+                K2P_STAT(sp_e++; sp_el += __popcll(holding); if (drained) dr_e++;)
                 bool ended = false;
 #pragma unroll 1
                 for (int k = 0; k < P; ++k) {
@@ -1403,6 +1444,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                 }
             }
             if (alive && lvl < 0 && q == qe && np == 0) finish();             // the walk is over and nothing is pending
+            K2P_STAT({ const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (dr_few) dr_t[2] += now - dr_last; dr_last = now; })
             if (leaving && __ballot(alive && np > 0) == 0) break;             // the hand-over records can be written now
         }
         } else {
@@ -1515,6 +1557,11 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
     }
     timeline(2);
 #ifdef HARE_K2P_STATS
+    if ((io.flags & 0x2000u) != 0 && io.prof != nullptr && lane == 0)       // rounds | pop steps | dense windows | exact phases after the tickets ran dry
+        io.prof[32 + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6)) + 3] = (unsigned long long)(dr_round & 0xFFFFu) | ((unsigned long long)(dr_p & 0xFFFFu) << 16) |
+                                                                            ((unsigned long long)(dr_c & 0xFFFFu) << 32) | ((unsigned long long)(dr_e & 0xFFFFu) << 48);
+    if ((io.flags & 0x2000u) != 0 && io.prof != nullptr && lane == 0)
+        for (int k = 0; k < 4; ++k) io.prof[32 + 4ull * 4096ull + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6)) + k] = dr_t[k];
     if (lane == 0 && io.prof) {
         const unsigned long long v[14] = {sp_round, sp_alive, sp_p, sp_pl, sp_c, sp_cl, sp_e, sp_el, sp_is, sp_il, sp_ls, sp_ll, sp_xl, sp_fl};
         for (int k = 0; k < 14; ++k) atomicAdd(&io.prof[k], v[k]);
@@ -1661,6 +1708,9 @@ __global__ __launch_bounds__(256) void hare_octree_shoot(OctreeArgs g, ShootIO i
 __global__ __launch_bounds__(256) void hare_octree_shoot_count(OctreeArgs g, ShootIO io) { octree_shoot_body<true>(g, io); }
 
 // K2p: persistent Octree.Shoot (default octree kernel); dynamic LDS = levels * blockDim * 24 bytes
+#ifndef HARE_K2D_WAVES_PER_EU
+#define HARE_K2D_WAVES_PER_EU 3
+#endif
 #ifndef HARE_K2P_WAVES_PER_EU
 #define HARE_K2P_WAVES_PER_EU 4
 #endif
@@ -1670,15 +1720,17 @@ __global__ __launch_bounds__(256) void hare_octree_tail(OctreeArgs g, ShootIO io
 // the occlusion predicate on the same walk (flags only, any-hit early out); same launch geometry
 // (round 5: K2d's OCC build -- the dense walk with the any-hit early out; K2p's, which this was until then, had fallen behind the closest-hit
 //  kernel it was meant to beat: 457 against 784 Mrays/s at t_max = half the mean free path)
-__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true, true>(g, io); }
+__global__ __launch_bounds__(256, HARE_K2D_WAVES_PER_EU) void hare_octree_occl(OctreeArgs g, ShootIO io) { octree_persist_body<true, true>(g, io); }
 // ... and K2p's stays for queries WITHOUT a t_max (any hit at all decides): there the first accepted test ends the ray, and testing a leaf's
 // entries at once beats deferring them -- 2356 against the dense build's 1627 Mrays/s
 __global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_occl_any(OctreeArgs g, ShootIO io) { octree_persist_body<true>(g, io); }
 // K2d: K2p with its leaf entries spread densely over the wave and its exact tests deferred (octree_persist_body<.., DENSE>);
-// dynamic LDS = K2p's frames + kOctDenseExtra bytes per workgroup
-__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense(OctreeArgs g, ShootIO io) { octree_persist_body<false, true>(g, io); }
+// dynamic LDS = K2p's frames + kOctDenseExtra bytes per workgroup.  Three waves per SIMD (round 6): from seven levels on the frames admit no
+// more than three workgroups per CU anyway, and with 168 registers the kernel spills nothing (at 128: 16 VGPRs, reloaded inside the pop loop;
+// 1M rays +2 %, profiles/r06_experiments/k2d_windows_pipelined.log)
+__global__ __launch_bounds__(256, HARE_K2D_WAVES_PER_EU) void hare_octree_dense(OctreeArgs g, ShootIO io) { octree_persist_body<false, true>(g, io); }
 // ... and its counting build (HARE_SHOOT_COUNT_OWN)
-__global__ __launch_bounds__(256, HARE_K2P_WAVES_PER_EU) void hare_octree_dense_own(OctreeArgs g, ShootIO io) { octree_persist_body<false, true, true>(g, io); }
+__global__ __launch_bounds__(256, HARE_K2D_WAVES_PER_EU) void hare_octree_dense_own(OctreeArgs g, ShootIO io) { octree_persist_body<false, true, true>(g, io); }
 
 // KDTree.Shoot (KDTree.cs:204-361); dynamic LDS = (depth + 2) * blockDim * 4 bytes
 __global__ __launch_bounds__(256) void hare_kdtree_shoot(KdArgs g, ShootIO io) { kdtree_shoot_body<false>(g, io); }

@@ -864,7 +864,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // 20 bytes x levels x 256 lanes per workgroup (interval + child word); the dense build: + its pending survivors and tables
             const bool dense_k = f != nullptr && (f == M.octree_dense || f == M.octree_dense_own || f == M.octree_occl);   // (the flags-only kernel is K2d's OCC build)
             const unsigned plds = (unsigned)g.max_depth * 256u * 20u + (dense_k ? kOctDenseExtra : 0u);
-            unsigned per_cu = std::min((unsigned)HARE_K2P_WAVES_PER_EU, std::max(1u, (unsigned)(kLdsMax / plds)));
+            unsigned per_cu = std::min((unsigned)(dense_k ? HARE_K2D_WAVES_PER_EU : HARE_K2P_WAVES_PER_EU), std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = cus * per_cu;
             pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);
             if (pgrid == 0) pgrid = 1;

@@ -23,6 +23,9 @@ constexpr unsigned kLdsMax = 160u * 1024u;
 #ifndef HARE_K2P_WAVES_PER_EU
 #define HARE_K2P_WAVES_PER_EU 4
 #endif
+#ifndef HARE_K2D_WAVES_PER_EU
+#define HARE_K2D_WAVES_PER_EU 3      // K2d and the flags-only build of it (kernels.hip): 168 registers, nothing spilled
+#endif
 
 // ---- device_scene.cpp
 int get_module(const HipApi* H, int device, const DeviceModule** out);
