@@ -350,6 +350,9 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 #ifndef HARE_K2D_POP_MIN
 #define HARE_K2D_POP_MIN 1         // lanes that make a second, third ... pop step of a round worth its instructions
 #endif
+#ifndef HARE_PIN_ARGS
+#define HARE_PIN_ARGS 1
+#endif
 #ifndef HARE_K2D_AHEAD
 #define HARE_K2D_AHEAD 1           // the dense passes as a pipeline: list entries two windows ahead, pre-cull records one (round 6; with three
                                    // waves per SIMD: hall 1M rays 773 -> 808 Mrays/s, 4M 1 024 -> 1 058, cathedral 550 -> 601)
@@ -466,5 +469,39 @@ struct ShootIO {
     unsigned char* oct_spill;  // K2g: stack entries beyond kGroupStack, oct_spill_cap x 24 bytes per group of eight lanes (null: the stack fits LDS)
     int32_t oct_spill_cap;
 };
+
+#if defined(__HIPCC__)
+// Every kernel argument as a scalar of its OWN (round 6).  The compiler fetches the 720-byte argument block in tuples of 8 and 16 SGPRs and,
+// short of SGPRs in these kernels, spills and reloads them AS tuples: a block that needs the rays' pointer reloaded sixteen registers to get
+// two (v_readlane each: a tenth of K1q's instructions were such reloads).  One s_mov per field at the top of the kernel cuts each loose from its
+// tuple; what is reloaded then is what is used.  K1q: 1 242 -> 357 v_readlane in the code, C2 2 903 -> 2 949 Mrays/s, C5 shard 836 -> 848, 262 144 rays
+// +3.5 % (profiles/r06_experiments/pin_args.log).  The tree kernels (K2d, K2g, K3d) and K1p were measured with it and gain nothing: not used there.
+#if HARE_PIN_ARGS
+template <class T> __device__ __forceinline__ void pin_s(T& x)          // a real move: a copy of a sub-register would be coalesced back into its tuple
+{
+    T y;
+    if constexpr (sizeof(T) == 4) asm volatile("s_mov_b32 %0, %1" : "=s"(y) : "s"(x));
+    else asm volatile("s_mov_b64 %0, %1" : "=s"(y) : "s"(x));
+    x = y;
+}
+#else
+template <class T> __device__ __forceinline__ void pin_s(T&) {}
+#endif
+__device__ __forceinline__ void pin_args(VoxelArgs& g)
+{
+    pin_s(g.polys); pin_s(g.quads); pin_s(g.cells); pin_s(g.items); pin_s(g.occ); pin_s(g.ct); pin_s(g.occ_words); pin_s(g.occ_shift); pin_s(g.occ_cd);
+    for (int k = 0; k < 3; ++k) { pin_s(g.omin[k]); pin_s(g.omax[k]); pin_s(g.vd[k]); pin_s(g.cf.org[k]); pin_s(g.cf.step[k]); pin_s(g.cellbox_mid[k]); }
+    pin_s(g.cull); pin_s(g.cf.err0); pin_s(g.cf.stride); pin_s(g.cellbox); pin_s(g.cellbox_rad); pin_s(g.bocc); pin_s(g.bocc_nb); pin_s(g.bocc_words);
+}
+__device__ __forceinline__ void pin_args(ShootIO& io)
+{
+    pin_s(io.rays); pin_s(io.excl1); pin_s(io.excl2); pin_s(io.out); pin_s(io.ctr); pin_s(io.work); pin_s(io.prof); pin_s(io.n); pin_s(io.flags);
+    pin_s(io.steps_per_round); pin_s(io.refill_min_idle); pin_s(io.ray_chunk); pin_s(io.exact_min_parked); pin_s(io.audit_polys);
+    pin_s(io.ticket_rays); pin_s(io.static_rays); pin_s(io.tmax); pin_s(io.occluded); pin_s(io.coop_tail); pin_s(io.wide_drain);
+    pin_s(io.oct_tail); pin_s(io.oct_tail_stride); pin_s(io.oct_tail_levels); pin_s(io.oct_tail_max); pin_s(io.oct_tail_patience);
+    pin_s(io.bounce_casts); pin_s(io.out_all); pin_s(io.out_stride); pin_s(io.ctr_casts); pin_s(io.order); pin_s(io.blocks); pin_s(io.blk_words);
+    pin_s(io.walk_steps); pin_s(io.hand_walk); pin_s(io.oct_spill); pin_s(io.oct_spill_cap);
+}
+#endif
 
 }  // namespace hare

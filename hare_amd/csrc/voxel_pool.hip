@@ -113,8 +113,12 @@ constexpr bool kK1qStats = false;
 // list entries it scanned, candidates it pre-culled, exact tests it made -- into words 2 .. 5 of the counters block: the numerator of
 // bench.py's `roofline.own` (the reference-priced figure counts voxels, entries and tests this kernel skips).  Events are identical.
 template <bool QUADS, bool COARSE, bool BOUNCE = false, bool OWN = false>
-__device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g, const ShootIO& io)
+__device__ __forceinline__ void voxel_pool_body(const VoxelArgs& g_in, const ShootIO& io_in)
 {
+    VoxelArgs g = g_in;
+    ShootIO io = io_in;
+    pin_args(g);                     // hare_device.h: every argument a scalar of its own
+    pin_args(io);
     OwnWork own;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr unsigned S = kPoolSlots, R = kPoolRing, SM = kPoolRing - 1;   // slots; queue (ring) capacity and its mask
