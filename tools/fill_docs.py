@@ -49,4 +49,24 @@ def fill(path, name, text):
 fill(os.path.join(R, "DESIGN.md"), "results", design_tbl)
 fill(os.path.join(R, "README.md"), "results", readme_tbl)
 fill(os.path.join(R, "profiles", "README.md"), f"{ROUND}_kernel_ms", prof_tbl)
+# ---- DESIGN.md section 5's counters table of the round, from profiles/traffic.json (written by tools/condense_profiles.py)
+def counters_table():
+    t = json.load(open(os.path.join(R, "profiles", "traffic.json")))
+    cols = [("C2: K1q, 1M", "hall-voxel-D64-n1048576"), ("K1q, 4M", "hall-voxel-D64-n4194304"), ("C3: K2d, 1M", "hall-octree-n1048576"), ("K2d, 262k rays", "hall-octree-n262144"),
+            ("C4 shard: K1q `_g`", "cathedral-voxel-D128-n2097152"), ("C5: K1q `_g`, per cast", "cathedral-voxel-D128-n1048576-b8"), ("C4, 16.7M rays", "cathedral-voxel-D128-n16777216"),
+            ("C5, 8.4M rays, per cast", "cathedral-voxel-D128-n8388608-b8")]
+    cols = [(c, k) for c, k in cols if k in t]
+    rows = [("VALU lane utilisation", "valu_lane_util", lambda v: f"{v:.2f}"), ("wave-VALU instructions", "SQ_INSTS_VALU", lambda v: f"{v:.2e}".replace("e+0", "e")),
+            ("a wave is issuing / sits at a `s_waitcnt`", None, None), ("TA busy", "ta_busy_frac", lambda v: f"{100 * v:.0f} %"),
+            ("L1 line accesses per ray", "l1_accesses_per_ray", lambda v: f"{v:.0f}"), ("HBM-side bytes per launch", "hbm_bytes_per_launch", lambda v: f"{v / 1e9:.2f} GB")]
+    out = ["| | " + " | ".join(c for c, _ in cols) + " |", "|" + "---|" * (len(cols) + 1)]
+    for name, key, fmt in rows:
+        if key is None:
+            out.append("| " + name + " | " + " | ".join(f"{100 * t[k]['sq_active_inst_any_frac']:.0f} % / {100 * t[k]['sq_wait_any_frac']:.0f} %" for _, k in cols) + " |")
+        else:
+            out.append("| " + name + " | " + " | ".join(fmt(t[k][key]) if t[k].get(key) is not None else "" for _, k in cols) + " |")
+    return "\n".join(out)
+
+
+fill(os.path.join(R, "DESIGN.md"), f"{ROUND}_counters", counters_table())
 print("filled DESIGN.md, README.md, profiles/README.md from profiles/%s_*" % ROUND)
