@@ -51,6 +51,8 @@ for cfg in sys.argv[1:] or ["default"]:      # optional arguments: HARE_TICKET v
     tier = (np.arange(W) // 4) // 256
     for k in range(4):
         m = live & (tier == k)
+        if not m.any():
+            continue
         print("  tier %d: start %.0f..%.0f  last-refill p10/50/90 %.0f/%.0f/%.0f  end p10/50/90/max %.0f/%.0f/%.0f/%.0f  tail(end-last) mean %.0f"
               % (k, start[m].min(), start[m].max(), *np.percentile(last[m], [10, 50, 90]), *np.percentile(end[m], [10, 50, 90]), end[m].max(),
                  (end[m] - last[m]).mean()))
