@@ -353,6 +353,9 @@ constexpr int kOctScratchRing = 4;    // launches of one scene's octree pool ker
 #ifndef HARE_PIN_ARGS
 #define HARE_PIN_ARGS 1
 #endif
+#ifndef HARE_K2D_SKIP_PID
+#define HARE_K2D_SKIP_PID 1
+#endif
 #ifndef HARE_K2D_AHEAD
 #define HARE_K2D_AHEAD 1           // the dense passes as a pipeline: list entries two windows ahead, pre-cull records one (round 6; with three
                                    // waves per SIMD: hall 1M rays 773 -> 808 Mrays/s, 4M 1 024 -> 1 058, cathedral 550 -> 601)

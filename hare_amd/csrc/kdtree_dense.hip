@@ -361,7 +361,8 @@ __device__ __forceinline__ void kdtree_dense_body(const KdArgs& g, const ShootIO
                     const int pos = take ? (int)__builtin_ctzll(seg) : lane;
                     const int poly = __shfl(i, pos, 64);
                     if (take) {
-                        if (poly != e1 && poly != e2) {                      // :221, applied by the owner
+                        // :221, applied by the owner -- and not the polygon the ray's hit lies on AGAIN (HARE_K2D_SKIP_PID, as K2d: the same t, never < closestT)
+                        if (poly != e1 && poly != e2 && !(HARE_K2D_SKIP_PID && hit && poly == pid)) {
                             pend_w[np * nt + tid] = poly;
                             ++np;
                         }

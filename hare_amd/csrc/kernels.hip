@@ -1391,7 +1391,10 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
                     const int pos = take ? (int)__builtin_ctzll(seg) : lane;
                     const int poly = __shfl(i, pos, 64);                     // every lane executes the shuffle
                     if (take) {
-                        if (poly != e1 && poly != e2) {                      // :218, applied by the owner
+                        // :218, applied by the owner -- and (round 6, HARE_K2D_SKIP_PID) the polygon the ray's hit lies on is not tested AGAIN: a polygon is
+                        // listed in every leaf it touches, the walk goes on behind a hit (F15), and the same ray against the same polygon yields
+                        // the same t bit for bit -- `t < closestT` (:225) fails, nothing changes.  Three of four exact tests were such repeats.
+                        if (poly != e1 && poly != e2 && !(HARE_K2D_SKIP_PID && hit && poly == pid)) {
                             pend_lca[np * nt + tid] = leaf_ca;
                             pend_w[np * nt + tid] = poly | (leaf_fresh ? (int)0x80000000 : 0);
                             leaf_fresh = false;
@@ -1455,7 +1458,7 @@ __device__ __forceinline__ void octree_persist_body(const OctreeArgs& g, const S
         auto load_rec = [&](int i) { return cull_load(g, i); };
         auto culled = [&](const CullRaw& r) { return cull_test(g, cray, r); };
         auto recently = [&](int i) {                                                                    // :218 (+ mailbox)
-            return i == e1 || i == e2 || (HARE_K2P_MAILBOX >= 1 && i == m0) || (HARE_K2P_MAILBOX >= 2 && i == m1) ||
+            return i == e1 || i == e2 || (HARE_K2D_SKIP_PID && hit && i == pid) || (HARE_K2P_MAILBOX >= 1 && i == m0) || (HARE_K2P_MAILBOX >= 2 && i == m1) ||
                    (HARE_K2P_MAILBOX >= 4 && (i == m2 || i == m3));
         };
 #pragma unroll 1

@@ -367,7 +367,9 @@ __device__ __forceinline__ void octree_group_body(const OctreeArgs& g, const Sho
                 K2G_STAT(st_l++; st_lg += __popcll(__ballot(scanning)) >> 3; st_ent += __popcll(__ballot(valid));)
                 int i = -1;
                 if (valid) i = g.items[k];
-                bool test = valid && i != e1 && i != e2;                                  // :218
+                // :218 -- and not the polygon the ray's hit lies on AGAIN (HARE_K2D_SKIP_PID, kernels.hip: the same ray against the same polygon yields the same t,
+                // which is never < closestT: nothing would change)
+                bool test = valid && i != e1 && i != e2 && !(HARE_K2D_SKIP_PID && hit && i == pid);
                 if (test) test = !cull_test(g, cray, cull_load(g, i));
                 const unsigned sm = gballot(test);
                 if (test) {

@@ -286,3 +286,32 @@ def test_exact_block_skip_option_changes_nothing_but_the_step_count():
                 for b in range(5):
                     assert_events_equal(evb[b], refb[b], what=f"bounce cast {b} voxel_skip={skip}")
         g.set_option("voxel_skip", 0)
+
+
+def test_trees_do_not_test_the_polygon_of_their_hit_again():
+    """`Octree.Shoot` walks on behind a hit (F15) and a polygon is listed in every leaf it touches: three of four exact tests of K2d were the
+    SAME ray against the SAME polygon its hit lies on -- the same t bit for bit, never `< closestT`, nothing changes.  The tree kernels skip
+    those (HARE_K2D_SKIP_PID: K2d, K2g, K2p, K3d).  Events equal to the oracle's (which tests them all); the counting builds show the repeats
+    gone: at most 1.5 exact tests per ray where the oracle makes 4 and more."""
+    import torch
+    from hare_amd import capi
+    m = H.scenes.hall()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    n = 200_000
+    rays = H.scenes.burst_rays(1 << 20, m.size)[::5][:n].copy()
+    d_rays = torch.from_numpy(rays).cuda()
+    d_out = torch.empty(n * 56, dtype=torch.uint8, device="cuda")
+    for name, g, o in (("octree", H.Octree([T], 8, 16), po.Octree([To], 8, 16)), ("kdtree", H.KDTree([T], 16, 8), po.KDTree([To], 16, 8))):
+        ref, rc = o.shoot(rays[:20_000], nthreads=16)
+        if name == "octree":
+            g.set_option("octree_kernel", 4)
+        d_ctr = torch.zeros(8, dtype=torch.int64, device="cuda")
+        assert g.kernel_name(n, flags=capi.SHOOT_COUNT_OWN).endswith("_dense_own")
+        g.shoot_device(n, d_rays.data_ptr(), d_out.data_ptr(), d_counters=d_ctr.data_ptr(), flags=capi.SHOOT_COUNT_OWN)
+        torch.cuda.synchronize()
+        ev = np.frombuffer(d_out.cpu().numpy().tobytes(), dtype=ref.dtype)
+        assert_events_equal(ev[:20_000], ref, what=name)
+        c = [int(x) for x in d_ctr.cpu()]
+        assert c[0] == n and c[1] > 0.9 * n, c
+        assert c[4] <= 1.5 * n, (name, "exact tests per ray", c[4] / n)
+        assert rc["tests"] >= 3.0 * len(ref) or name == "kdtree", (name, rc)       # what the reference's walk makes of the same rays
