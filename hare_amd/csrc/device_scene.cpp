@@ -546,7 +546,7 @@ void reserve_oct_scratch(Scene& s, const HipApi* H)
     const size_t stride = ((size_t)kOctTailHead + 20u * levels + 15u) & ~(size_t)15u;
     const size_t rec_bytes = (cus * p_per_cu * 4u * 64u * stride + 255u) & ~(size_t)255u;
     const size_t tail_spill = cus * (size_t)HARE_K2G_WAVES_PER_EU * 4u * 8u * spill_entries * 24u;
-    // ... but only what the scene's OPTIONS can launch (ADVICE, round 5): by the library's rule -- K2g below 196 608 rays, K2d above, K2d handing
+    // ... but only what the scene's OPTIONS can launch (ADVICE, round 5): by the library's rule -- K2g below 320 rays per CU, K2d above, K2d handing
     // nothing over -- no launch ever writes a hand-over record, and the blocks hold K2g's stack spill alone (nothing for trees up to
     // (kGroupStack - 8) / 7 levels: the 8-level bench tree reserves 0 bytes where round 5 held 0.7 GB per scene).  Records are reserved when
     // K2p is forced ("octree_kernel" 1), a developer hand-over rule is set, or the tree is too deep for K2d's LDS -- hare_scene_set_option

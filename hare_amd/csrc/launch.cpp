@@ -198,8 +198,15 @@ void read_env_options(SceneOptions& o)
 int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tickets, bool keep_half = false)
 {
     int64_t per_wave = n / ((int64_t)std::max(1u, pgrid) * 4);
-    if (keep_half) per_wave = per_wave / 2;          // K2d (swept, tools/k2d_static_sweep.sh): the optimum is half the share at every size below 786k rays
-    else if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
+    if (keep_half) {
+        // K2d (swept, tools/k2d_static_sweep.sh): the optimum is half the share at every size below 786k rays -- and (round 6) that holds for the
+        // caller-sized batches too, where a floor of 64 rays used to make the whole batch static: a wave that starts HALF full runs short rounds, and a
+        // short launch is the chain of its heaviest rays' rounds (131 072 rays: 32 static rays per wave 261 Mrays/s, 64: 208; 196 608: 330 / 271; 262 144:
+        // 48 static rays 397, 64: 366; profiles/r06_experiments/k2d_static_chunk_small_batches.log)
+        per_wave = per_wave / 2;
+        return (int32_t)std::max<int64_t>(16, std::min<int64_t>(128, per_wave / 8 * 8));      // never MORE than half: a wave that starts fuller than that ends late
+    }
+    if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
     return (int32_t)std::max<int64_t>(64, std::min<int64_t>(128, per_wave / 32 * 32));
 }
 size_t voxel_scene_bytes(const Scene& s, size_t top)
@@ -344,7 +351,9 @@ KernChoice choose_kernel(const Scene& s, const DeviceModule* M, int32_t kind, si
             // (second half of round 4: K2d no longer spends a pop step on an exhausted frame, forms its slabs in cursor order and keeps HALF
             //  of a wave's share for tickets -- K2d / K2g at 131k 159 / 180, 196k 235 / 225, 262k 293 / 255, 393k 418 / 283, 524k 474 / 304:
             //  the crossover is a ray for every lane of K2d's grid, 768 per CU)
-            const int64_t group_below = (int64_t)cus * 768;           // 196 608 rays on the 256-CU part
+            // (round 6: K2d's static first chunk is half a wave's share at EVERY size -- a floor of 64 rays used to make a small batch all static --
+            //  and the crossover fell: K2d / K2g at 65 536 rays 123 / 135, 81 920 169 / 152, 98 304 188 / 168, 131 072 263 / 217 Mrays/s)
+            const int64_t group_below = (int64_t)cus * 320;           // 81 920 rays on the 256-CU part
             const bool group_wanted = s.opt.octree_kernel == 3 || (s.opt.octree_kernel == 0 && (n < group_below || !fits_p));
             if (group_wanted && group_ok) {
                 if (own) { c = KernChoice(); return c; }          // no counting build of K2g: the caller is told so
@@ -866,7 +875,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             const unsigned plds = (unsigned)g.max_depth * 256u * 20u + (dense_k ? kOctDenseExtra : 0u);
             unsigned per_cu = std::min((unsigned)(dense_k ? HARE_K2D_WAVES_PER_EU : HARE_K2P_WAVES_PER_EU), std::max(1u, (unsigned)(kLdsMax / plds)));
             unsigned pgrid = cus * per_cu;
-            pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);
+            pgrid = std::min<unsigned>(pgrid, (unsigned)((m + 63) / 64 + 3) / 4);      // (a wave for every 32 rays of a small batch was measured: no better)
             if (pgrid == 0) pgrid = 1;
             // an octree ray costs ~10x a voxel ray: ticket atomics never bind.  K2p: 32 rays; K2d finishes rays sooner and likes 16
             // (8 / 16 / 24 / 32 rays per ticket: 1M rays 478 / 502 / 466 / 489 Mrays/s, 1.5M 553 / 570 / 569 / 563, 524k 353 / 354 / 348 / 346)
@@ -877,7 +886,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             if (dense_k && !(s.opt.tune[0] > 0 && s.opt.tune[1] > 0)) sub.refill_min_idle = m < (int64_t)cus * kK2dShortBatchPerCu ? 32 : 16;
             sub.static_rays = static_chunk_rays(m, pgrid, true, dense_k);    // K2p: 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336; K2d: half
                                                                              // the share (393k rays 338 -> 418 Mrays/s, 524k 421 -> 474, 655k 393 -> 515)
-            if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(32, std::min(256, s.opt.k2p_static_rays / 32 * 32));   // developer sweeps
+            if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(8, std::min(256, s.opt.k2p_static_rays / 8 * 8));   // developer sweeps
             void* a[] = {&g, &sub};
             // The closest-hit kernel hands rays to a tail kernel (the occlusion build keeps them).  Rule: K2g-tail takes EVERY ray a wave
             // still walks when the tickets run dry (option "octree_tail" 2, the default); K2t takes a wave's last sixteen after 64 rounds (1)

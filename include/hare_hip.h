@@ -183,7 +183,7 @@ HARE_API void hare_scene_destroy(hare_scene *s);
  * HARE_BATCH_CHUNKS, HARE_OCTREE_TIGHT, HARE_VOXEL_TIGHT, HARE_TUNE): no call reads the environment afterwards.  Options:
  *   "build_host"      1: host builders even when a GPU is present (identical lists either way)
  *   "voxel_kernel"    0: the library's rule, 1: hare_voxel_persist_* (K1p), 2: hare_voxel_pool_* (K1q)
- *   "octree_kernel"   0: the library's rule (K2g below 196 608 rays on a 256-CU part, K2d from there), 1: hare_octree_persist (K2p, one lane per ray),
+ *   "octree_kernel"   0: the library's rule (K2g below 81 920 rays on a 256-CU part -- 320 per CU --, K2d from there), 1: hare_octree_persist (K2p, one lane per ray),
  *                     2: hare_octree_pool (K2q), 3: hare_octree_group (K2g, eight lanes per ray), 4: hare_octree_dense (K2d: K2p with its leaf
  *                     entries spread densely over the wave and its exact tests deferred)
  *   "bounce_fused"    1: hare_bounce_device / hare_bounce_batch (last cast's events only) run a Voxel_Grid's bounce loop as ONE launch where they can; 0 (default): a launch per cast

@@ -117,11 +117,11 @@ def test_bounce_device_without_a_gpu_fails_loudly_and_the_kernel_name_query_foll
 
 
 def test_the_kernel_rule_for_octree_batches_and_the_tight_box_options():
-    """The K2g / K2d crossover is a ray per lane of K2d's grid (196 608 rays on the 256-CU part the rule assumes without a device); the
+    """The K2g / K2d crossover is 320 rays per CU (81 920 rays on the 256-CU part the rule assumes without a device; round 6: it was 768); the
     tight-box switches are scene options with values 0 / 1 (anything else is refused), and an unknown name is an error, not a no-op."""
     m = H.scenes.shoebox()
     o = H.Octree([H.Topology(m.verts, m.nverts)], 4, 8)
-    assert o.kernel_name(196_607) == "hare_octree_group" and o.kernel_name(196_608) == "hare_octree_dense"
+    assert o.kernel_name(81_919) == "hare_octree_group" and o.kernel_name(81_920) == "hare_octree_dense"
     for name in ("octree_tight", "voxel_tight"):
         o.set_option(name, 0)
         o.set_option(name, 1)

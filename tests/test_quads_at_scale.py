@@ -69,9 +69,12 @@ def test_one_million_burst_rays_into_the_quad_hall_voxel_and_octree(scene):
     ev, c = oc.Shoot_batch(rays)
     assert_events_equal(ev, ref, what="octree, 1M rays, quads")
     assert c["hits"] == rc["hits"]
-    small = rays[:100_000]                                              # ... and the kernel small batches get (eight lanes per ray)
+    small = rays[:60_000]                                               # ... and the kernel small batches get (eight lanes per ray: below 320 rays per CU)
     assert oc.kernel_name(len(small)) == "hare_octree_group"
-    assert_events_equal(oc.Shoot_batch(small)[0], ref[:100_000], what="octree, 100k rays, quads")
+    assert_events_equal(oc.Shoot_batch(small)[0], ref[:60_000], what="octree, 60k rays, quads")
+    mid = rays[:100_000]                                                # ... and K2d with half-full waves (round 6: from 81 920 rays)
+    assert oc.kernel_name(len(mid)) == "hare_octree_dense"
+    assert_events_equal(oc.Shoot_batch(mid)[0], ref[:100_000], what="octree, 100k rays, quads")
 
 
 @pytest.mark.gpu
