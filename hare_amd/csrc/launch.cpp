@@ -195,10 +195,10 @@ void read_env_options(SceneOptions& o)
 // is cheap against the ~30 ns of a ticket draw, so K1p takes the whole per-wave share statically (393k rays: 0.286 ms, with a
 // quarter kept for tickets 0.335); an octree ray costs ten times as much and the end of the batch matters more than the
 // tickets, so K2p keeps a quarter of the share for them (524k rays: 2.34 ms against 2.61 all static).
-int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tickets, bool keep_half = false)
+int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tickets, bool keep_half = false, bool half_at_every_size = false)
 {
     int64_t per_wave = n / ((int64_t)std::max(1u, pgrid) * 4);
-    if (keep_half) {
+    if (keep_half && half_at_every_size) {
         // K2d (swept, tools/k2d_static_sweep.sh): the optimum is half the share at every size below 786k rays -- and (round 6) that holds for the
         // caller-sized batches too, where a floor of 64 rays used to make the whole batch static: a wave that starts HALF full runs short rounds, and a
         // short launch is the chain of its heaviest rays' rounds (131 072 rays: 32 static rays per wave 261 Mrays/s, 64: 208; 196 608: 330 / 271; 262 144:
@@ -206,7 +206,9 @@ int32_t static_chunk_rays(int64_t n, unsigned pgrid, bool keep_a_quarter_for_tic
         per_wave = per_wave / 2;
         return (int32_t)std::max<int64_t>(16, std::min<int64_t>(128, per_wave / 8 * 8));      // never MORE than half: a wave that starts fuller than that ends late
     }
-    if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
+    // (K3d keeps the floor: its 16 waves per CU hold cheaper rays -- the hall at 262 144 rays 64 static rays per wave 406 Mrays/s, 32: 355; 393 216: 501 / 436)
+    if (keep_half) per_wave = per_wave / 2;
+    else if (keep_a_quarter_for_tickets) per_wave = per_wave * 3 / 4;
     return (int32_t)std::max<int64_t>(64, std::min<int64_t>(128, per_wave / 32 * 32));
 }
 size_t voxel_scene_bytes(const Scene& s, size_t top)
@@ -884,7 +886,7 @@ int shoot_device_impl(Scene& s, const HipApi* H, int32_t kind, int32_t top, int6
             // swept (k2d_refill_by_size.log), 16 / 24 / 32 / 48 idle lanes: 196 608 rays 247 / 249 / 251 / 251 Mrays/s, 262 144 317 / 336 / 341 / 340,
             // 393 216 489 / 495 / 471 / 395, 524 288 559 / 556 / 558 / 530, 655 360 662 / 649 / 624 / 587, 1M 775 / 775 / 757 / 676
             if (dense_k && !(s.opt.tune[0] > 0 && s.opt.tune[1] > 0)) sub.refill_min_idle = m < (int64_t)cus * kK2dShortBatchPerCu ? 32 : 16;
-            sub.static_rays = static_chunk_rays(m, pgrid, true, dense_k);    // K2p: 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336; K2d: half
+            sub.static_rays = static_chunk_rays(m, pgrid, true, dense_k, dense_k);    // K2p: 262k rays 2.607 -> 1.861 ms, 524k 2.569 -> 2.336; K2d: half
                                                                              // the share (393k rays 338 -> 418 Mrays/s, 524k 421 -> 474, 655k 393 -> 515)
             if (s.opt.k2p_static_rays > 0) sub.static_rays = std::max(8, std::min(256, s.opt.k2p_static_rays / 8 * 8));   // developer sweeps
             void* a[] = {&g, &sub};
