@@ -64,7 +64,20 @@ def main(src):
         sys.exit("condense_profiles: %s holds csv files more than an hour apart -- remove the older run's files first" % src)
     rows = [("config", "kernel", "counter", "mean_per_dispatch", "dispatches")]
     traffic = {}
+    # ONLY="c3_262k": a re-take of some configurations -- the other configurations' rows of <round>_pmc_summary.csv and their entries of
+    # traffic.json are kept as they are (without it, everything not in `src` is dropped from both files)
+    only = os.environ.get("ONLY", "").split()
+    kept_rows, kept_traffic = [], {}
+    if only:
+        ps = os.path.join(out, f"{ROUND}_pmc_summary.csv")
+        if os.path.exists(ps):
+            kept_rows = [tuple(ln.split(",")) for ln in open(ps).read().splitlines()[1:] if ln and ln.split(",")[0] not in only]
+        tj0 = os.path.join(out, "traffic.json")
+        if os.path.exists(tj0):
+            kept_traffic = {k: v for k, v in json.load(open(tj0)).items() if k not in [KEYS[t] for t in only if t in KEYS]}
     for tag, key in KEYS.items():
+        if only and tag not in only:
+            continue
         ks = glob.glob(os.path.join(src, tag + "_kt", "**", "*kernel_stats.csv"), recursive=True)
         if ks:
             lines = open(ks[0]).read().splitlines()
@@ -108,6 +121,7 @@ def main(src):
             txt = [ln for ln in open(b).read().splitlines() if ln.startswith("{")]
             if txt:
                 open(os.path.join(out, f"{ROUND}_{tag}_bench.json"), "w").write(txt[-1] + "\n")
+    rows = rows[:1] + kept_rows + rows[1:]
     with open(os.path.join(out, f"{ROUND}_pmc_summary.csv"), "w") as f:
         for r in rows:
             f.write(",".join(str(x) for x in r) + "\n")
@@ -115,6 +129,7 @@ def main(src):
     tj = os.path.join(out, "traffic.json")
     if os.path.exists(tj):
         old = {k: v for k, v in json.load(open(tj)).items() if k not in traffic and "(" in k}     # keep the labelled history entries
+    old.update(kept_traffic)
     old.update(traffic)
     json.dump(old, open(tj, "w"), indent=1)
     for r in rows:
