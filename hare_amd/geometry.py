@@ -245,8 +245,10 @@ class Spatial_Partition:
         slim=True: the events come back as slim records (capi.SLIM_DTYPE for Voxel_Grid, SLIM_UV_DTYPE for the trees; 16 / 32
         bytes over the host link instead of 56); expand_events(rays, records) rebuilds the X_Events bit for bit.
         ray_ids (optional, one Ray_ID per ray) only matters with `mailbox_ray_id0` on: entries equal to 0 come back as miss records."""
-        if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
-            rays = np.array(rays, np.float64, order="C")
+        if writeback_origin and not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous):
+            rays = np.array(rays, np.float64, order="C")              # nothing of the caller's to write back into
+        else:
+            rays = np.ascontiguousarray(rays, np.float64)             # without the flag the library only reads them: no copy of 48 B per ray
         rays = rays.reshape(-1, 6)
         n = rays.shape[0]
         out = np.zeros(n, self._slim_dtype() if slim else XEVENT_DTYPE)
@@ -292,8 +294,10 @@ class Spatial_Partition:
         parts = list(partitions)
         if not parts or any(p._kind != parts[0]._kind for p in parts):
             raise ValueError("need one or more partitions of the same kind")
-        if not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous and writeback_origin):
-            rays = np.array(rays, np.float64, order="C")
+        if writeback_origin and not (isinstance(rays, np.ndarray) and rays.dtype == np.float64 and rays.flags.c_contiguous):
+            rays = np.array(rays, np.float64, order="C")              # nothing of the caller's to write back into
+        else:
+            rays = np.ascontiguousarray(rays, np.float64)             # without the flag the library only reads them: no copy of 48 B per ray
         rays = rays.reshape(-1, 6)
         n = rays.shape[0]
         out = np.zeros(n, parts[0]._slim_dtype() if slim else XEVENT_DTYPE)
