@@ -129,3 +129,32 @@ def test_the_kernel_rule_for_octree_batches_and_the_tight_box_options():
             o.set_option(name, 2)
     with pytest.raises(H.HareError):
         o.set_option("octree_tights", 1)
+
+
+def test_the_callers_result_array_is_checked_never_converted():
+    """`out=` of the host-buffer calls of the Python mirror (Shoot_batch, Shoot_batch_sharded, Bounce_batch, Bounce_batch_sharded): the
+    library writes straight into the caller's array, so a wrong length, record type, layout or a read-only array is a ValueError before
+    anything is called -- never a silent copy.  (What it is for: a caller that keeps its result array across calls does not pay a fresh
+    array's page faults, tests/test_gpu_round6.py.)  Needs no GPU: a good array gets as far as the library, which has no CPU path."""
+    m = H.scenes.shoebox()
+    g = H.Voxel_Grid([H.Topology(m.verts, m.nverts)], 8)
+    rays = H.scenes.burst_rays(100, m.size)
+    ro = np.zeros(100, capi.XEVENT_DTYPE)
+    ro.flags.writeable = False
+    bad = (np.zeros(99, capi.XEVENT_DTYPE), np.zeros(100, capi.SLIM_DTYPE), np.zeros((100, 7)), np.zeros(200, capi.XEVENT_DTYPE)[::2], ro, [0] * 100)
+    SP = H.Spatial_Partition
+    for b in bad:
+        for call in (lambda: g.Shoot_batch(rays, out=b), lambda: SP.Shoot_batch_sharded([g], rays, out=b),
+                     lambda: g.Bounce_batch(rays, 3, out=b), lambda: SP.Bounce_batch_sharded([g], rays, 3, out=b)):
+            with pytest.raises(ValueError, match="out must be"):
+                call()
+    with pytest.raises(ValueError, match="out must be"):
+        g.Bounce_batch(rays, 3, all_casts=True, out=np.zeros(100, capi.XEVENT_DTYPE))          # all casts: [bounces, n]
+    with pytest.raises(ValueError, match="out must be"):
+        g.Shoot_batch(rays, slim=True, out=np.zeros(100, capi.XEVENT_DTYPE))                   # slim records are another type
+    if H.device_count() == 0:
+        for call in (lambda: g.Shoot_batch(rays, out=np.zeros(100, capi.XEVENT_DTYPE)), lambda: g.Shoot_batch(rays, slim=True, out=np.zeros(100, capi.SLIM_DTYPE)),
+                     lambda: g.Bounce_batch(rays, 3, all_casts=True, out=np.zeros((3, 100), capi.XEVENT_DTYPE))):
+            with pytest.raises(H.HareError) as ei:
+                call()
+            assert ei.value.code == capi.HARE_E_NODEVICE

@@ -315,3 +315,44 @@ def test_trees_do_not_test_the_polygon_of_their_hit_again():
         assert c[0] == n and c[1] > 0.9 * n, c
         assert c[4] <= 1.5 * n, (name, "exact tests per ray", c[4] / n)
         assert rc["tests"] >= 3.0 * len(ref) or name == "kdtree", (name, rc)       # what the reference's walk makes of the same rays
+
+
+def test_host_buffer_calls_write_into_the_callers_array_and_only_read_its_rays():
+    """The Python mirror's host-buffer calls with `out=`: the events land in the caller's array (the same object comes back), byte for byte
+    what a call without it returns and what the oracle says, call after call into the same array (a stale record would show: the second
+    batch differs from the first), sharded or not, the bounce loop too.  And a call without `writeback_origin` only READS the rays: the
+    mirror passes the caller's array itself (no defensive copy any more) and its bytes are what they were."""
+    from hare_amd import capi
+    m = H.scenes.hall()
+    T, To = H.Topology(m.verts, m.nverts), po.Topology(m.verts, m.nverts)
+    g, g2, o = H.Voxel_Grid([T], 64), H.Voxel_Grid([T], 64), po.VoxelGrid([To], domain=64)
+    n = 50_000
+    all_rays = H.scenes.burst_rays(1 << 20, m.size)
+    ra, rb = all_rays[:n].copy(), all_rays[7 * n:8 * n].copy()
+    ra[::3, :3] += 40.0                                      # origins outside the grid: the rays a write-back would move
+    SP = H.Spatial_Partition
+    out = np.zeros(n, capi.XEVENT_DTYPE)
+    for rays in (ra, rb):
+        before = rays.tobytes()
+        ref, rc = o.shoot(rays, nthreads=16)
+        ev, c = g.Shoot_batch(rays, out=out)
+        assert ev is out and c["hits"] == rc["hits"]
+        assert_events_equal(out, ref, what="Shoot_batch out=")
+        assert out.tobytes() == g.Shoot_batch(rays)[0].tobytes()
+        out[:] = 0
+        ev, c = SP.Shoot_batch_sharded([g, g2], rays, out=out)
+        assert ev is out and c["hits"] == rc["hits"]
+        assert_events_equal(out, ref, what="Shoot_batch_sharded out=")
+        assert rays.tobytes() == before
+    sl = np.zeros(n, capi.SLIM_DTYPE)
+    assert g.Shoot_batch(rb, slim=True, out=sl)[0] is sl
+    assert g.expand_events(rb, sl).tobytes() == out.tobytes()
+    refb, _ = oracle_bounce_loop(po, To, o, rb, 4)
+    before = rb.tobytes()
+    allc = np.zeros((4, n), capi.XEVENT_DTYPE)
+    assert g.Bounce_batch(rb, 4, all_casts=True, out=allc)[0] is allc
+    assert SP.Bounce_batch_sharded([g, g2], rb, 4, out=out)[0] is out
+    for b in range(4):
+        assert_events_equal(allc[b], refb[b], what=f"Bounce_batch out=, cast {b}")
+    assert_events_equal(out, refb[3], what="Bounce_batch_sharded out=, last cast")
+    assert rb.tobytes() == before
