@@ -943,6 +943,9 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, the two must agree")
 
+    # dmabuf IPC is the only kind this pool's host driver supports (RCCL over xGMI needs it); exported on the boxes already, and set here
+    # for a launcher that dropped it -- before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     if not torch.cuda.is_available():
