@@ -965,11 +965,25 @@ def main() -> None:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
-            # RCCL builds its communicator on the first collective: do that here, never inside the timed region
-            _t = torch.zeros(8, dtype=torch.int64, device="cuda")
-            dist.all_reduce(_t)
-            torch.cuda.synchronize()
+            # RCCL prints a version banner on STDOUT when it builds its first communicator: the contract is ONE JSON line there, so the
+            # process's fd 1 points at stderr while that happens (a C library's printf does not go through sys.stdout)
+            sys.stdout.flush()
+            _fd1 = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+                # RCCL builds its communicator on the first collective: do that here, never inside the timed region
+                _t = torch.zeros(8, dtype=torch.int64, device="cuda")
+                dist.all_reduce(_t)
+                torch.cuda.synchronize()
+            finally:
+                try:
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)          # whatever the C side still holds in its stdio buffer goes where fd 1 points NOW
+                except Exception:
+                    pass
+                os.dup2(_fd1, 1)
+                os.close(_fd1)
         else:
             dist.init_process_group(backend="gloo")
             dist.all_reduce(torch.zeros(8, dtype=torch.int64))

@@ -22,6 +22,9 @@ def _bench(*args):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # ONE JSON line and nothing else on stdout: RCCL's version banner (printed by the C library when the first communicator is built)
+    # goes to stderr (bench.py points fd 1 there while the process group comes up)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[:2000]
     assert len(lines[0]) < 8000, len(lines[0])         # the driver keeps the last 8 KB of stdout: the whole line must survive
     return json.loads(lines[0])
 
